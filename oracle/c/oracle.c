@@ -1,0 +1,446 @@
+/* ORACLE -- test infrastructure, NOT product code.
+ *
+ * Plain-C / OpenMP restatement ("port") of the reference's CPU path for the
+ * gpu-poly hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load the shared object built from this file; the
+ * product library (libministark_hip.so) never links or calls it.
+ *
+ * The reference's own CPU path is arkworks (ark-poly 0.4.2 / ark-ff 0.4.2 /
+ * ark-ff-optimized 0.4.1, un-vendored crates pinned in Cargo.lock) + sha2 +
+ * rayon; none of it can be built here (no Rust toolchain), so this file
+ * restates the algorithms at the reference's call sites:
+ *
+ *   Goldilocks Montgomery arithmetic ... gpu/src/metal/felt_u64.h.metal:147-177
+ *   NTT / iNTT, coset pre/post scaling . src/matrix.rs:119-139,166-190;
+ *                                        gpu/src/plan.rs:254-263,300-309,386-424
+ *   bit reversal ...................... gpu/src/utils.rs:4-41
+ *   LDE ............................... src/prover.rs:50-51; src/matrix.rs:225-251
+ *   row hashing + Merkle nodes ........ src/merkle.rs:412-508; src/hash.rs:77-99
+ *   FRI fold (apply_drp) .............. src/fri.rs:526-567
+ *   element-wise stages ............... gpu/src/metal/evaluation_shaders.h.metal:11-168
+ *
+ * All field data is in the reference's memory format: Montgomery residues
+ * (R = 2^64) as u64; an Fq3 element is 3 consecutive u64 (c0,c1,c2).
+ * "V" below is the number of u64 words per element (1 = Fp, 3 = Fq3); base
+ * field twiddles act component-wise (ark-poly DomainCoeff), so an Fq3
+ * transform is 3 interleaved Fp transforms.
+ *
+ * Pinned against: oracle/pyref (independent big-int Python) on the
+ * reference's test shapes, and the reference's in-tree constants
+ * (tests/test_oracle_kat.py).  Parity for FFT/LDE/FRI outputs is otherwise
+ * unpinned by stored vectors (the reference stores none).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_ONE 0xFFFFFFFFULL            /* R mod p   (felt_u64.h.metal:118) */
+#define GL_R2 18446744065119617025ULL   /* R^2 mod p (felt_u64.h.metal:127) */
+
+/* ---- Goldilocks, Montgomery form ------------------------------------- */
+static inline uint64_t gl_add(uint64_t a, uint64_t b) {
+    uint64_t tmp = GL_P - b;               /* a + b = a - (p - b) */
+    uint64_t x = a - tmp;
+    return (a < tmp) ? x + GL_P : x;
+}
+static inline uint64_t gl_sub(uint64_t a, uint64_t b) {
+    uint64_t x = a - b;
+    return (a < b) ? x + GL_P : x;
+}
+static inline uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
+/* Montgomery product a*b*R^-1 mod p */
+static inline uint64_t gl_mul(uint64_t a, uint64_t b) {
+    u128 x = (u128)a * b;
+    uint64_t xl = (uint64_t)x, xh = (uint64_t)(x >> 64);
+    uint64_t tmp = xl << 32;
+    uint64_t s = xl + tmp;
+    uint64_t ov = s < xl;
+    uint64_t bb = s - (s >> 32) - ov;
+    uint64_t r = xh - bb;
+    return (xh < bb) ? r + GL_P : r;
+}
+static inline uint64_t gl_to_mont(uint64_t canon) { return gl_mul(canon, GL_R2); }
+static inline uint64_t gl_from_mont(uint64_t m) { return gl_mul(m, 1); }
+static uint64_t gl_pow(uint64_t a, uint64_t e) {
+    uint64_t r = GL_ONE;
+    while (e) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); e >>= 1; }
+    return r;
+}
+static inline uint64_t gl_inv(uint64_t a) { return gl_pow(a, GL_P - 2); }
+
+uint64_t oracle_gl_to_mont(uint64_t c) { return gl_to_mont(c % GL_P); }
+uint64_t oracle_gl_from_mont(uint64_t m) { return gl_from_mont(m); }
+uint64_t oracle_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a, b); }
+uint64_t oracle_gl_add(uint64_t a, uint64_t b) { return gl_add(a, b); }
+uint64_t oracle_gl_sub(uint64_t a, uint64_t b) { return gl_sub(a, b); }
+uint64_t oracle_gl_inv(uint64_t a) { return gl_inv(a); }
+uint64_t oracle_gl_pow(uint64_t a, uint64_t e) { return gl_pow(a, e); }
+
+/* 2^32-th root of unity 7^((p-1)/2^32), canonical */
+#define GL_TWO_ADIC_ROOT 1753635133440165772ULL
+uint64_t oracle_gl_root_of_unity(unsigned log_n) { /* Montgomery form */
+    uint64_t r = gl_to_mont(GL_TWO_ADIC_ROOT);
+    for (unsigned i = log_n; i < 32; i++) r = gl_mul(r, r);
+    return r;
+}
+
+/* ---- Fq3 = Fp[x]/(x^3-2), Montgomery components ----------------------- */
+typedef struct { uint64_t c0, c1, c2; } fq3;
+static inline fq3 fq3_add(fq3 a, fq3 b) { fq3 r = {gl_add(a.c0,b.c0), gl_add(a.c1,b.c1), gl_add(a.c2,b.c2)}; return r; }
+static inline fq3 fq3_sub(fq3 a, fq3 b) { fq3 r = {gl_sub(a.c0,b.c0), gl_sub(a.c1,b.c1), gl_sub(a.c2,b.c2)}; return r; }
+static inline fq3 fq3_neg(fq3 a) { fq3 r = {gl_neg(a.c0), gl_neg(a.c1), gl_neg(a.c2)}; return r; }
+static inline uint64_t gl_dbl(uint64_t a) { return gl_add(a, a); }
+static inline fq3 fq3_mul(fq3 a, fq3 b) {       /* schoolbook, x^3 = 2 */
+    uint64_t t00 = gl_mul(a.c0,b.c0), t01 = gl_mul(a.c0,b.c1), t02 = gl_mul(a.c0,b.c2);
+    uint64_t t10 = gl_mul(a.c1,b.c0), t11 = gl_mul(a.c1,b.c1), t12 = gl_mul(a.c1,b.c2);
+    uint64_t t20 = gl_mul(a.c2,b.c0), t21 = gl_mul(a.c2,b.c1), t22 = gl_mul(a.c2,b.c2);
+    fq3 r;
+    r.c0 = gl_add(t00, gl_dbl(gl_add(t12, t21)));
+    r.c1 = gl_add(gl_add(t01, t10), gl_dbl(t22));
+    r.c2 = gl_add(gl_add(t02, t11), t20);
+    return r;
+}
+static inline fq3 fq3_mul_fp(fq3 a, uint64_t s) { fq3 r = {gl_mul(a.c0,s), gl_mul(a.c1,s), gl_mul(a.c2,s)}; return r; }
+static fq3 fq3_pow(fq3 a, uint64_t e) {
+    fq3 r = {GL_ONE, 0, 0};
+    while (e) { if (e & 1) r = fq3_mul(r, a); a = fq3_mul(a, a); e >>= 1; }
+    return r;
+}
+/* inverse via norm: for t = x^3 - 2.  N(a) = a * a^p * a^(p^2) in Fp.  We use
+ * the adjugate formula of the multiplication matrix (exact, any correct
+ * formula agrees with arkworks' CubicExtField::inverse). */
+static fq3 fq3_inv(fq3 a) {
+    /* a = c0 + c1 x + c2 x^2, x^3 = 2:
+       s0 = c0^2 - 2 c1 c2 ; s1 = 2 c2^2 - c0 c1 ; s2 = c1^2 - c0 c2
+       n  = c0 s0 + 2 (c2 s1 + c1 s2) ;  a^-1 = (s0, s1, s2) / n            */
+    uint64_t s0 = gl_sub(gl_mul(a.c0,a.c0), gl_dbl(gl_mul(a.c1,a.c2)));
+    uint64_t s1 = gl_sub(gl_dbl(gl_mul(a.c2,a.c2)), gl_mul(a.c0,a.c1));
+    uint64_t s2 = gl_sub(gl_mul(a.c1,a.c1), gl_mul(a.c0,a.c2));
+    uint64_t n = gl_add(gl_mul(a.c0,s0), gl_dbl(gl_add(gl_mul(a.c2,s1), gl_mul(a.c1,s2))));
+    uint64_t ni = gl_inv(n);
+    fq3 r = {gl_mul(s0,ni), gl_mul(s1,ni), gl_mul(s2,ni)};
+    return r;
+}
+void oracle_fq3_mul(const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    fq3 x = {a[0],a[1],a[2]}, y = {b[0],b[1],b[2]}; fq3 r = fq3_mul(x,y);
+    out[0]=r.c0; out[1]=r.c1; out[2]=r.c2;
+}
+void oracle_fq3_inv(const uint64_t* a, uint64_t* out) {
+    fq3 x = {a[0],a[1],a[2]}; fq3 r = fq3_inv(x); out[0]=r.c0; out[1]=r.c1; out[2]=r.c2;
+}
+
+/* ---- bit reversal ------------------------------------------------------ */
+static inline size_t bitrev(size_t i, unsigned log_n) {
+    size_t r = 0;
+    for (unsigned b = 0; b < log_n; b++) { r = (r << 1) | (i & 1); i >>= 1; }
+    return r;
+}
+/* in-place, elements of V words; only the first `prefix` positions take part
+ * (prefix = n for a full reversal; prefix < n is prover.rs:185-194's
+ * bit_reverse_ce_trace, a reversal of the size-`prefix` prefix). */
+void oracle_bit_reverse(uint64_t* data, unsigned log_n, unsigned V) {
+    size_t n = (size_t)1 << log_n;
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        size_t j = bitrev(i, log_n);
+        if (j > i) for (unsigned v = 0; v < V; v++) {
+            uint64_t t = data[i*V+v]; data[i*V+v] = data[j*V+v]; data[j*V+v] = t;
+        }
+    }
+}
+
+/* ---- NTT --------------------------------------------------------------- */
+/* In-place radix-2 transform of one column of n elements x V words.
+ * root, offset, scale in Montgomery form.
+ *   forward: x_i *= offset^i ; DFT(root)
+ *   inverse: DFT(root) ; x_i *= scale * offset^i   (root = gen^-1,
+ *            offset = offset^-1, scale = n^-1 supplied by the caller)      */
+static void ntt_core(uint64_t* a, unsigned log_n, unsigned V, const uint64_t* tw /* n/2 powers of root */) {
+    size_t n = (size_t)1 << log_n;
+    oracle_bit_reverse(a, log_n, V);
+    for (unsigned s = 1; s <= log_n; s++) {
+        size_t m = (size_t)1 << s, half = m >> 1, tstride = n >> s;
+        #pragma omp parallel for schedule(static)
+        for (size_t k = 0; k < n / 2; k++) {
+            size_t blk = k / half, i = k % half;
+            size_t lo = blk * m + i, hi = lo + half;
+            uint64_t w = tw[i * tstride];
+            for (unsigned v = 0; v < V; v++) {
+                uint64_t u = a[lo*V+v], t = gl_mul(a[hi*V+v], w);
+                a[lo*V+v] = gl_add(u, t);
+                a[hi*V+v] = gl_sub(u, t);
+            }
+        }
+    }
+}
+static uint64_t* make_twiddles(unsigned log_n, uint64_t root) {
+    size_t half = ((size_t)1 << log_n) / 2;
+    if (half == 0) half = 1;
+    uint64_t* tw = (uint64_t*)malloc(half * sizeof(uint64_t));
+    /* chunked powers like gpu/src/utils.rs:13-30 (fill_twiddles) */
+    size_t chunk = 1024;
+    #pragma omp parallel for schedule(static)
+    for (size_t c = 0; c < (half + chunk - 1) / chunk; c++) {
+        size_t s = c * chunk, e = s + chunk < half ? s + chunk : half;
+        uint64_t x = gl_pow(root, s);
+        for (size_t i = s; i < e; i++) { tw[i] = x; x = gl_mul(x, root); }
+    }
+    return tw;
+}
+static void distribute_powers(uint64_t* a, size_t n, unsigned V, uint64_t g, uint64_t c) {
+    /* a_i *= c * g^i   (gpu/src/utils.rs:139-156) */
+    size_t chunk = 4096;
+    #pragma omp parallel for schedule(static)
+    for (size_t b = 0; b < (n + chunk - 1) / chunk; b++) {
+        size_t s = b * chunk, e = s + chunk < n ? s + chunk : n;
+        uint64_t x = gl_mul(c, gl_pow(g, s));
+        for (size_t i = s; i < e; i++) {
+            for (unsigned v = 0; v < V; v++) a[i*V+v] = gl_mul(a[i*V+v], x);
+            x = gl_mul(x, g);
+        }
+    }
+}
+/* offset_canon: canonical (non-Montgomery) integer of the coset offset. */
+void oracle_ntt(uint64_t* a, unsigned log_n, unsigned V, int inverse, uint64_t offset_canon) {
+    size_t n = (size_t)1 << log_n;
+    uint64_t gen = oracle_gl_root_of_unity(log_n);
+    uint64_t off = gl_to_mont(offset_canon % GL_P);
+    if (!inverse) {
+        if (off != GL_ONE) distribute_powers(a, n, V, off, GL_ONE);
+        uint64_t* tw = make_twiddles(log_n, gen);
+        ntt_core(a, log_n, V, tw);
+        free(tw);
+    } else {
+        uint64_t* tw = make_twiddles(log_n, gl_inv(gen));
+        ntt_core(a, log_n, V, tw);
+        free(tw);
+        uint64_t size_inv = gl_inv(gl_to_mont((uint64_t)n % GL_P));
+        distribute_powers(a, n, V, gl_inv(off), size_inv);
+    }
+}
+void oracle_ntt_columns(uint64_t** cols, unsigned ncols, unsigned log_n, unsigned V, int inverse, uint64_t offset_canon) {
+    for (unsigned c = 0; c < ncols; c++) oracle_ntt(cols[c], log_n, V, inverse, offset_canon);
+}
+
+/* LDE of one column: in (n elems) -> out (n*2^log_blowup elems), bit-reversed
+ * when bit_reversed != 0.  src/prover.rs:50-51. `in` is left untouched. */
+void oracle_lde(const uint64_t* in, uint64_t* out, unsigned log_n, unsigned log_blowup, unsigned V,
+                uint64_t offset_canon, int bit_reversed) {
+    size_t n = (size_t)1 << log_n, N = n << log_blowup;
+    memcpy(out, in, n * V * sizeof(uint64_t));
+    oracle_ntt(out, log_n, V, 1, 1);
+    memset(out + n * V, 0, (N - n) * V * sizeof(uint64_t));
+    oracle_ntt(out, log_n + log_blowup, V, 0, offset_canon);
+    if (bit_reversed) oracle_bit_reverse(out, log_n + log_blowup, V);
+}
+
+/* ---- SHA-256 ----------------------------------------------------------- */
+static const uint32_t K256[64] = {
+0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,
+0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,
+0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,0x5cb0a9dc,0x76f988da,
+0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,
+0x27b70a85,0x2e1b2138,0x4d2c6dfc,0x53380d13,0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,
+0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,0xd192e819,0xd6990624,0xf40e3585,0x106aa070,
+0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,
+0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
+#define ROR(x,n) (((x) >> (n)) | ((x) << (32-(n))))
+static void sha256_block(uint32_t st[8], const uint8_t blk[64]) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((uint32_t)blk[4*i] << 24) | ((uint32_t)blk[4*i+1] << 16) | ((uint32_t)blk[4*i+2] << 8) | blk[4*i+3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = ROR(w[i-15],7) ^ ROR(w[i-15],18) ^ (w[i-15] >> 3);
+        uint32_t s1 = ROR(w[i-2],17) ^ ROR(w[i-2],19) ^ (w[i-2] >> 10);
+        w[i] = w[i-16] + s0 + w[i-7] + s1;
+    }
+    uint32_t a=st[0],b=st[1],c=st[2],d=st[3],e=st[4],f=st[5],g=st[6],h=st[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1 = ROR(e,6) ^ ROR(e,11) ^ ROR(e,25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = h + S1 + ch + K256[i] + w[i];
+        uint32_t S0 = ROR(a,2) ^ ROR(a,13) ^ ROR(a,22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        h=g; g=f; f=e; e=d+t1; d=c; c=b; b=a; a=t1+t2;
+    }
+    st[0]+=a; st[1]+=b; st[2]+=c; st[3]+=d; st[4]+=e; st[5]+=f; st[6]+=g; st[7]+=h;
+}
+static void sha256(const uint8_t* msg, size_t len, uint8_t out[32]) {
+    uint32_t st[8] = {0x6a09e667,0xbb67ae85,0x3c6ef372,0xa54ff53a,0x510e527f,0x9b05688c,0x1f83d9ab,0x5be0cd19};
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) sha256_block(st, msg + i);
+    uint8_t tail[128]; size_t rem = len - i;
+    memset(tail, 0, sizeof tail);
+    memcpy(tail, msg + i, rem);
+    tail[rem] = 0x80;
+    size_t tl = (rem + 9 <= 64) ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int b = 0; b < 8; b++) tail[tl - 1 - b] = (uint8_t)(bits >> (8*b));
+    sha256_block(st, tail);
+    if (tl == 128) sha256_block(st, tail + 64);
+    for (int k = 0; k < 8; k++) { out[4*k]=st[k]>>24; out[4*k+1]=st[k]>>16; out[4*k+2]=st[k]>>8; out[4*k+3]=st[k]; }
+}
+void oracle_sha256(const uint8_t* msg, size_t len, uint8_t* out) { sha256(msg, len, out); }
+
+/* leaves[r] = SHA256( || _c  LE8(canonical(cols[c][r*V + v])) , v < V )
+ * src/merkle.rs:412-436 + src/hash.rs:92-99                                */
+void oracle_sha256_rows(const uint64_t* const* cols, unsigned ncols, unsigned V, size_t nrows, uint8_t* leaves) {
+    size_t rowbytes = (size_t)ncols * V * 8;
+    #pragma omp parallel
+    {
+        uint8_t* buf = (uint8_t*)malloc(rowbytes);
+        #pragma omp for schedule(static)
+        for (size_t r = 0; r < nrows; r++) {
+            uint8_t* p = buf;
+            for (unsigned c = 0; c < ncols; c++)
+                for (unsigned v = 0; v < V; v++) {
+                    uint64_t x = gl_from_mont(cols[c][r*V+v]);
+                    for (int b = 0; b < 8; b++) *p++ = (uint8_t)(x >> (8*b));
+                }
+            sha256(buf, rowbytes, leaves + 32*r);
+        }
+        free(buf);
+    }
+}
+/* nodes: n x 32 bytes; nodes[1] = root; nodes[0] zeroed.  src/merkle.rs:485-508 */
+void oracle_sha256_merkle(const uint8_t* leaves, size_t n, uint8_t* nodes) {
+    memset(nodes, 0, 32);
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n/2; i++) sha256(leaves + 64*i, 64, nodes + 32*(n/2 + i));
+    for (size_t size = n/4; size >= 1; size >>= 1) {
+        #pragma omp parallel for schedule(static)
+        for (size_t i = size; i < 2*size; i++) sha256(nodes + 64*i, 64, nodes + 32*i);
+    }
+}
+
+/* ---- FRI fold (src/fri.rs:526-567) ------------------------------------ */
+/* evals: n elems x V words, bit-reversed order; out: n/ff elems, bit-reversed.
+ * alpha: V words (Montgomery). domain_offset canonical. */
+void oracle_fri_fold(const uint64_t* evals, uint64_t* out, unsigned log_n, unsigned V, unsigned ff,
+                     const uint64_t* alpha, uint64_t offset_canon) {
+    size_t n = (size_t)1 << log_n, m = n / ff;
+    unsigned log_ff = 0; while ((1u << log_ff) < ff) log_ff++;
+    uint64_t* co = (uint64_t*)malloc(n * V * 8);
+    memcpy(co, evals, n * V * 8);
+    oracle_bit_reverse(co, log_n, V);
+    oracle_ntt(co, log_n, V, 1, offset_canon);
+    uint64_t fold = gl_to_mont(ff);
+    for (size_t i = 0; i < n * V; i++) co[i] = gl_mul(co[i], fold);
+    if (V == 1) {
+        uint64_t ap[16]; ap[0] = GL_ONE;
+        for (unsigned k = 1; k < ff; k++) ap[k] = gl_mul(ap[k-1], alpha[0]);
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < m; i++) {
+            uint64_t acc = 0;
+            for (unsigned k = 0; k < ff; k++) acc = gl_add(acc, gl_mul(co[i*ff+k], ap[k]));
+            out[i] = acc;
+        }
+    } else {
+        fq3 ap[16]; fq3 one = {GL_ONE,0,0}; ap[0] = one; fq3 al = {alpha[0],alpha[1],alpha[2]};
+        for (unsigned k = 1; k < ff; k++) ap[k] = fq3_mul(ap[k-1], al);
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < m; i++) {
+            fq3 acc = {0,0,0};
+            for (unsigned k = 0; k < ff; k++) {
+                fq3 c = {co[(i*ff+k)*3], co[(i*ff+k)*3+1], co[(i*ff+k)*3+2]};
+                acc = fq3_add(acc, fq3_mul(c, ap[k]));
+            }
+            out[i*3] = acc.c0; out[i*3+1] = acc.c1; out[i*3+2] = acc.c2;
+        }
+    }
+    free(co);
+    uint64_t off_ff = gl_from_mont(gl_pow(gl_to_mont(offset_canon % GL_P), ff));
+    oracle_ntt(out, log_n - log_ff, V, 0, off_ff);
+    oracle_bit_reverse(out, log_n - log_ff, V);
+}
+
+/* ---- element-wise stages (evaluation_shaders.h.metal:11-168) ---------- */
+/* op codes shared with include/ministark_hip.h */
+enum { OP_ADD = 0, OP_MUL = 1 };
+enum { UN_NEG = 0, UN_INV = 1, UN_EXP = 2 };
+static inline fq3 ld3(const uint64_t* p, size_t i, unsigned V) {
+    fq3 r; if (V == 3) { r.c0 = p[3*i]; r.c1 = p[3*i+1]; r.c2 = p[3*i+2]; } else { r.c0 = p[i]; r.c1 = 0; r.c2 = 0; } return r;
+}
+/* dst[i] = lhs[i] op rhs[(i+shift) % n]; lhs/dst have VL words, rhs VR (VR<=VL) */
+void oracle_binary(int op, unsigned VL, unsigned VR, size_t n, uint64_t* dst, const uint64_t* lhs,
+                   const uint64_t* rhs, size_t shift) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        size_t j = (i + shift) % n;
+        if (VL == 1) {
+            dst[i] = op == OP_ADD ? gl_add(lhs[i], rhs[j]) : gl_mul(lhs[i], rhs[j]);
+        } else {
+            fq3 a = ld3(lhs, i, 3), b = ld3(rhs, j, VR), r;
+            if (op == OP_ADD) r = fq3_add(a, b);
+            else r = (VR == 1) ? fq3_mul_fp(a, b.c0) : fq3_mul(a, b);
+            dst[3*i] = r.c0; dst[3*i+1] = r.c1; dst[3*i+2] = r.c2;
+        }
+    }
+}
+void oracle_binary_const(int op, unsigned VL, unsigned VR, size_t n, uint64_t* dst, const uint64_t* lhs,
+                         const uint64_t* c) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        if (VL == 1) {
+            dst[i] = op == OP_ADD ? gl_add(lhs[i], c[0]) : gl_mul(lhs[i], c[0]);
+        } else {
+            fq3 a = ld3(lhs, i, 3), b = ld3(c, 0, VR), r;
+            if (op == OP_ADD) r = fq3_add(a, b);
+            else r = (VR == 1) ? fq3_mul_fp(a, b.c0) : fq3_mul(a, b);
+            dst[3*i] = r.c0; dst[3*i+1] = r.c1; dst[3*i+2] = r.c2;
+        }
+    }
+}
+/* dst[i] = lhs[i] * rhs[(i+shift)%n]^e */
+void oracle_mul_pow(unsigned VL, unsigned VR, size_t n, uint64_t* dst, const uint64_t* lhs,
+                    const uint64_t* rhs, unsigned e, size_t shift) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        size_t j = (i + shift) % n;
+        if (VL == 1) dst[i] = gl_mul(lhs[i], gl_pow(rhs[j], e));
+        else {
+            fq3 a = ld3(lhs, i, 3), r;
+            if (VR == 1) r = fq3_mul_fp(a, gl_pow(rhs[j], e));
+            else r = fq3_mul(a, fq3_pow(ld3(rhs, j, 3), e));
+            dst[3*i] = r.c0; dst[3*i+1] = r.c1; dst[3*i+2] = r.c2;
+        }
+    }
+}
+void oracle_unary(int op, unsigned V, size_t n, uint64_t* dst, const uint64_t* src, unsigned e) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        if (V == 1) {
+            uint64_t x = src[i];
+            dst[i] = op == UN_NEG ? gl_neg(x) : op == UN_INV ? (x ? gl_inv(x) : 0) : gl_pow(x, e);
+        } else {
+            fq3 x = ld3(src, i, 3), r;
+            if (op == UN_NEG) r = fq3_neg(x);
+            else if (op == UN_INV) { if (x.c0 | x.c1 | x.c2) r = fq3_inv(x); else r = x; }
+            else r = fq3_pow(x, e);
+            dst[3*i] = r.c0; dst[3*i+1] = r.c1; dst[3*i+2] = r.c2;
+        }
+    }
+}
+/* dst = sum of columns (src/matrix.rs:357-394) */
+void oracle_sum_columns(const uint64_t* const* cols, unsigned ncols, unsigned V, size_t n, uint64_t* dst) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n * V; i++) {
+        uint64_t acc = 0;
+        for (unsigned c = 0; c < ncols; c++) acc = gl_add(acc, cols[c][i]);
+        dst[i] = acc;
+    }
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
