@@ -1,0 +1,103 @@
+/* ministark_hip.h -- C ABI of the MI355X (gfx950) backend for miniSTARK's gpu-poly path.
+ *
+ * The reference has no FFI seam: its GPU boundary is the Rust API of crate
+ * `ministark-gpu` (Apple-Metal only).  Every entry point below names the Rust
+ * item it stands in for (path:line under the reference tree); INTEGRATION.md
+ * shows the `cfg(feature = "hip")` Rust shim that binds them.
+ *
+ * Conventions
+ *   - All field data is the reference's in-memory format, untouched at the
+ *     boundary: Montgomery residues, little-endian u64 limbs
+ *     (Fp = 1 limb, R = 2^64; Fq3 = 3 consecutive Fp; Fp252 = 4 limbs, R = 2^256).
+ *   - `void* d_*` are DEVICE pointers (hipMalloc / ms_alloc / a torch tensor's
+ *     data_ptr); `const void* h_*` are small HOST constants (one field element).
+ *   - Every function returns 0 on success, a negative MS_ERR_* otherwise, and
+ *     never throws; ms_last_error() describes the last failure of the calling
+ *     thread.  The reference panics (`assert!`/`unwrap()`, e.g.
+ *     gpu/src/plan.rs:248,255,360); the Rust shim turns non-zero into panic!.
+ *   - Work is enqueued on the context's HIP stream; functions documented
+ *     "blocks" synchronise it (the reference's execute() = commit +
+ *     wait_until_completed, gpu/src/plan.rs:229-232).
+ */
+#ifndef MINISTARK_HIP_H
+#define MINISTARK_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GpuField::field_name() (gpu/src/lib.rs:20-26, gpu/src/fields.rs:55-60,199-205,250-256) */
+typedef enum {
+    MS_GOLDILOCKS_FP = 0,  /* "p18446744069414584321_fp"  */
+    MS_GOLDILOCKS_FQ3 = 1, /* "p18446744069414584321_fq3" */
+    MS_STARK252_FP = 2     /* "p3618502788666131213697322783095070105623107215331596699973092056135872020481_fp" */
+} ms_field;
+
+typedef enum { MS_ADD = 0, MS_MUL = 1 } ms_binop;          /* {Add,Mul}{Assign,Into}[Const] */
+typedef enum { MS_NEG = 0, MS_INV = 1, MS_EXP = 2 } ms_unop; /* {Neg,Inverse,Exp}{InPlace,Into} */
+
+enum {
+    MS_OK = 0,
+    MS_ERR_INVALID = -1,     /* bad argument (size not a power of two, null pointer, ...) */
+    MS_ERR_UNSUPPORTED = -2, /* field / size / option outside what the backend implements */
+    MS_ERR_HIP = -3,         /* a HIP runtime call failed */
+    MS_ERR_NOMEM = -4
+};
+
+typedef struct ms_ctx ms_ctx;
+typedef struct ms_ntt_plan ms_ntt_plan;
+
+/* ---- runtime: Planner / get_planner (gpu/src/plan.rs:327-351, 464-469) ---------------- */
+int ms_ctx_create(int device, ms_ctx** out);
+int ms_ctx_destroy(ms_ctx* ctx);
+int ms_sync(ms_ctx* ctx);                      /* command_buffer.wait_until_completed() */
+void* ms_ctx_stream(ms_ctx* ctx);              /* the hipStream_t work is enqueued on   */
+const char* ms_last_error(void);
+size_t ms_field_bytes(int field);              /* 8 / 24 / 32 */
+
+/* ---- memory: GpuAllocator + buffer_no_copy (src/utils.rs:438-470, gpu/src/utils.rs:103-134).
+ * The reference aliases page-aligned host Vecs (unified memory); on a discrete GPU
+ * columns live in HBM and are mirrored explicitly. */
+int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr);
+int ms_free(ms_ctx* ctx, void* d_ptr);
+int ms_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* blocks */
+int ms_download(ms_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* blocks */
+
+/* ---- NTT plans: GpuFft / GpuIfft (gpu/src/plan.rs:236-325, 353-462) --------------------
+ * ms_ntt_plan_create   = GpuFft::from(domain) / GpuIfft::from(domain)
+ *     field       element type of the columns (Fp or Fq3; twiddles are in Fp = F::FftField)
+ *     log_n       domain.size() = 2^log_n      (any log_n >= 0; the reference needs >= 2048)
+ *     inverse     0: GpuFft (c_i *= offset^i, then DFT)   1: GpuIfft (DFT^-1, then e_i *= offset^-i / n)
+ *     h_offset    domain.offset (coset shift h), one Fp element, Montgomery form; NULL = 1
+ *     h_group_gen domain.group_gen, Montgomery form, or NULL.  When given it must equal
+ *                 arkworks' get_root_of_unity(n) (the only root the kernels' constants are
+ *                 built for); otherwise MS_ERR_UNSUPPORTED.
+ * ms_ntt_encode        = fft.encode(&mut column): queue one column (n elements, in place)
+ * ms_ntt_execute       = fft.execute(): run every queued column, BLOCKS, clears the queue
+ *                        (the plan stays usable; the reference consumes it)
+ * ms_ntt_enqueue       = encode + launch without blocking (for pipelines and timing) */
+int ms_ntt_plan_create(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset,
+                       const void* h_group_gen, ms_ntt_plan** out);
+int ms_ntt_plan_destroy(ms_ntt_plan* plan);
+int ms_ntt_encode(ms_ntt_plan* plan, void* d_column);
+int ms_ntt_execute(ms_ntt_plan* plan);
+int ms_ntt_enqueue(ms_ntt_plan* plan, void* const* d_columns, unsigned ncols);
+
+/* ---- bit reversal: BitReverseGpuStage + bit_reverse (gpu/src/stage.rs:280-332,
+ * gpu/src/utils.rs:32-78), Matrix::bit_reverse_rows (src/matrix.rs:352-354).
+ * Reverses the first 2^log_n elements of each column in place (log_n smaller than the
+ * column = prover.rs:185-194 bit_reverse_ce_trace). */
+int ms_bit_reverse(ms_ctx* ctx, int field, unsigned log_n, void* const* d_columns, unsigned ncols);
+
+/* ---- fused LDE: Matrix::interpolate + bit_reversed_evaluate (src/prover.rs:50-51,
+ * src/matrix.rs:142-163,211-251): per column  iNTT on subgroup(2^log_n)  ->  zero-extend
+ * -> NTT on coset(2^(log_n+log_blowup), h_offset) -> optional bit-reversed order.
+ * d_in[c] (2^log_n elements) is preserved; d_out[c] has 2^(log_n+log_blowup) elements. */
+int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowup, const void* h_offset,
+           const void* const* d_in, void* const* d_out, unsigned ncols, int bit_reversed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINISTARK_HIP_H */

@@ -1,0 +1,8 @@
+"""ministark_amd -- MI355X (gfx950) backend for miniSTARK's gpu-poly hot path.
+
+Product = ministark_amd/libministark_hip.so (hand-written HIP kernels behind the C ABI
+in include/ministark_hip.h).  This package is the thin host mirror of the reference's
+`ministark-gpu` interface on top of it.  No CPU fallback exists.
+"""
+from .api import (GOLDILOCKS_FP, GOLDILOCKS_FQ3, STARK252_FP, GL_GENERATOR, GL_P, GpuFft, GpuIfft,  # noqa: F401
+                  GpuVec, Matrix, Planner, Radix2EvaluationDomain, get_planner, gl_from_mont, gl_to_mont)

@@ -1,0 +1,83 @@
+"""ctypes loader for libministark_hip.so -- the ONLY native library the package loads.
+
+There is no CPU fallback: if the hipcc-built library is missing, or no AMD GPU is
+visible when a context is created, this raises.  (tests/emu builds a g++ simulator
+of the same sources for kernel-logic tests; that library is loaded by the tests
+through `Lib(path)` explicitly and is never looked for here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_SO = os.path.join(_HERE, "libministark_hip.so")
+
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class MsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ministark_hip error {code}: {msg}")
+        self.code = code
+
+
+class Lib:
+    """Typed view of the C ABI in include/ministark_hip.h."""
+
+    def __init__(self, path=None):
+        path = path or DEFAULT_SO
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it with `python -m ministark_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback.")
+        self.path = path
+        L = ctypes.CDLL(path)
+        self.L = L
+        vp, u, i, sz = ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_size_t
+        sigs = {
+            "ms_ctx_create": (i, [i, c_void_pp]),
+            "ms_ctx_destroy": (i, [vp]),
+            "ms_sync": (i, [vp]),
+            "ms_ctx_stream": (vp, [vp]),
+            "ms_last_error": (ctypes.c_char_p, []),
+            "ms_field_bytes": (sz, [i]),
+            "ms_alloc": (i, [vp, sz, c_void_pp]),
+            "ms_free": (i, [vp, vp]),
+            "ms_upload": (i, [vp, vp, vp, sz]),
+            "ms_download": (i, [vp, vp, vp, sz]),
+            "ms_ntt_plan_create": (i, [vp, i, u, i, vp, vp, c_void_pp]),
+            "ms_ntt_plan_destroy": (i, [vp]),
+            "ms_ntt_encode": (i, [vp, vp]),
+            "ms_ntt_execute": (i, [vp]),
+            "ms_ntt_enqueue": (i, [vp, c_void_pp, u]),
+            "ms_bit_reverse": (i, [vp, i, u, c_void_pp, u]),
+            "ms_lde": (i, [vp, i, u, u, vp, c_void_pp, c_void_pp, u, i]),
+        }
+        self.optional = {}
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        self.sigs = sigs
+
+    def declare(self, name, res, args):
+        fn = getattr(self.L, name)
+        fn.restype = res
+        fn.argtypes = args
+        return fn
+
+    def check(self, rc):
+        if rc != 0:
+            raise MsError(rc, self.L.ms_last_error().decode())
+
+    def __getattr__(self, name):
+        return getattr(self.L, name)
+
+
+_default = None
+
+
+def lib():
+    global _default
+    if _default is None:
+        _default = Lib()
+    return _default

@@ -1,0 +1,315 @@
+"""Host-side mirror of the reference's gpu-poly interface, over the C ABI.
+
+Same names, argument meaning and error behaviour as the Rust items they mirror
+(reference path:line in each docstring), so the parity tests read like the
+reference's own tests (gpu/tests/shaders.rs).  Python is only plumbing here: all
+arithmetic happens in the HIP kernels behind include/ministark_hip.h.  (The
+reference is Rust; there is no Rust toolchain in the build image, so this file and
+ministark_amd/csrc/host/ministark.hpp stand where the `cfg(feature = "hip")`
+shim of INTEGRATION.md would.)
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+GOLDILOCKS_FP, GOLDILOCKS_FQ3, STARK252_FP = 0, 1, 2
+FIELD_WORDS = {GOLDILOCKS_FP: 1, GOLDILOCKS_FQ3: 3, STARK252_FP: 4}
+
+GL_P = (1 << 64) - (1 << 32) + 1
+_GL_R = (1 << 64) % GL_P
+_GL_TWO_ADIC_ROOT = 1753635133440165772
+GL_GENERATOR = 7
+
+
+def gl_to_mont(x):
+    return (int(x) * _GL_R) % GL_P
+
+
+def gl_from_mont(x):
+    return (int(x) * pow(_GL_R, -1, GL_P)) % GL_P
+
+
+class Planner:
+    """`Planner` / `get_planner()` (gpu/src/plan.rs:327-351, 464-469): owns the device,
+    the kernel library and the command queue (here: a HIP stream)."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or _lib.lib()
+        h = ctypes.c_void_p()
+        self.lib.check(self.lib.ms_ctx_create(device, ctypes.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def sync(self):
+        self.lib.check(self.lib.ms_sync(self.handle))
+
+    @property
+    def stream(self):
+        return self.lib.ms_ctx_stream(self.handle)
+
+    def close(self):
+        if self.handle:
+            self.lib.ms_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_PLANNER = None
+
+
+def get_planner():
+    global _PLANNER
+    if _PLANNER is None:
+        _PLANNER = Planner()
+    return _PLANNER
+
+
+class GpuVec:
+    """`GpuVec<F>` (src/utils.rs:438-470): a column of `n` field elements.  The reference
+    aliases a page-aligned host Vec (unified memory); here the column lives in HBM and
+    `to_numpy()` / `from_numpy()` are the explicit mirror."""
+
+    def __init__(self, planner, n, field=GOLDILOCKS_FP, ptr=None, owner=True):
+        self.planner = planner
+        self.n = n
+        self.field = field
+        self.words = n * FIELD_WORDS[field]
+        self.owner = owner and ptr is None
+        if ptr is None:
+            p = ctypes.c_void_p()
+            planner.lib.check(planner.lib.ms_alloc(planner.handle, max(self.words * 8, 8), ctypes.byref(p)))
+            ptr = p.value
+        self.ptr = ptr
+
+    @classmethod
+    def from_numpy(cls, planner, arr, field=GOLDILOCKS_FP):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64).ravel()
+        V = FIELD_WORDS[field]
+        assert arr.size % V == 0
+        v = cls(planner, arr.size // V, field)
+        if arr.size:
+            planner.lib.check(planner.lib.ms_upload(planner.handle, v.ptr, arr.ctypes.data, arr.size * 8))
+        return v
+
+    def to_numpy(self):
+        out = np.empty(self.words, dtype=np.uint64)
+        if self.words:
+            self.planner.lib.check(self.planner.lib.ms_download(self.planner.handle, out.ctypes.data, self.ptr, self.words * 8))
+        return out
+
+    def clone(self):
+        return GpuVec.from_numpy(self.planner, self.to_numpy(), self.field)
+
+    def free(self):
+        if self.owner and self.ptr:
+            self.planner.lib.ms_free(self.planner.handle, self.ptr)
+            self.ptr = None
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Radix2EvaluationDomain:
+    """ark_poly::Radix2EvaluationDomain over Goldilocks as the reference uses it
+    (gpu/src/plan.rs:386-423): `new(n)` / `new_coset(n, offset)`; constants are canonical
+    integers, `*_mont` the Montgomery words that cross the C ABI."""
+
+    def __init__(self, size, offset=1):
+        if size < 1 or size & (size - 1):
+            raise ValueError("domain size must be a power of two")
+        self.size = size
+        self.log_size = size.bit_length() - 1
+        if self.log_size > 32:
+            raise ValueError("domain exceeds the two-adicity of the field")
+        self.group_gen = pow(_GL_TWO_ADIC_ROOT, 1 << (32 - self.log_size), GL_P)
+        self.group_gen_inv = pow(self.group_gen, -1, GL_P)
+        self.size_inv = pow(size % GL_P, -1, GL_P)
+        self.offset = offset % GL_P
+        self.offset_inv = pow(self.offset, -1, GL_P)
+
+    @classmethod
+    def new(cls, size):
+        return cls(size)
+
+    @classmethod
+    def new_coset(cls, size, offset):
+        return cls(size, offset)
+
+    @property
+    def offset_mont(self):
+        return gl_to_mont(self.offset)
+
+    @property
+    def group_gen_mont(self):
+        return gl_to_mont(self.group_gen)
+
+
+def _ptr_array(vecs):
+    return (ctypes.c_void_p * len(vecs))(*[v.ptr for v in vecs])
+
+
+class _FftBase:
+    MIN_SIZE = 1  # the reference asserts >= 2048 (gpu/src/plan.rs:248,294); this backend has no lower bound
+    _inverse = 0
+
+    def __init__(self, domain, field=GOLDILOCKS_FP, planner=None):
+        self.planner = planner or get_planner()
+        self.domain = domain
+        self.field = field
+        off = ctypes.c_uint64(domain.offset_mont)
+        gen = ctypes.c_uint64(domain.group_gen_mont)
+        h = ctypes.c_void_p()
+        L = self.planner.lib
+        L.check(L.ms_ntt_plan_create(self.planner.handle, field, domain.log_size, self._inverse,
+                                     ctypes.byref(off), ctypes.byref(gen), ctypes.byref(h)))
+        self.handle = h
+        self._keep = []
+
+    @classmethod
+    def from_domain(cls, domain, field=GOLDILOCKS_FP, planner=None):
+        return cls(domain, field, planner)
+
+    def encode(self, column):
+        """`encode(&mut [F])` (gpu/src/plan.rs:254-263 / 300-309): queue one column, in place."""
+        if len(column) != self.domain.size:
+            raise ValueError(f"column has {len(column)} elements, domain {self.domain.size}")  # plan.rs:257 assert_eq!
+        if column.field != self.field:
+            raise ValueError("column field differs from the plan's")
+        self._keep.append(column)
+        self.planner.lib.check(self.planner.lib.ms_ntt_encode(self.handle, column.ptr))
+
+    def execute(self):
+        """`execute(self)` (gpu/src/plan.rs:229-232): run everything queued and block."""
+        self.planner.lib.check(self.planner.lib.ms_ntt_execute(self.handle))
+        self._keep = []
+
+    def enqueue(self, columns):
+        """Non-blocking launch of a batch (no reference equivalent; used for timing)."""
+        arr = _ptr_array(columns)
+        self.planner.lib.check(self.planner.lib.ms_ntt_enqueue(self.handle, arr, len(columns)))
+
+    def close(self):
+        if self.handle:
+            self.planner.lib.ms_ntt_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuFft(_FftBase):
+    """`GpuFft::from(domain)` (gpu/src/plan.rs:236-279)."""
+    _inverse = 0
+
+
+class GpuIfft(_FftBase):
+    """`GpuIfft::from(domain)` (gpu/src/plan.rs:282-325)."""
+    _inverse = 1
+
+
+class Matrix:
+    """`Matrix<F>(Vec<GpuVec<F>>)` (src/matrix.rs:26): column-major, one GpuVec per column."""
+
+    def __init__(self, columns):
+        self.columns = list(columns)
+
+    @classmethod
+    def from_numpy(cls, planner, cols, field=GOLDILOCKS_FP):
+        return cls([GpuVec.from_numpy(planner, c, field) for c in cols])
+
+    def num_rows(self):
+        return len(self.columns[0]) if self.columns else 0
+
+    def num_cols(self):
+        return len(self.columns)
+
+    @property
+    def field(self):
+        return self.columns[0].field
+
+    @property
+    def planner(self):
+        return self.columns[0].planner
+
+    def clone(self):
+        return Matrix([c.clone() for c in self.columns])
+
+    def to_numpy(self):
+        return [c.to_numpy() for c in self.columns]
+
+    # src/matrix.rs:102-116 (into_polynomials_gpu) ------------------------------------
+    def into_polynomials(self, domain):
+        ifft = GpuIfft(domain, self.field, self.planner)
+        for c in self.columns:
+            ifft.encode(c)
+        ifft.execute()
+        ifft.close()
+        return self
+
+    def interpolate(self, domain):        # src/matrix.rs:155-163
+        return self.clone().into_polynomials(domain)
+
+    # src/matrix.rs:193-208 (into_evaluations_gpu): column.resize(domain.size(), 0) then fft
+    def into_evaluations(self, domain):
+        cols = []
+        for c in self.columns:
+            if len(c) > domain.size:
+                raise ValueError("column longer than the evaluation domain")
+            if len(c) < domain.size:
+                a = np.zeros(domain.size * FIELD_WORDS[c.field], dtype=np.uint64)
+                a[:c.words] = c.to_numpy()
+                c = GpuVec.from_numpy(self.planner, a, c.field)
+            cols.append(c)
+        self.columns = cols
+        fft = GpuFft(domain, self.field, self.planner)
+        for c in self.columns:
+            fft.encode(c)
+        fft.execute()
+        fft.close()
+        return self
+
+    def evaluate(self, domain):           # src/matrix.rs:237-243
+        return self.clone().into_evaluations(domain)
+
+    def bit_reverse_rows(self):           # src/matrix.rs:352-354
+        L = self.planner.lib
+        n = self.num_rows()
+        arr = _ptr_array(self.columns)
+        L.check(L.ms_bit_reverse(self.planner.handle, self.field, n.bit_length() - 1, arr, len(self.columns)))
+        self.planner.sync()
+        return self
+
+    def into_bit_reversed_evaluations(self, domain):   # src/matrix.rs:225-234
+        return self.into_evaluations(domain).bit_reverse_rows()
+
+    def bit_reversed_evaluate(self, domain):           # src/matrix.rs:245-251
+        return self.clone().into_bit_reversed_evaluations(domain)
+
+    def lde(self, blowup, offset=GL_GENERATOR, bit_reversed=True):
+        """Fused `interpolate(trace_domain)` + `bit_reversed_evaluate(lde_domain)`
+        (src/prover.rs:50-51) in one call; returns a new Matrix, self is preserved."""
+        L = self.planner.lib
+        n = self.num_rows()
+        log_n, log_b = n.bit_length() - 1, blowup.bit_length() - 1
+        outs = [GpuVec(self.planner, n * blowup, self.field) for _ in self.columns]
+        off = ctypes.c_uint64(gl_to_mont(offset))
+        L.check(L.ms_lde(self.planner.handle, self.field, log_n, log_b, ctypes.byref(off),
+                         _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
+        self.planner.sync()
+        return Matrix(outs)

@@ -1,0 +1,42 @@
+"""Build libministark_hip.so (hipcc, gfx950) in-tree.
+
+    python -m ministark_amd.build            # build if sources are newer
+    python -m ministark_amd.build --force
+
+The shared object is git-ignored but travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libministark_hip.so")
+SOURCES = ["ministark_hip.cpp"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _deps():
+    out = []
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".cpp", ".hip"))]
+    out.append(os.path.join(ROOT, "include", "ministark_hip.h"))
+    return out
+
+
+def build(force=False, verbose=True):
+    newest = max(os.path.getmtime(p) for p in _deps())
+    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
+        return SO
+    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO]
+    if verbose:
+        print("[ministark_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,494 @@
+// Host side of libministark_hip.so: the C ABI declared in include/ministark_hip.h.
+// Compiled as HIP for gfx950 (see ministark_amd/build.py).  Mirrors the reference's
+// Planner / GpuFft / GpuIfft / *Stage front-ends (gpu/src/plan.rs, gpu/src/stage.rs).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ministark_hip.h"
+#include "gl.h"
+#include "ntt_kernels.h"
+
+using msntt::MAXC;
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(MS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define MSCHK(expr)                \
+    do {                           \
+        int r_ = (expr);           \
+        if (r_ != MS_OK) return r_; \
+    } while (0)
+
+extern "C" const char* ms_last_error(void) { return g_last_error.c_str(); }
+extern "C" size_t ms_field_bytes(int field) {
+    switch (field) {
+    case MS_GOLDILOCKS_FP: return 8;
+    case MS_GOLDILOCKS_FQ3: return 24;
+    case MS_STARK252_FP: return 32;
+    default: return 0;
+    }
+}
+static int field_words(int field, unsigned* V) {
+    if (field == MS_GOLDILOCKS_FP) { *V = 1; return MS_OK; }
+    if (field == MS_GOLDILOCKS_FQ3) { *V = 3; return MS_OK; }
+    if (field == MS_STARK252_FP) return fail(MS_ERR_UNSUPPORTED, "Fp252 is not implemented yet on this path");
+    return fail(MS_ERR_INVALID, "unknown field id %d", field);
+}
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+struct ms_ntt_plan;
+struct PlanKey { unsigned V, log_n; bool inverse; uint64_t h; };
+struct ms_ctx {
+    int device = 0;
+    std::vector<std::pair<PlanKey, ms_ntt_plan*>> plan_cache;   // plans used by the fused entry points
+    hipStream_t stream = nullptr;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    size_t group_bytes = (size_t)32 << 20;   // columns are processed in groups of about this size
+    std::mutex mu;
+};
+
+static int ctx_scratch(ms_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->scratch_bytes < bytes) {
+        if (ctx->scratch) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        hipError_t e = hipMalloc(&ctx->scratch, bytes);
+        if (e != hipSuccess) return fail(MS_ERR_NOMEM, "scratch allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        ctx->scratch_bytes = bytes;
+    }
+    *out = ctx->scratch;
+    return MS_OK;
+}
+
+extern "C" int ms_ctx_create(int device, ms_ctx** out) {
+    if (!out) return fail(MS_ERR_INVALID, "ms_ctx_create: out is null");
+    int count = 0;
+    HIPCHK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(MS_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+    HIPCHK(hipSetDevice(device));
+    ms_ctx* ctx = new ms_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(MS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    if (const char* g = getenv("MS_NTT_GROUP_BYTES")) ctx->group_bytes = (size_t)strtoull(g, nullptr, 10);
+    *out = ctx;
+    return MS_OK;
+}
+extern "C" int ms_ntt_plan_destroy(ms_ntt_plan* plan);
+extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
+    if (!ctx) return MS_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->plan_cache) ms_ntt_plan_destroy(kv.second);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MS_OK;
+}
+extern "C" int ms_sync(ms_ctx* ctx) {
+    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MS_OK;
+}
+extern "C" void* ms_ctx_stream(ms_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return fail(MS_ERR_INVALID, "ms_alloc: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e != hipSuccess) return fail(MS_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return MS_OK;
+}
+extern "C" int ms_free(ms_ctx* ctx, void* d_ptr) {
+    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_ptr));
+    return MS_OK;
+}
+extern "C" int ms_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MS_OK;
+}
+extern "C" int ms_download(ms_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// NTT plans
+// ---------------------------------------------------------------------------------------
+struct ms_ntt_plan {
+    ms_ctx* ctx = nullptr;
+    unsigned V = 1, log_n = 0;
+    bool inverse = false, coset = false;
+    // small path (log_n < 12)
+    bool small = false;
+    uint64_t *d_tw = nullptr, *d_scale_in = nullptr, *d_scale_out = nullptr;
+    // multi-pass path
+    int npass = 0;
+    unsigned lr[4] = {0, 0, 0, 0};      // log2 radix per pass
+    unsigned log_s[4] = {0, 0, 0, 0};   // log2 element stride of the pass's digit
+    unsigned nfields[4] = {0, 0, 0, 0};
+    msntt::DigitField fields[4][3];
+    unsigned lo_bits = 0;
+    uint64_t *d_tw_lo = nullptr, *d_tw_hi = nullptr, *d_aux_lo = nullptr, *d_aux_hi = nullptr, *d_gtab = nullptr;
+    uint64_t* d_wr[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t scale_const = 0;
+    int scale_mode = 0;                 // last pass: 0 none, 1 const, 2 table
+    uint64_t* d_tables = nullptr;       // one allocation backing every table
+    std::vector<void*> queue;
+};
+
+static void powers(std::vector<uint64_t>& out, size_t count, uint64_t base, uint64_t first = 1) {
+    out.resize(count);
+    uint64_t x = first;
+    for (size_t i = 0; i < count; i++) { out[i] = x; x = gl::mul(x, base); }
+}
+
+static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uint64_t h, ms_ntt_plan** out);
+
+extern "C" int ms_ntt_plan_create(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset,
+                                  const void* h_group_gen, ms_ntt_plan** out) {
+    if (!ctx || !out) return fail(MS_ERR_INVALID, "ms_ntt_plan_create: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (log_n > 32) return fail(MS_ERR_INVALID, "log_n = %u exceeds the field's two-adicity (32)", log_n);
+    if (h_group_gen) {
+        uint64_t g_m;
+        memcpy(&g_m, h_group_gen, 8);
+        if (gl::from_mont(g_m) != gl::root_of_unity(log_n))
+            return fail(MS_ERR_UNSUPPORTED, "group_gen is not arkworks' get_root_of_unity(2^%u)", log_n);
+    }
+    uint64_t h = 1;
+    if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
+    if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
+    return plan_build(ctx, V, log_n, inverse != 0, h, out);
+}
+
+// plan owned by the context, reused by the fused entry points (ms_lde, ms_fri_fold)
+static int ctx_plan(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uint64_t h, ms_ntt_plan** out) {
+    for (auto& kv : ctx->plan_cache)
+        if (kv.first.V == V && kv.first.log_n == log_n && kv.first.inverse == inverse && kv.first.h == h) { *out = kv.second; return MS_OK; }
+    MSCHK(plan_build(ctx, V, log_n, inverse, h, out));
+    ctx->plan_cache.push_back({PlanKey{V, log_n, inverse, h}, *out});
+    return MS_OK;
+}
+
+static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, uint64_t h, ms_ntt_plan** out) {
+    const int inverse = inverse_b ? 1 : 0;
+    const uint64_t gen = gl::root_of_unity(log_n);           // plain, arkworks get_root_of_unity
+    ms_ntt_plan* p = new ms_ntt_plan();
+    p->ctx = ctx; p->V = V; p->log_n = log_n; p->inverse = inverse != 0; p->coset = (h != 1);
+    const size_t n = (size_t)1 << log_n;
+    const uint64_t w = p->inverse ? gl::inv(gen) : gen;       // transform root
+    const uint64_t hinv = gl::inv(h);
+    const uint64_t ninv = gl::inv((uint64_t)(n % gl::P));
+
+    std::vector<uint64_t> host;                                // all tables, concatenated
+    auto append = [&](const std::vector<uint64_t>& t) { size_t off = host.size(); host.insert(host.end(), t.begin(), t.end()); return off; };
+    std::vector<uint64_t> t;
+    size_t off_tw = 0, off_si = 0, off_so = 0, off_lo = 0, off_hi = 0, off_alo = 0, off_ahi = 0, off_g = 0, off_wr[4] = {0, 0, 0, 0};
+    bool has_si = false, has_so = false, has_aux = false, has_g = false;
+
+    if (log_n < 12) {
+        p->small = true;
+        powers(t, std::max<size_t>(n / 2, 1), w); off_tw = append(t);
+        if (!p->inverse && p->coset) { powers(t, n, h); off_si = append(t); has_si = true; }
+        if (p->inverse) { powers(t, n, hinv, ninv); off_so = append(t); has_so = true; }
+    } else {
+        // radix decomposition: R1 = 256, the rest split as evenly as possible into radices 16..256
+        const unsigned rest = log_n - 8;
+        const int extra = (int)((rest + 7) / 8);
+        p->npass = 1 + extra;
+        p->lr[0] = 8;
+        for (int i = 0; i < extra; i++) p->lr[1 + i] = rest / extra + ((unsigned)i < rest % extra ? 1 : 0);
+        unsigned acc = 0;
+        for (int q = 0; q < p->npass; q++) { p->log_s[q] = acc; acc += p->lr[q]; }
+        // digit fields.  pass 1 maps j' = (j2..jm) [jm least significant] to layout (jm..j2) [j2 least]
+        {
+            unsigned nf = 0, in_shift = 0;
+            for (int q = p->npass - 1; q >= 1; q--) {            // jm first (least significant of j')
+                unsigned out_shift = 0;
+                for (int r = 1; r < q; r++) out_shift += p->lr[r];
+                p->fields[0][nf++] = {in_shift, out_shift, (1u << p->lr[q]) - 1};
+                in_shift += p->lr[q];
+            }
+            p->nfields[0] = nf;
+        }
+        // pass q (0-based, 1 <= q < npass-1): U = (jm..j_{q+2}) [j_{q+2} least significant in U]
+        //   -> j' = (j_{q+2}, ..., jm) [jm least significant]
+        for (int q = 1; q < p->npass - 1; q++) {
+            unsigned nf = 0, in_shift = 0;
+            for (int r = q + 1; r < p->npass; r++) {             // r = digit index (0-based) above q
+                unsigned out_shift = 0;
+                for (int r2 = r + 1; r2 < p->npass; r2++) out_shift += p->lr[r2];
+                p->fields[q][nf++] = {in_shift, out_shift, (1u << p->lr[r]) - 1};
+                in_shift += p->lr[r];
+            }
+            p->nfields[q] = nf;
+        }
+        p->lo_bits = std::min(12u, log_n);
+        powers(t, (size_t)1 << p->lo_bits, w); off_lo = append(t);
+        powers(t, n >> p->lo_bits, gl::pow(w, (uint64_t)1 << p->lo_bits)); off_hi = append(t);
+        for (int q = 0; q < p->npass; q++) {
+            powers(t, (size_t)1 << p->lr[q], gl::pow(w, (uint64_t)n >> p->lr[q])); off_wr[q] = append(t);
+        }
+        if (!p->inverse && p->coset) {
+            powers(t, (size_t)1 << p->lo_bits, h); off_alo = append(t);
+            powers(t, std::max<size_t>((n >> 8) >> p->lo_bits, 1), gl::pow(h, (uint64_t)1 << p->lo_bits)); off_ahi = append(t);
+            powers(t, 256, gl::pow(h, (uint64_t)(n >> 8))); off_g = append(t);
+            has_aux = has_g = true;
+        }
+        if (p->inverse) {
+            if (!p->coset) { p->scale_mode = 1; p->scale_const = ninv; }
+            else {
+                p->scale_mode = 2;
+                powers(t, (size_t)1 << p->lo_bits, hinv, ninv); off_alo = append(t);
+                powers(t, n >> p->lo_bits, gl::pow(hinv, (uint64_t)1 << p->lo_bits)); off_ahi = append(t);
+                has_aux = true;
+            }
+        }
+    }
+    hipError_t e = hipMalloc(&p->d_tables, host.size() * 8);
+    if (e != hipSuccess) { delete p; return fail(MS_ERR_NOMEM, "plan tables (%zu bytes): %s", host.size() * 8, hipGetErrorString(e)); }
+    e = hipMemcpy(p->d_tables, host.data(), host.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(p->d_tables); delete p; return fail(MS_ERR_HIP, "plan table upload: %s", hipGetErrorString(e)); }
+    if (p->small) {
+        p->d_tw = p->d_tables + off_tw;
+        p->d_scale_in = has_si ? p->d_tables + off_si : nullptr;
+        p->d_scale_out = has_so ? p->d_tables + off_so : nullptr;
+    } else {
+        p->d_tw_lo = p->d_tables + off_lo; p->d_tw_hi = p->d_tables + off_hi;
+        for (int q = 0; q < p->npass; q++) p->d_wr[q] = p->d_tables + off_wr[q];
+        if (has_aux) { p->d_aux_lo = p->d_tables + off_alo; p->d_aux_hi = p->d_tables + off_ahi; }
+        if (has_g) p->d_gtab = p->d_tables + off_g;
+    }
+    *out = p;
+    return MS_OK;
+}
+
+extern "C" int ms_ntt_plan_destroy(ms_ntt_plan* plan) {
+    if (!plan) return MS_OK;
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    if (plan->d_tables) (void)hipFree(plan->d_tables);
+    delete plan;
+    return MS_OK;
+}
+
+template <int RB, bool INV, bool LAST>
+static void launch_mid_scale(int scale, dim3 grid, hipStream_t st, const msntt::PassParams& P) {
+    if constexpr (LAST) {
+        if (scale == 1) hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 1>), grid, dim3(msntt::NT), 0, st, P);
+        else if (scale == 2) hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 2>), grid, dim3(msntt::NT), 0, st, P);
+        else hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 0>), grid, dim3(msntt::NT), 0, st, P);
+    } else {
+        hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, false, 0>), grid, dim3(msntt::NT), 0, st, P);
+    }
+}
+template <int RB>
+static void launch_mid(bool inv, bool last, int scale, dim3 grid, hipStream_t st, const msntt::PassParams& P) {
+    if (inv) { if (last) launch_mid_scale<RB, true, true>(scale, grid, st, P); else launch_mid_scale<RB, true, false>(scale, grid, st, P); }
+    else     { if (last) launch_mid_scale<RB, false, true>(scale, grid, st, P); else launch_mid_scale<RB, false, false>(scale, grid, st, P); }
+}
+
+// Transform `ncols` columns: src[c] -> dst[c] (may alias).  valid_rows < 256 means the
+// source only holds the first valid_rows/256 of the domain, the rest is implicit zeros.
+static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows) {
+    ms_ctx* ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << p->log_n;
+    const size_t col_bytes = n * p->V * 8;
+    if (p->small) {
+        if (valid_rows != 256) return fail(MS_ERR_INVALID, "zero-extended input needs a domain of at least 4096 points");
+        for (unsigned c0 = 0; c0 < ncols; c0 += MAXC) {
+            unsigned nc = std::min<unsigned>(MAXC, ncols - c0);
+            msntt::SmallParams S;
+            memset(&S, 0, sizeof S);
+            for (unsigned c = 0; c < nc; c++) { S.src[c] = (const uint64_t*)src[c0 + c]; S.dst[c] = (uint64_t*)dst[c0 + c]; }
+            S.tw = p->d_tw; S.scale_in = p->d_scale_in; S.scale_out = p->d_scale_out; S.log_n = p->log_n; S.V = p->V;
+            hipLaunchKernelGGL(msntt::ntt_small, dim3(1, nc), dim3(msntt::NT), 0, st, S);
+        }
+        HIPCHK(hipGetLastError());
+        return MS_OK;
+    }
+    unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
+    group = std::min(group, ncols);
+    void* scratch = nullptr;
+    MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes, &scratch));
+    const unsigned tiles = (unsigned)(n * p->V / msntt::TILE);
+    for (unsigned c0 = 0; c0 < ncols; c0 += group) {
+        const unsigned nc = std::min(group, ncols - c0);
+        for (int q = 0; q < p->npass; q++) {
+            msntt::PassParams P;
+            memset(&P, 0, sizeof P);
+            const bool last = (q == p->npass - 1);
+            for (unsigned c = 0; c < nc; c++) {
+                uint64_t* scr = (uint64_t*)((char*)scratch + (size_t)c * col_bytes);
+                P.src[c] = (q == 0) ? (const uint64_t*)src[c0 + c] : scr;
+                P.dst[c] = last ? (uint64_t*)dst[c0 + c] : scr;
+            }
+            P.tw_lo = p->d_tw_lo; P.tw_hi = p->d_tw_hi; P.wr = p->d_wr[q];
+            P.aux_lo = p->d_aux_lo; P.aux_hi = p->d_aux_hi; P.gtab = p->d_gtab;
+            P.log_n = p->log_n; P.V = p->V; P.valid_rows = valid_rows; P.lo_bits = p->lo_bits; P.log_s = p->log_s[q];
+            P.nfields = p->nfields[q];
+            for (unsigned f = 0; f < P.nfields; f++) P.fields[f] = p->fields[q][f];
+            P.scale_const = p->scale_const;
+            dim3 grid(tiles, nc);
+            if (q == 0) {
+                const bool cos = (!p->inverse && p->coset);
+                if (p->inverse) hipLaunchKernelGGL((msntt::ntt_first_pass<true, false>), grid, dim3(msntt::NT), 0, st, P);
+                else if (cos) hipLaunchKernelGGL((msntt::ntt_first_pass<false, true>), grid, dim3(msntt::NT), 0, st, P);
+                else hipLaunchKernelGGL((msntt::ntt_first_pass<false, false>), grid, dim3(msntt::NT), 0, st, P);
+            } else {
+                const int scale = last ? p->scale_mode : 0;
+                switch (p->lr[q]) {
+                case 4: launch_mid<1>(p->inverse, last, scale, grid, st, P); break;
+                case 5: launch_mid<2>(p->inverse, last, scale, grid, st, P); break;
+                case 6: launch_mid<4>(p->inverse, last, scale, grid, st, P); break;
+                case 7: launch_mid<8>(p->inverse, last, scale, grid, st, P); break;
+                case 8: launch_mid<16>(p->inverse, last, scale, grid, st, P); break;
+                default: return fail(MS_ERR_INVALID, "internal: bad pass radix 2^%u", p->lr[q]);
+                }
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
+extern "C" int ms_ntt_encode(ms_ntt_plan* plan, void* d_column) {
+    if (!plan || !d_column) return fail(MS_ERR_INVALID, "ms_ntt_encode: null argument");
+    plan->queue.push_back(d_column);
+    return MS_OK;
+}
+extern "C" int ms_ntt_enqueue(ms_ntt_plan* plan, void* const* d_columns, unsigned ncols) {
+    if (!plan || (!d_columns && ncols)) return fail(MS_ERR_INVALID, "ms_ntt_enqueue: null argument");
+    if (ncols == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(plan->ctx->mu);
+    return plan_run(plan, (const void* const*)d_columns, d_columns, ncols, 256);
+}
+extern "C" int ms_ntt_execute(ms_ntt_plan* plan) {
+    if (!plan) return fail(MS_ERR_INVALID, "ms_ntt_execute: null plan");
+    std::vector<void*> q;
+    q.swap(plan->queue);
+    if (!q.empty()) MSCHK(ms_ntt_enqueue(plan, q.data(), (unsigned)q.size()));
+    HIPCHK(hipStreamSynchronize(plan->ctx->stream));
+    return MS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// bit reversal
+// ---------------------------------------------------------------------------------------
+static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* const* src, void* const* dst, unsigned ncols) {
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << log_n;
+    if (log_n >= 10) {
+        for (unsigned c0 = 0; c0 < ncols; c0 += MAXC) {
+            unsigned nc = std::min<unsigned>(MAXC, ncols - c0);
+            msntt::BitrevParams B;
+            memset(&B, 0, sizeof B);
+            for (unsigned c = 0; c < nc; c++) { B.src[c] = (const uint64_t*)src[c0 + c]; B.dst[c] = (uint64_t*)dst[c0 + c]; }
+            B.log_n = log_n;
+            dim3 grid((unsigned)(n >> 10), nc);
+            if (V == 1) hipLaunchKernelGGL(msntt::bit_reverse_tiled<1>, grid, dim3(msntt::NT), 0, st, B);
+            else hipLaunchKernelGGL(msntt::bit_reverse_tiled<3>, grid, dim3(msntt::NT), 0, st, B);
+        }
+    } else {
+        // tiny: out of place through scratch when aliased
+        const size_t col_bytes = n * V * 8;
+        void* scratch = nullptr;
+        MSCHK(ctx_scratch(ctx, (size_t)MAXC * col_bytes, &scratch));
+        for (unsigned c0 = 0; c0 < ncols; c0 += MAXC) {
+            unsigned nc = std::min<unsigned>(MAXC, ncols - c0);
+            msntt::BitrevParams B;
+            memset(&B, 0, sizeof B);
+            for (unsigned c = 0; c < nc; c++) { B.src[c] = (const uint64_t*)src[c0 + c]; B.dst[c] = (uint64_t*)((char*)scratch + c * col_bytes); }
+            B.log_n = log_n;
+            dim3 grid((unsigned)((n + msntt::NT - 1) / msntt::NT), nc);
+            if (V == 1) hipLaunchKernelGGL(msntt::bit_reverse_simple<1>, grid, dim3(msntt::NT), 0, st, B);
+            else hipLaunchKernelGGL(msntt::bit_reverse_simple<3>, grid, dim3(msntt::NT), 0, st, B);
+            for (unsigned c = 0; c < nc; c++)
+                HIPCHK(hipMemcpyAsync(dst[c0 + c], (char*)scratch + c * col_bytes, col_bytes, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_bit_reverse(ms_ctx* ctx, int field, unsigned log_n, void* const* d_columns, unsigned ncols) {
+    if (!ctx || (!d_columns && ncols)) return fail(MS_ERR_INVALID, "ms_bit_reverse: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (log_n > 40) return fail(MS_ERR_INVALID, "log_n too large");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return bit_reverse_run(ctx, V, log_n, (const void* const*)d_columns, d_columns, ncols);
+}
+
+// ---------------------------------------------------------------------------------------
+// fused LDE
+// ---------------------------------------------------------------------------------------
+extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowup, const void* h_offset,
+                      const void* const* d_in, void* const* d_out, unsigned ncols, int bit_reversed) {
+    if (!ctx || !d_in || !d_out) return fail(MS_ERR_INVALID, "ms_lde: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    const unsigned log_N = log_n + log_blowup;
+    if (log_N > 32) return fail(MS_ERR_INVALID, "LDE domain 2^%u exceeds the two-adicity", log_N);
+    uint64_t h = 1;
+    if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
+    if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
+    ms_ntt_plan *inv = nullptr, *fwd = nullptr;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        MSCHK(ctx_plan(ctx, V, log_n, true, 1, &inv));
+        MSCHK(ctx_plan(ctx, V, log_N, false, h, &fwd));
+        // coefficients land in the first 2^log_n elements of the output column
+        rc = plan_run(inv, d_in, d_out, ncols, 256);
+        const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
+        if (rc == MS_OK) {
+            if (!fwd->small && log_blowup <= 4) {
+                rc = plan_run(fwd, (const void* const*)d_out, d_out, ncols, 256u >> log_blowup);
+            } else {
+                for (unsigned c = 0; c < ncols && rc == MS_OK; c++)
+                    if (hipMemsetAsync((char*)d_out[c] + n * V * 8, 0, (N - n) * V * 8, ctx->stream) != hipSuccess)
+                        rc = fail(MS_ERR_HIP, "hipMemsetAsync failed");
+                if (rc == MS_OK) rc = plan_run(fwd, (const void* const*)d_out, d_out, ncols, 256);
+            }
+        }
+        if (rc == MS_OK && bit_reversed) rc = bit_reverse_run(ctx, V, log_N, (const void* const*)d_out, d_out, ncols);
+    }
+    return rc;
+}

@@ -1,0 +1,356 @@
+// Goldilocks NTT kernels for gfx950.
+//
+// Replaces the reference's FftSingle / FftMultiple / BitReverse / MulAssign(scale)
+// kernel chain (gpu/src/metal/fft_shaders.h.metal:13-101, gpu/src/plan.rs:378-462:
+// log2(n)-10 full read+write passes + a bit-reverse pass + a scale pass) by a
+// mixed-radix decomposition with at most ceil(log2(n)/8) passes over HBM and
+// NO separate bit-reversal or scaling pass.  Output order is natural, identical
+// to ark_poly Radix2EvaluationDomain::{fft,ifft}_in_place.
+//
+// Decomposition of n = R1*R2*...*Rm (R1 = 256, 16 <= Rp <= 256):
+//   input index  j = (j1, j2, ..., jm)   j1 most significant
+//   output index k = k1 + R1*k2 + ...    k1 least significant
+//   pass 1 (x -> scratch): tile = all j1 x 16 consecutive words of j' = (j2..jm);
+//       y[k1][j'] = (h*w_n^k1)^j' * sum_j1 (x[j1][j'] * g^j1) w_R1^(j1 k1),  g = h^(n/R1)
+//       stored at (digit-reversed j') * R1 + k1, i.e. layout (jm, ..., j2, k1):
+//       every later pass finds its digit at stride R1*...*R(p-1) and the final
+//       layout (km, ..., k2, k1) is the natural order -- the "bit reversal" is
+//       folded into the 2 KiB-contiguous stores of pass 1.
+//   pass p >= 2 (in place on scratch; the last one scratch -> x): tile = all jp x T
+//       consecutive low words, T = 4096/Rp; twiddle w_(np)^(j'_p * kp) is a
+//       per-tile geometric sequence kept in LDS.
+// Every workgroup is 256 threads owning 16 elements each: a radix-16 butterfly
+// network in registers, one exchange through LDS, a second radix-(Rp/16) network
+// in registers.  Loads and stores are 128 B .. 2 KiB contiguous per wave.
+//
+// The data words are the reference's Montgomery residues; by linearity they are
+// transformed as plain residues with plain twiddles (see gl.h).
+// V = u64 words per element: 1 for Fp, 3 for Fq3 (base-field twiddles act
+// component-wise, so an Fq3 column is three interleaved Fp transforms).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.h"
+
+namespace msntt {
+
+static constexpr int MAXC = 16;        // columns per launch (grid.y)
+static constexpr int TILE = 4096;      // words per workgroup tile
+static constexpr int NT = 256;         // threads per workgroup
+static constexpr int LDS_PAD_CS = 272; // c-stride (words) of the mid-pass exchange layout
+
+struct DigitField { unsigned in_shift, out_shift, mask; };
+
+struct PassParams {
+    const uint64_t* src[MAXC];
+    uint64_t* dst[MAXC];
+    const uint64_t* tw_lo;     // w_n^i,        i < 2^lo_bits
+    const uint64_t* tw_hi;     // w_n^(i<<lo_bits)
+    const uint64_t* wr;        // w_R^e, e < R of this pass
+    const uint64_t* aux_lo;    // pass 1: h^i (coset) ; last pass: c*hinv^i (inverse scale)
+    const uint64_t* aux_hi;    //         h^(i<<lo_bits)            hinv^(i<<lo_bits)
+    const uint64_t* gtab;      // pass 1 coset: g^j1, j1 < 256
+    unsigned log_n;
+    unsigned V;                // u64 words per element (1 Fp, 3 Fq3)
+    unsigned valid_rows;       // pass 1: rows j1 >= valid_rows are implicit zeros (LDE zero padding)
+    unsigned lo_bits;          // two-level table split
+    unsigned log_s;            // log2 of the element stride of this pass's digit
+    unsigned nfields;          // digit-reversal fields
+    DigitField fields[3];
+    uint64_t scale_const;      // last pass, inverse & offset==1: n^-1 (plain)
+};
+
+// w_n^e for e < n via the two-level table
+__device__ __forceinline__ uint64_t tw_pow(const PassParams& P, uint64_t e) {
+    uint64_t lo = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+    uint64_t hi_i = e >> P.lo_bits;
+    return hi_i ? gl::mul(lo, P.tw_hi[hi_i]) : lo;
+}
+__device__ __forceinline__ uint64_t aux_pow(const PassParams& P, uint64_t e) {
+    uint64_t lo = P.aux_lo[e & ((1u << P.lo_bits) - 1)];
+    uint64_t hi_i = e >> P.lo_bits;
+    return hi_i ? gl::mul(lo, P.aux_hi[hi_i]) : lo;
+}
+__device__ __forceinline__ unsigned digit_rev(const PassParams& P, unsigned x) {
+    unsigned r = 0;
+    for (unsigned f = 0; f < P.nfields; f++)
+        r |= ((x >> P.fields[f].in_shift) & P.fields[f].mask) << P.fields[f].out_shift;
+    return r;
+}
+
+// ---- radix-2^k butterfly networks in registers ---------------------------------
+// w_16 = 2^156 (arkworks' 16th root of unity for Goldilocks is a power of two:
+// 7^((p-1)/16) = 2^156); table of w_16^j, and of its inverse powers.
+__device__ static const uint64_t W16_FWD[8] = {
+    1ull, 17293822564807737345ull, 18446744069397807105ull, 4503599626321920ull,
+    281474976710656ull, 4096ull, 18446742969902956801ull, 18446744000695107585ull};
+__device__ static const uint64_t W16_INV[8] = {
+    1ull, 68719476736ull, 1099511627520ull, 18446744069414580225ull,
+    18446462594437873665ull, 18442240469788262401ull, 16777216ull, 1152921504606846976ull};
+
+// In-register DFT of N (power of two <= 16) values, natural order in and out:
+//   X[c] = sum_a x[a] w_N^(a c),  w_N = w_16^(16/N)  (inverse: w_16^-1)
+template <int N, bool INV>
+__device__ __forceinline__ void dft_regs(uint64_t* x) {
+    if constexpr (N == 1) return;
+    // bit-reversal by register renaming
+    constexpr int LOGN = (N == 2) ? 1 : (N == 4) ? 2 : (N == 8) ? 3 : 4;
+    #pragma unroll
+    for (int i = 0; i < N; i++) {
+        int r = 0;
+        #pragma unroll
+        for (int b = 0; b < LOGN; b++) r |= ((i >> b) & 1) << (LOGN - 1 - b);
+        if (r > i) { uint64_t t = x[i]; x[i] = x[r]; x[r] = t; }
+    }
+    const uint64_t* W = INV ? W16_INV : W16_FWD;
+    #pragma unroll
+    for (int s = 1; s <= LOGN; s++) {
+        const int half = 1 << (s - 1);
+        #pragma unroll
+        for (int blk = 0; blk < N; blk += 2 * half) {
+            #pragma unroll
+            for (int i = 0; i < half; i++) {
+                const int e = i * (16 >> s);            // exponent of w_16, < 8
+                uint64_t u = x[blk + i];
+                uint64_t t = (e == 0) ? x[blk + i + half] : gl::mul(x[blk + i + half], W[e]);
+                x[blk + i] = gl::add(u, t);
+                x[blk + i + half] = gl::sub(u, t);
+            }
+        }
+    }
+}
+
+// ---- pass 1 ----------------------------------------------------------------------
+// grid = (n*V/256/16, columns).  COSET: input scaled by h^j (offset != 1, forward).
+template <bool INV, bool COSET>
+__global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
+    const unsigned V = P.V;
+    __shared__ uint64_t lds[TILE];
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const unsigned tid = threadIdx.x;
+    const size_t row_words = ((size_t)1 << (P.log_n - 8)) * V;   // words per j1 row
+    const size_t w0 = (size_t)blockIdx.x * 16;
+
+    // phase 1: thread (t, b) owns rows j1 = 16a + b, a = 0..15, word column w0 + t
+    {
+        const unsigned t = tid & 15, b = tid >> 4;
+        uint64_t x[16];
+        #pragma unroll
+        for (int a = 0; a < 16; a++)
+            x[a] = (16u * a + b < P.valid_rows) ? src[(size_t)(16 * a + b) * row_words + w0 + t] : 0;
+        if constexpr (COSET) {
+            #pragma unroll
+            for (int a = 0; a < 16; a++) x[a] = gl::mul(x[a], P.gtab[16 * a + b]);
+        }
+        dft_regs<16, INV>(x);
+        // internal twiddle w_256^(b c), then exchange so that thread (c, t) gets all b
+        #pragma unroll
+        for (int c = 0; c < 16; c++) {
+            uint64_t y = (c == 0 || b == 0) ? x[c] : gl::mul(x[c], P.wr[(b * c) & 255]);
+            lds[t * 256 + (((b << 4) | c) ^ (t | ((t & 1) << 4)))] = y;
+        }
+    }
+    __syncthreads();
+    // phase 2: thread (c, t) owns b = 0..15 -> outputs k1 = c + 16 d
+    {
+        const unsigned c = tid & 15, t = tid >> 4;
+        uint64_t y[16];
+        #pragma unroll
+        for (int b = 0; b < 16; b++) y[b] = lds[t * 256 + (((b << 4) | c) ^ (t | ((t & 1) << 4)))];
+        dft_regs<16, INV>(y);
+        const size_t w = w0 + t;
+        const unsigned jp = (unsigned)(w / V), v = (unsigned)(w % V);
+        const size_t out_base = ((size_t)digit_rev(P, jp) << 8) * V + v;
+        // twiddle (h w_n^k1)^j' for k1 = c + 16 d:  A * B^d   (j'*k1 < n: no wrap)
+        uint64_t A = tw_pow(P, (uint64_t)jp * c);
+        if constexpr (COSET) A = gl::mul(A, aux_pow(P, jp));
+        const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
+        uint64_t tw = A;
+        #pragma unroll
+        for (int d = 0; d < 16; d++) {
+            dst[out_base + (size_t)(c + 16 * d) * V] = gl::mul(y[d], tw);
+            if (d < 15) tw = gl::mul(tw, B);
+        }
+    }
+}
+
+// ---- passes 2..m -------------------------------------------------------------------
+// R = 16*RB rows at element stride s = 2^log_s, T = 4096/R = 256/RB consecutive words.
+// SCALE (last pass only): 0 none, 1 multiply by scale_const, 2 multiply by c*hinv^k (aux tables)
+template <int RB, bool INV, bool LAST, int SCALE>
+__global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
+    constexpr int R = 16 * RB, T = 256 / RB, G = 16 / RB;
+    const unsigned V = P.V;
+    __shared__ uint64_t lds[16 * LDS_PAD_CS];
+    __shared__ uint64_t twl[R];
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const unsigned tid = threadIdx.x;
+    const size_t sw = ((size_t)1 << P.log_s) * V;            // words per unit of this digit
+    const unsigned tiles_per_u = (unsigned)(sw / T);
+    const unsigned U = blockIdx.x / tiles_per_u;
+    const size_t lo0 = (size_t)(blockIdx.x % tiles_per_u) * T;
+    const size_t base = (size_t)U * R * sw + lo0;
+
+    if constexpr (!LAST) {
+        // per-tile twiddles w_U^k, w_U = w_(n_p)^(rev(U)) = w_n^(rev(U) * s)
+        if (tid < R) {
+            const uint64_t nmask = (((uint64_t)1) << P.log_n) - 1;
+            uint64_t e = (((uint64_t)digit_rev(P, U) * tid) << P.log_s) & nmask;
+            twl[tid] = tw_pow(P, e);
+        }
+    }
+    uint64_t y[16];
+    if constexpr (RB == 1) {
+        // R = 16: a single network, no exchange
+        const unsigned t = tid;
+        #pragma unroll
+        for (int a = 0; a < 16; a++) y[a] = src[base + (size_t)a * sw + t];
+        dft_regs<16, INV>(y);
+        if constexpr (!LAST) __syncthreads();
+    } else {
+        {
+            const unsigned t = tid % T, b = tid / T;
+            uint64_t x[16];
+            #pragma unroll
+            for (int a = 0; a < 16; a++) x[a] = src[base + (size_t)(a * RB + b) * sw + t];
+            dft_regs<16, INV>(x);
+            #pragma unroll
+            for (int c = 0; c < 16; c++) {
+                uint64_t z = (c == 0 || b == 0) ? x[c] : gl::mul(x[c], P.wr[(b * c) & (R - 1)]);
+                lds[c * LDS_PAD_CS + b * T + t] = z;
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned t = tid % T, cl = tid / T;
+            #pragma unroll
+            for (int g = 0; g < G; g++) {
+                #pragma unroll
+                for (int b = 0; b < RB; b++) y[g * RB + b] = lds[(cl * G + g) * LDS_PAD_CS + b * T + t];
+                dft_regs<RB, INV>(y + g * RB);
+            }
+        }
+    }
+    // outputs: thread (t, cl) holds k = c + 16 d, c = cl*G + g, d = 0..RB-1 in y[g*RB + d]
+    {
+        const unsigned t = tid % T, cl = tid / T;
+        #pragma unroll
+        for (int g = 0; g < G; g++) {
+            #pragma unroll
+            for (int d = 0; d < RB; d++) {
+                const unsigned k = (cl * G + g) + 16 * d;
+                uint64_t val = y[g * RB + d];
+                const size_t pos = base + (size_t)k * sw + t;
+                if constexpr (!LAST) {
+                    val = gl::mul(val, twl[k]);
+                } else if constexpr (SCALE == 1) {
+                    val = gl::mul(val, P.scale_const);
+                } else if constexpr (SCALE == 2) {
+                    val = gl::mul(val, aux_pow(P, pos / V));
+                }
+                dst[pos] = val;
+            }
+        }
+    }
+}
+
+// ---- small transforms (n <= 2048): one workgroup per column, everything in LDS ----
+// scale_in[j]  (forward coset)  multiplies input j   (nullptr: none)
+// scale_out[k] (inverse)        multiplies output k  (nullptr: none)
+// tw[i] = w_n^i, i < n/2.
+struct SmallParams {
+    const uint64_t* src[MAXC];
+    uint64_t* dst[MAXC];
+    const uint64_t* tw;
+    const uint64_t* scale_in;
+    const uint64_t* scale_out;
+    unsigned log_n;
+    unsigned V;
+};
+__global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
+    __shared__ uint64_t lds[2048];
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const unsigned n = 1u << P.log_n, tid = threadIdx.x, V = P.V;
+    for (unsigned v = 0; v < V; v++) {
+        for (unsigned j = tid; j < n; j += NT) {
+            uint64_t x = src[(size_t)j * V + v];
+            if (P.scale_in) x = gl::mul(x, P.scale_in[j]);
+            const unsigned r = P.log_n ? (__brev(j) >> (32 - P.log_n)) : 0;
+            lds[r] = x;
+        }
+        __syncthreads();
+        for (unsigned s = 1; s <= P.log_n; s++) {
+            const unsigned half = 1u << (s - 1);
+            for (unsigned q = tid; q < n / 2; q += NT) {
+                const unsigned i = q & (half - 1), lo = ((q >> (s - 1)) << s) + i, hi = lo + half;
+                uint64_t u = lds[lo];
+                uint64_t t = gl::mul(lds[hi], P.tw[i << (P.log_n - s)]);
+                lds[lo] = gl::add(u, t);
+                lds[hi] = gl::sub(u, t);
+            }
+            __syncthreads();
+        }
+        for (unsigned k = tid; k < n; k += NT) {
+            uint64_t x = lds[k];
+            if (P.scale_out) x = gl::mul(x, P.scale_out[k]);
+            dst[(size_t)k * V + v] = x;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- bit reversal (gpu/src/metal/fft_shaders.h.metal:32-44) -----------------------
+// dst[bitrev(i)] = src[i] for i < 2^log_n, elements of V words; dst may equal src.
+// Index i = (hi:5 | mid | lo:5), rev(i) = (rev(lo):5 | rev(mid) | rev(hi):5).  A workgroup
+// owns the pair of regions {mid, rev(mid)}: it stages both 32x32-element tiles in LDS
+// and writes each to the other's region, so reads and writes are both 32 elements
+// contiguous and the permutation is safe in place.
+struct BitrevParams {
+    const uint64_t* src[MAXC];
+    uint64_t* dst[MAXC];
+    unsigned log_n;
+};
+template <int V>
+__global__ void __launch_bounds__(NT) bit_reverse_tiled(BitrevParams P) {
+    __shared__ uint64_t tile[2][32 * 33 * V];
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const unsigned log_mid = P.log_n - 10;
+    const unsigned mid = blockIdx.x;
+    const unsigned rmid = log_mid ? (__brev(mid) >> (32 - log_mid)) : 0;
+    if (rmid < mid) return;
+    const int ntile = (rmid == mid) ? 1 : 2;
+    for (int q = 0; q < ntile; q++) {
+        const unsigned m = q ? rmid : mid;
+        for (unsigned e = threadIdx.x; e < 32 * 32 * V; e += NT) {
+            const unsigned w = e % (32 * V), hi = e / (32 * V);         // w = lo*V + v
+            const size_t i = (((size_t)hi << (log_mid + 5)) | ((size_t)m << 5)) * V + w;
+            tile[q][hi * 33 * V + w] = src[i];
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < ntile; q++) {
+        const unsigned m_out = q ? mid : rmid;                          // data of region m goes to rev(m)
+        for (unsigned e = threadIdx.x; e < 32 * 32 * V; e += NT) {
+            const unsigned w = e % (32 * V), lo_r = e / (32 * V);       // output row = rev(lo)
+            const unsigned hi_r = w / V, v = w % V;                     // output col = rev(hi)
+            const unsigned lo = __brev(lo_r) >> 27, hi = __brev(hi_r) >> 27;
+            const size_t o = (((size_t)lo_r << (log_mid + 5)) | ((size_t)m_out << 5)) * V + w;
+            dst[o] = tile[q][hi * 33 * V + lo * V + v];
+        }
+    }
+}
+// small sizes (log_n < 10): one thread per element, OUT OF PLACE only (dst != src)
+template <int V>
+__global__ void __launch_bounds__(NT) bit_reverse_simple(BitrevParams P) {
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= ((size_t)1 << P.log_n)) return;
+    const size_t r = P.log_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - P.log_n)) : 0;
+    for (int v = 0; v < V; v++) dst[r * V + v] = src[i * V + v];
+}
+
+}  // namespace msntt

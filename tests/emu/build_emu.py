@@ -1,0 +1,30 @@
+"""TEST INFRASTRUCTURE ONLY: compile the product sources with g++ against the HIP
+execution-model simulator (tests/emu/hip/hip_runtime.h) into
+tests/emu/_build/libministark_emu.so, so kernel logic can be checked against the
+oracle without a GPU.  Never imported by the ministark_amd package."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "ministark_amd", "csrc")
+SO = os.path.join(HERE, "_build", "libministark_emu.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, "ministark_hip.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
+    deps = list(srcs) + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "ministark_hip.h")]
+    for d, _, files in os.walk(CSRC):
+        deps += [os.path.join(d, f) for f in files]
+    newest = max(os.path.getmtime(p) for p in deps)
+    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
+        return SO
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
+           "-Wno-unknown-pragmas"] + srcs + ["-o", SO]
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,178 @@
+"""NTT / iNTT / LDE / bit-reverse parity: HIP kernels (through the C ABI) vs the oracle.
+
+Shapes follow the reference's own GPU tests (gpu/tests/shaders.rs:17-117): sizes 2048,
+4096, 65536, subgroup and coset (offset = GENERATOR = 7), Fp and Fq3, forward and
+inverse -- bit-exact.  The `emu` variants run the same kernels under the simulator in
+tests/emu on CPU (kernel-logic check, not gpu); the `hip` variants are the parity tests
+proper on an MI355X.
+"""
+import numpy as np
+import pytest
+
+from oracle import cref
+from tests import backends
+from ministark_amd import (GOLDILOCKS_FP, GOLDILOCKS_FQ3, GpuFft, GpuIfft, GpuVec, Matrix,
+                           Radix2EvaluationDomain)
+
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _rand(n_words, seed):
+    return cref.random_elements(n_words, seed)
+
+
+def _run(kind, field, log_n, inverse, offset, ncols=1, seed=1):
+    pl = backends.planner(kind)
+    V = 3 if field == GOLDILOCKS_FQ3 else 1
+    n = 1 << log_n
+    dom = Radix2EvaluationDomain(n, offset)
+    cols = [_rand(n * V, seed + c) for c in range(ncols)]
+    vecs = [GpuVec.from_numpy(pl, c, field) for c in cols]
+    plan = (GpuIfft if inverse else GpuFft)(dom, field, pl)
+    for v in vecs:
+        plan.encode(v)
+    plan.execute()
+    for c, v in zip(cols, vecs):
+        want = cref.ntt(c, log_n, V, inverse, offset)
+        got = v.to_numpy()
+        bad = np.nonzero(want != got)[0]
+        assert bad.size == 0, f"mismatch at {bad[:8]} of {bad.size} (log_n={log_n} inv={inverse} off={offset} V={V})"
+    plan.close()
+
+
+# --- emu: every code path at the smallest size that reaches it -----------------------
+@pytest.mark.parametrize("log_n", [0, 1, 3, 8, 11])
+@pytest.mark.parametrize("inverse,offset", [(False, 1), (False, 7), (True, 1), (True, 7)])
+def test_small_sizes_emu(log_n, inverse, offset):
+    _run("emu", GOLDILOCKS_FP, log_n, inverse, offset, ncols=2)
+
+
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
+def test_multipass_forward_emu(log_n):
+    _run("emu", GOLDILOCKS_FP, log_n, False, 1)
+
+
+@pytest.mark.parametrize("log_n,inverse,offset", [(12, False, 7), (12, True, 1), (12, True, 7), (16, True, 7),
+                                                   (17, False, 7), (18, True, 7), (20, False, 7)])
+def test_multipass_variants_emu(log_n, inverse, offset):
+    _run("emu", GOLDILOCKS_FP, log_n, inverse, offset)
+
+
+@pytest.mark.parametrize("log_n,inverse,offset", [(5, False, 7), (11, True, 7), (12, False, 1), (13, True, 7), (17, False, 7)])
+def test_fq3_emu(log_n, inverse, offset):
+    _run("emu", GOLDILOCKS_FQ3, log_n, inverse, offset, ncols=2)
+
+
+# --- hip: the reference's shapes and beyond --------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,offset", [(11, 1), (12, 1), (16, 1), (11, 7), (12, 7)])
+def test_fft_with_64_bit_field(log_n, offset):          # gpu/tests/shaders.rs:17-40
+    _run("hip", GOLDILOCKS_FP, log_n, False, offset)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,offset", [(11, 1), (12, 1), (16, 1), (11, 7), (12, 7)])
+def test_fft_with_extension_field(log_n, offset):       # gpu/tests/shaders.rs:43-66
+    _run("hip", GOLDILOCKS_FQ3, log_n, False, offset)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,offset", [(11, 1), (12, 1), (11, 7), (12, 7)])
+def test_ifft(log_n, offset):                           # gpu/tests/shaders.rs:94-117
+    _run("hip", GOLDILOCKS_FP, log_n, True, offset)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", list(range(0, 25)))
+def test_all_sizes_forward_coset_hip(log_n):
+    _run("hip", GOLDILOCKS_FP, log_n, False, 7, ncols=3 if log_n < 20 else 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [9, 12, 13, 17, 20, 22, 24])
+@pytest.mark.parametrize("offset", [1, 7])
+def test_inverse_sizes_hip(log_n, offset):
+    _run("hip", GOLDILOCKS_FP, log_n, True, offset)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,inverse,offset", [(13, False, 7), (17, True, 7), (20, False, 7), (22, True, 1)])
+def test_fq3_sizes_hip(log_n, inverse, offset):
+    _run("hip", GOLDILOCKS_FQ3, log_n, inverse, offset, ncols=2)
+
+
+@pytest.mark.gpu
+def test_many_columns_hip():
+    _run("hip", GOLDILOCKS_FP, 16, False, 7, ncols=37)   # more than one launch group
+
+
+# --- round trip / properties at BASELINE's full size ----------------------------------
+@pytest.mark.gpu
+def test_roundtrip_2_24_hip():
+    pl = backends.planner("hip")
+    n = 1 << 24
+    x = _rand(n, 99)
+    v = GpuVec.from_numpy(pl, x)
+    dom = Radix2EvaluationDomain(n, 7)
+    f = GpuFft(dom, GOLDILOCKS_FP, pl); f.encode(v); f.execute()
+    y = v.to_numpy()
+    assert not np.array_equal(x, y)
+    g = GpuIfft(dom, GOLDILOCKS_FP, pl); g.encode(v); g.execute()
+    assert np.array_equal(v.to_numpy(), x)
+
+
+# --- bit reversal ------------------------------------------------------------------------
+def _bitrev(kind, field, log_n, ncols=2):
+    pl = backends.planner(kind)
+    V = 3 if field == GOLDILOCKS_FQ3 else 1
+    cols = [_rand((1 << log_n) * V, 5 + c) for c in range(ncols)]
+    m = Matrix.from_numpy(pl, cols, field)
+    m.bit_reverse_rows()
+    for c, got in zip(cols, m.to_numpy()):
+        assert np.array_equal(got, cref.bit_reverse(c, log_n, V))
+
+
+@pytest.mark.parametrize("log_n", [1, 4, 9, 10, 11, 13])
+@pytest.mark.parametrize("field", [GOLDILOCKS_FP, GOLDILOCKS_FQ3])
+def test_bit_reverse_emu(log_n, field):
+    _bitrev("emu", field, log_n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [0, 4, 10, 15, 20, 23])
+@pytest.mark.parametrize("field", [GOLDILOCKS_FP, GOLDILOCKS_FQ3])
+def test_bit_reverse_hip(log_n, field):
+    _bitrev("hip", field, log_n)
+
+
+# --- LDE -----------------------------------------------------------------------------------
+def _lde(kind, field, log_n, log_b, ncols=2, bit_reversed=True):
+    pl = backends.planner(kind)
+    V = 3 if field == GOLDILOCKS_FQ3 else 1
+    cols = [_rand((1 << log_n) * V, 50 + c) for c in range(ncols)]
+    m = Matrix.from_numpy(pl, cols, field)
+    out = m.lde(1 << log_b, 7, bit_reversed)
+    for c, keep, got in zip(cols, m.to_numpy(), out.to_numpy()):
+        assert np.array_equal(keep, c), "input column must be preserved"
+        assert np.array_equal(got, cref.lde(c, log_n, log_b, V, 7, bit_reversed))
+
+
+@pytest.mark.parametrize("log_n,log_b", [(4, 1), (8, 3), (9, 3), (10, 4), (12, 1), (13, 3)])
+def test_lde_emu(log_n, log_b):
+    _lde("emu", GOLDILOCKS_FP, log_n, log_b)
+
+
+def test_lde_fq3_emu():
+    _lde("emu", GOLDILOCKS_FQ3, 10, 3)
+    _lde("emu", GOLDILOCKS_FP, 10, 2, bit_reversed=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,log_b", [(9, 4), (11, 3), (16, 3), (20, 3), (18, 0)])
+def test_lde_hip(log_n, log_b):
+    _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=3)
+
+
+@pytest.mark.gpu
+def test_lde_fq3_hip():
+    _lde("hip", GOLDILOCKS_FQ3, 14, 3)
