@@ -55,6 +55,12 @@ int ms_sync(ms_ctx* ctx);                      /* command_buffer.wait_until_comp
 void* ms_ctx_stream(ms_ctx* ctx);              /* the hipStream_t work is enqueued on   */
 const char* ms_last_error(void);
 size_t ms_field_bytes(int field);              /* 8 / 24 / 32 */
+/* Per-launch timing (the reference's `Timer` / Instant prints, src/utils.rs:32-51,
+ * src/prover.rs:30-159): with profiling on, every kernel launch is bracketed by hipEvents
+ * on the context's stream.  ms_profile_read blocks and writes lines
+ * "kernel_name calls total_microseconds algorithmic_bytes_per_call". */
+int ms_profile_enable(ms_ctx* ctx, int on);
+int ms_profile_read(ms_ctx* ctx, char* buf, size_t cap);
 
 /* ---- memory: GpuAllocator + buffer_no_copy (src/utils.rs:438-470, gpu/src/utils.rs:103-134).
  * The reference aliases page-aligned host Vecs (unified memory); on a discrete GPU

@@ -40,6 +40,8 @@ class Lib:
             "ms_ctx_stream": (vp, [vp]),
             "ms_last_error": (ctypes.c_char_p, []),
             "ms_field_bytes": (sz, [i]),
+            "ms_profile_enable": (i, [vp, i]),
+            "ms_profile_read": (i, [vp, ctypes.c_char_p, sz]),
             "ms_alloc": (i, [vp, sz, c_void_pp]),
             "ms_free": (i, [vp, vp]),
             "ms_upload": (i, [vp, vp, vp, sz]),

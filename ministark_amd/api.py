@@ -49,6 +49,21 @@ class Planner:
     def stream(self):
         return self.lib.ms_ctx_stream(self.handle)
 
+    def profile(self, on=True):
+        """Bracket every kernel launch with hipEvents on the context's stream."""
+        self.lib.check(self.lib.ms_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        """-> {kernel: {"calls", "total_us", "avg_us", "bytes_per_call"}} (blocks)."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self.lib.check(self.lib.ms_profile_read(self.handle, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, us, b = line.split()
+            out[name] = {"calls": int(calls), "total_us": float(us), "avg_us": float(us) / int(calls),
+                         "bytes_per_call": float(b)}
+        return out
+
     def close(self):
         if self.handle:
             self.lib.ms_ctx_destroy(self.handle)

@@ -72,6 +72,25 @@ struct ms_ctx {
     size_t scratch_bytes = 0;
     size_t group_bytes = (size_t)32 << 20;   // columns are processed in groups of about this size
     std::mutex mu;
+    // optional per-launch timing (ms_profile_*): hipEvent pairs around every kernel launch
+    bool profiling = false;
+    struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes; };
+    std::vector<ProfRec> prof;
+};
+
+// RAII: brackets one kernel launch with events on the context's stream when profiling is on
+struct ProfScope {
+    ms_ctx* ctx; hipEvent_t e0 = nullptr, e1 = nullptr; const char* name; double bytes;
+    ProfScope(ms_ctx* c, const char* nm, double algorithmic_bytes) : ctx(c), name(nm), bytes(algorithmic_bytes) {
+        if (!ctx->profiling) return;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!ctx->profiling) return;
+        (void)hipEventRecord(e1, ctx->stream);
+        ctx->prof.push_back({name, e0, e1, bytes});
+    }
 };
 
 static int ctx_scratch(ms_ctx* ctx, size_t bytes, void** out) {
@@ -120,6 +139,35 @@ extern "C" int ms_sync(ms_ctx* ctx) {
     return MS_OK;
 }
 extern "C" void* ms_ctx_stream(ms_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int ms_profile_enable(ms_ctx* ctx, int on) {
+    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    ctx->prof.clear();
+    ctx->profiling = on != 0;
+    return MS_OK;
+}
+// Writes one line per kernel name: "name calls total_us algorithmic_bytes_per_call\n".
+extern "C" int ms_profile_read(ms_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || !cap) return fail(MS_ERR_INVALID, "ms_profile_read: null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    struct Acc { const char* name; unsigned calls; double us; double bytes; };
+    std::vector<Acc> acc;
+    for (auto& r : ctx->prof) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        bool found = false;
+        for (auto& a : acc) if (!strcmp(a.name, r.name)) { a.calls++; a.us += ms * 1e3; a.bytes += r.bytes; found = true; break; }
+        if (!found) acc.push_back({r.name, 1, ms * 1e3, r.bytes});
+    }
+    std::string out;
+    char line[256];
+    for (auto& a : acc) { snprintf(line, sizeof line, "%s %u %.3f %.0f\n", a.name, a.calls, a.us, a.bytes / a.calls); out += line; }
+    if (out.size() + 1 > cap) return fail(MS_ERR_INVALID, "profile buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return MS_OK;
+}
 
 extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {
     if (!ctx || !d_ptr) return fail(MS_ERR_INVALID, "ms_alloc: null argument");
@@ -209,6 +257,7 @@ static int ctx_plan(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uint6
 
 static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, uint64_t h, ms_ntt_plan** out) {
     const int inverse = inverse_b ? 1 : 0;
+    HIPCHK(hipSetDevice(ctx->device));
     const uint64_t gen = gl::root_of_unity(log_n);           // plain, arkworks get_root_of_unity
     ms_ntt_plan* p = new ms_ntt_plan();
     p->ctx = ctx; p->V = V; p->log_n = log_n; p->inverse = inverse != 0; p->coset = (h != 1);
@@ -329,6 +378,7 @@ static void launch_mid(bool inv, bool last, int scale, dim3 grid, hipStream_t st
 static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows) {
     ms_ctx* ctx = p->ctx;
     hipStream_t st = ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << p->log_n;
     const size_t col_bytes = n * p->V * 8;
     if (p->small) {
@@ -339,6 +389,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             memset(&S, 0, sizeof S);
             for (unsigned c = 0; c < nc; c++) { S.src[c] = (const uint64_t*)src[c0 + c]; S.dst[c] = (uint64_t*)dst[c0 + c]; }
             S.tw = p->d_tw; S.scale_in = p->d_scale_in; S.scale_out = p->d_scale_out; S.log_n = p->log_n; S.V = p->V;
+            ProfScope ps(ctx, "ntt_small", 2.0 * col_bytes * nc);
             hipLaunchKernelGGL(msntt::ntt_small, dim3(1, nc), dim3(msntt::NT), 0, st, S);
         }
         HIPCHK(hipGetLastError());
@@ -367,6 +418,8 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             for (unsigned f = 0; f < P.nfields; f++) P.fields[f] = p->fields[q][f];
             P.scale_const = p->scale_const;
             dim3 grid(tiles, nc);
+            static const char* const pass_names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
+            ProfScope ps(ctx, pass_names[q], 2.0 * col_bytes * nc);
             if (q == 0) {
                 const bool cos = (!p->inverse && p->coset);
                 if (p->inverse) hipLaunchKernelGGL((msntt::ntt_first_pass<true, false>), grid, dim3(msntt::NT), 0, st, P);
@@ -414,6 +467,7 @@ extern "C" int ms_ntt_execute(ms_ntt_plan* plan) {
 // ---------------------------------------------------------------------------------------
 static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* const* src, void* const* dst, unsigned ncols) {
     hipStream_t st = ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << log_n;
     if (log_n >= 10) {
         for (unsigned c0 = 0; c0 < ncols; c0 += MAXC) {
@@ -423,6 +477,7 @@ static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* 
             for (unsigned c = 0; c < nc; c++) { B.src[c] = (const uint64_t*)src[c0 + c]; B.dst[c] = (uint64_t*)dst[c0 + c]; }
             B.log_n = log_n;
             dim3 grid((unsigned)(n >> 10), nc);
+            ProfScope ps(ctx, "bit_reverse", 2.0 * n * V * 8 * nc);
             if (V == 1) hipLaunchKernelGGL(msntt::bit_reverse_tiled<1>, grid, dim3(msntt::NT), 0, st, B);
             else hipLaunchKernelGGL(msntt::bit_reverse_tiled<3>, grid, dim3(msntt::NT), 0, st, B);
         }
