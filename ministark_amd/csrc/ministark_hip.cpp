@@ -331,6 +331,9 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             }
         }
     }
+    // device tables are in Montgomery form: gld::mmul(data, w * 2^64) = data * w
+    for (auto& v : host) v = gl::to_mont(v);
+    p->scale_const = gl::to_mont(p->scale_const);
     hipError_t e = hipMalloc(&p->d_tables, host.size() * 8);
     if (e != hipSuccess) { delete p; return fail(MS_ERR_NOMEM, "plan tables (%zu bytes): %s", host.size() * 8, hipGetErrorString(e)); }
     e = hipMemcpy(p->d_tables, host.data(), host.size() * 8, hipMemcpyHostToDevice);

@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gl.h"
+#include "gl_dev.h"
 
 namespace msntt {
 
@@ -63,12 +64,12 @@ struct PassParams {
 __device__ __forceinline__ uint64_t tw_pow(const PassParams& P, uint64_t e) {
     uint64_t lo = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
     uint64_t hi_i = e >> P.lo_bits;
-    return hi_i ? gl::mul(lo, P.tw_hi[hi_i]) : lo;
+    return hi_i ? gld::mmul(lo, P.tw_hi[hi_i]) : lo;
 }
 __device__ __forceinline__ uint64_t aux_pow(const PassParams& P, uint64_t e) {
     uint64_t lo = P.aux_lo[e & ((1u << P.lo_bits) - 1)];
     uint64_t hi_i = e >> P.lo_bits;
-    return hi_i ? gl::mul(lo, P.aux_hi[hi_i]) : lo;
+    return hi_i ? gld::mmul(lo, P.aux_hi[hi_i]) : lo;
 }
 __device__ __forceinline__ unsigned digit_rev(const PassParams& P, unsigned x) {
     unsigned r = 0;
@@ -77,47 +78,9 @@ __device__ __forceinline__ unsigned digit_rev(const PassParams& P, unsigned x) {
     return r;
 }
 
-// ---- radix-2^k butterfly networks in registers ---------------------------------
-// w_16 = 2^156 (arkworks' 16th root of unity for Goldilocks is a power of two:
-// 7^((p-1)/16) = 2^156); table of w_16^j, and of its inverse powers.
-__device__ static const uint64_t W16_FWD[8] = {
-    1ull, 17293822564807737345ull, 18446744069397807105ull, 4503599626321920ull,
-    281474976710656ull, 4096ull, 18446742969902956801ull, 18446744000695107585ull};
-__device__ static const uint64_t W16_INV[8] = {
-    1ull, 68719476736ull, 1099511627520ull, 18446744069414580225ull,
-    18446462594437873665ull, 18442240469788262401ull, 16777216ull, 1152921504606846976ull};
-
-// In-register DFT of N (power of two <= 16) values, natural order in and out:
-//   X[c] = sum_a x[a] w_N^(a c),  w_N = w_16^(16/N)  (inverse: w_16^-1)
-template <int N, bool INV>
-__device__ __forceinline__ void dft_regs(uint64_t* x) {
-    if constexpr (N == 1) return;
-    // bit-reversal by register renaming
-    constexpr int LOGN = (N == 2) ? 1 : (N == 4) ? 2 : (N == 8) ? 3 : 4;
-    #pragma unroll
-    for (int i = 0; i < N; i++) {
-        int r = 0;
-        #pragma unroll
-        for (int b = 0; b < LOGN; b++) r |= ((i >> b) & 1) << (LOGN - 1 - b);
-        if (r > i) { uint64_t t = x[i]; x[i] = x[r]; x[r] = t; }
-    }
-    const uint64_t* W = INV ? W16_INV : W16_FWD;
-    #pragma unroll
-    for (int s = 1; s <= LOGN; s++) {
-        const int half = 1 << (s - 1);
-        #pragma unroll
-        for (int blk = 0; blk < N; blk += 2 * half) {
-            #pragma unroll
-            for (int i = 0; i < half; i++) {
-                const int e = i * (16 >> s);            // exponent of w_16, < 8
-                uint64_t u = x[blk + i];
-                uint64_t t = (e == 0) ? x[blk + i + half] : gl::mul(x[blk + i + half], W[e]);
-                x[blk + i] = gl::add(u, t);
-                x[blk + i + half] = gl::sub(u, t);
-            }
-        }
-    }
-}
+// The radix-16 / radix-(Rp/16) register networks are gld::dft_lazy (gl_dev.h): inputs
+// canonical, outputs weak; every table below is in MONTGOMERY form (w * 2^64 mod p) so that
+// gld::mmul(data, table) = data * w, canonical, for weak `data`.
 
 // ---- pass 1 ----------------------------------------------------------------------
 // grid = (n*V/256/16, columns).  COSET: input scaled by h^j (offset != 1, forward).
@@ -140,13 +103,14 @@ __global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
             x[a] = (16u * a + b < P.valid_rows) ? src[(size_t)(16 * a + b) * row_words + w0 + t] : 0;
         if constexpr (COSET) {
             #pragma unroll
-            for (int a = 0; a < 16; a++) x[a] = gl::mul(x[a], P.gtab[16 * a + b]);
+            for (int a = 0; a < 16; a++) x[a] = gld::mmul(x[a], P.gtab[16 * a + b]);
         }
-        dft_regs<16, INV>(x);
-        // internal twiddle w_256^(b c), then exchange so that thread (c, t) gets all b
+        gld::dft_lazy<16, INV>(x);
+        // internal twiddle w_256^(b c) (also canonicalises: wr[0] = 1), then exchange so that
+        // thread (c, t) gets all b
         #pragma unroll
         for (int c = 0; c < 16; c++) {
-            uint64_t y = (c == 0 || b == 0) ? x[c] : gl::mul(x[c], P.wr[(b * c) & 255]);
+            const uint64_t y = gld::mmul(x[c], P.wr[(b * c) & 255]);
             lds[t * 256 + (((b << 4) | c) ^ (t | ((t & 1) << 4)))] = y;
         }
     }
@@ -157,19 +121,19 @@ __global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
         uint64_t y[16];
         #pragma unroll
         for (int b = 0; b < 16; b++) y[b] = lds[t * 256 + (((b << 4) | c) ^ (t | ((t & 1) << 4)))];
-        dft_regs<16, INV>(y);
+        gld::dft_lazy<16, INV>(y);
         const size_t w = w0 + t;
         const unsigned jp = (unsigned)(w / V), v = (unsigned)(w % V);
         const size_t out_base = ((size_t)digit_rev(P, jp) << 8) * V + v;
         // twiddle (h w_n^k1)^j' for k1 = c + 16 d:  A * B^d   (j'*k1 < n: no wrap)
         uint64_t A = tw_pow(P, (uint64_t)jp * c);
-        if constexpr (COSET) A = gl::mul(A, aux_pow(P, jp));
+        if constexpr (COSET) A = gld::mmul(A, aux_pow(P, jp));
         const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
         uint64_t tw = A;
         #pragma unroll
         for (int d = 0; d < 16; d++) {
-            dst[out_base + (size_t)(c + 16 * d) * V] = gl::mul(y[d], tw);
-            if (d < 15) tw = gl::mul(tw, B);
+            dst[out_base + (size_t)(c + 16 * d) * V] = gld::mmul(y[d], tw);
+            if (d < 15) tw = gld::mmul(tw, B);
         }
     }
 }
@@ -206,7 +170,7 @@ __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
         const unsigned t = tid;
         #pragma unroll
         for (int a = 0; a < 16; a++) y[a] = src[base + (size_t)a * sw + t];
-        dft_regs<16, INV>(y);
+        gld::dft_lazy<16, INV>(y);
         if constexpr (!LAST) __syncthreads();
     } else {
         {
@@ -214,12 +178,10 @@ __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
             uint64_t x[16];
             #pragma unroll
             for (int a = 0; a < 16; a++) x[a] = src[base + (size_t)(a * RB + b) * sw + t];
-            dft_regs<16, INV>(x);
+            gld::dft_lazy<16, INV>(x);
             #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                uint64_t z = (c == 0 || b == 0) ? x[c] : gl::mul(x[c], P.wr[(b * c) & (R - 1)]);
-                lds[c * LDS_PAD_CS + b * T + t] = z;
-            }
+            for (int c = 0; c < 16; c++)
+                lds[c * LDS_PAD_CS + b * T + t] = gld::mmul(x[c], P.wr[(b * c) & (R - 1)]);
         }
         __syncthreads();
         {
@@ -228,7 +190,7 @@ __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
             for (int g = 0; g < G; g++) {
                 #pragma unroll
                 for (int b = 0; b < RB; b++) y[g * RB + b] = lds[(cl * G + g) * LDS_PAD_CS + b * T + t];
-                dft_regs<RB, INV>(y + g * RB);
+                gld::dft_lazy<RB, INV>(y + g * RB);
             }
         }
     }
@@ -243,11 +205,13 @@ __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
                 uint64_t val = y[g * RB + d];
                 const size_t pos = base + (size_t)k * sw + t;
                 if constexpr (!LAST) {
-                    val = gl::mul(val, twl[k]);
+                    val = gld::mmul(val, twl[k]);
                 } else if constexpr (SCALE == 1) {
-                    val = gl::mul(val, P.scale_const);
+                    val = gld::mmul(val, P.scale_const);
                 } else if constexpr (SCALE == 2) {
-                    val = gl::mul(val, aux_pow(P, pos / V));
+                    val = gld::mmul(val, aux_pow(P, pos / V));
+                } else {
+                    val = gld::canon(val);
                 }
                 dst[pos] = val;
             }
@@ -276,7 +240,7 @@ __global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
     for (unsigned v = 0; v < V; v++) {
         for (unsigned j = tid; j < n; j += NT) {
             uint64_t x = src[(size_t)j * V + v];
-            if (P.scale_in) x = gl::mul(x, P.scale_in[j]);
+            if (P.scale_in) x = gld::mmul(x, P.scale_in[j]);
             const unsigned r = P.log_n ? (__brev(j) >> (32 - P.log_n)) : 0;
             lds[r] = x;
         }
@@ -286,7 +250,7 @@ __global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
             for (unsigned q = tid; q < n / 2; q += NT) {
                 const unsigned i = q & (half - 1), lo = ((q >> (s - 1)) << s) + i, hi = lo + half;
                 uint64_t u = lds[lo];
-                uint64_t t = gl::mul(lds[hi], P.tw[i << (P.log_n - s)]);
+                uint64_t t = gld::mmul(lds[hi], P.tw[i << (P.log_n - s)]);
                 lds[lo] = gl::add(u, t);
                 lds[hi] = gl::sub(u, t);
             }
@@ -294,7 +258,7 @@ __global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
         }
         for (unsigned k = tid; k < n; k += NT) {
             uint64_t x = lds[k];
-            if (P.scale_out) x = gl::mul(x, P.scale_out[k]);
+            if (P.scale_out) x = gld::mmul(x, P.scale_out[k]);
             dst[(size_t)k * V + v] = x;
         }
         __syncthreads();

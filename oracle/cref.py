@@ -26,10 +26,23 @@ def build(force=False):
     return _SO
 
 
+def _cpu_budget():
+    """CPUs this process may really use: min(affinity, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_budget()))
         L = ctypes.CDLL(_SO)
         L.oracle_gl_to_mont.restype = ctypes.c_uint64
         L.oracle_gl_to_mont.argtypes = [ctypes.c_uint64]
