@@ -103,6 +103,37 @@ int ms_bit_reverse(ms_ctx* ctx, int field, unsigned log_n, void* const* d_column
 int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowup, const void* h_offset,
            const void* const* d_in, void* const* d_out, unsigned ncols, int bit_reversed);
 
+/* ---- element-wise stages (gpu/src/stage.rs:115-1155; kernels evaluation_shaders.h.metal:11-168).
+ * lf / rf are the fields of lhs(=dst) and rhs: (Fp,Fp), (Fq3,Fq3) or (Fq3,Fp) -- the GpuMul / GpuAdd
+ * impls of gpu/src/fields.rs:55-216.  `shift` rotates the rhs index: rhs[(i + shift) mod n], any sign
+ * (the reference normalises with (n + shift) % n, stage.rs:168,227,449,515).  d_dst may alias d_lhs
+ * (the *Assign / *InPlace stages) but not d_rhs when shift != 0.  All calls are asynchronous.
+ *   ms_binary        MulAssign / MulInto / AddAssign / AddInto            (stage.rs:115-233, 393-521)
+ *   ms_binary_const  {Mul,Add}{Into,Assign}Const                          (stage.rs:523-806)
+ *   ms_mul_pow       MulPowStage: dst = lhs * rhs[(i+shift)%n]^power      (stage.rs:334-391)
+ *   ms_unary         Neg / Inverse / Exp, in place or into                (stage.rs:808-1109);
+ *                    inverse of 0 is 0; Fq3 inverse is implemented (a todo!() in the reference)
+ *   ms_convert       ConvertIntoStage: Fp -> Fq3 embedding                (stage.rs:581-635)
+ *   ms_fill          FillBuffStage                                        (stage.rs:1111-1155)
+ *   ms_sum_columns   Matrix::sum_columns (src/matrix.rs:357-394)                              */
+int ms_binary(ms_ctx* ctx, int op, int lf, int rf, size_t n, void* d_dst, const void* d_lhs, const void* d_rhs, long shift);
+int ms_binary_const(ms_ctx* ctx, int op, int lf, int rf, size_t n, void* d_dst, const void* d_lhs, const void* h_const);
+int ms_mul_pow(ms_ctx* ctx, int lf, int rf, size_t n, void* d_dst, const void* d_lhs, const void* d_rhs, unsigned power, long shift);
+int ms_unary(ms_ctx* ctx, int op, int field, size_t n, void* d_dst, const void* d_src, unsigned exponent);
+int ms_convert(ms_ctx* ctx, int dst_field, int src_field, size_t n, void* d_dst, const void* d_src);
+int ms_fill(ms_ctx* ctx, int field, size_t n, void* d_dst, const void* h_value);
+int ms_sum_columns(ms_ctx* ctx, int field, size_t n, const void* const* d_cols, unsigned ncols, void* d_dst);
+
+/* ---- commitments: hash_rows + build_merkle_nodes with Sha256HashFn (src/merkle.rs:412-508,
+ * src/hash.rs:58-100; CPU-only in the reference).  Digests are 32 raw bytes.
+ * ms_sha256_rows   leaves[r] = SHA-256( ||_c canonical little-endian bytes of d_cols[c][r] )
+ *                  (Matrix::hash_rows / MatrixMerkleTree::from_matrix's leaf layer)
+ * ms_sha256_merkle nodes[] has nleaves slots of 32 bytes: nodes[k] = SHA-256(nodes[2k]||nodes[2k+1]),
+ *                  leaf pairs feed nodes[nleaves/2 ..), nodes[1] = root, nodes[0] = zero
+ *                  (MerkleTreeImpl::new -> build_merkle_nodes).  nleaves = 2^k >= 2. */
+int ms_sha256_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_leaves);
+int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leaves, void* d_nodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,15 @@ class Lib:
             "ms_ntt_enqueue": (i, [vp, c_void_pp, u]),
             "ms_bit_reverse": (i, [vp, i, u, c_void_pp, u]),
             "ms_lde": (i, [vp, i, u, u, vp, c_void_pp, c_void_pp, u, i]),
+            "ms_binary": (i, [vp, i, i, i, sz, vp, vp, vp, ctypes.c_long]),
+            "ms_binary_const": (i, [vp, i, i, i, sz, vp, vp, vp]),
+            "ms_mul_pow": (i, [vp, i, i, sz, vp, vp, vp, u, ctypes.c_long]),
+            "ms_unary": (i, [vp, i, i, sz, vp, vp, u]),
+            "ms_convert": (i, [vp, i, i, sz, vp, vp]),
+            "ms_fill": (i, [vp, i, sz, vp, vp]),
+            "ms_sum_columns": (i, [vp, i, sz, c_void_pp, u, vp]),
+            "ms_sha256_rows": (i, [vp, i, sz, c_void_pp, u, vp]),
+            "ms_sha256_merkle": (i, [vp, sz, vp, vp]),
         }
         self.optional = {}
         for name, (res, args) in sigs.items():

@@ -137,6 +137,54 @@ class GpuVec:
             pass
 
 
+class DeviceBytes:
+    """Raw device allocation (digest arrays)."""
+
+    def __init__(self, planner, nbytes):
+        self.planner = planner
+        self.nbytes = nbytes
+        p = ctypes.c_void_p()
+        planner.lib.check(planner.lib.ms_alloc(planner.handle, max(nbytes, 32), ctypes.byref(p)))
+        self.ptr = p.value
+
+    def to_numpy(self):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        self.planner.lib.check(self.planner.lib.ms_download(self.planner.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.planner.lib.ms_free(self.planner.handle, self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class MerkleTree:
+    """`MatrixMerkleTreeImpl<Sha256HashFn>` (src/merkle.rs:296-361): `from_matrix` hashes the
+    rows and builds the node array on device; `root` is nodes[1] (src/merkle.rs:145-147)."""
+
+    def __init__(self, planner, leaves, nleaves):
+        self.planner = planner
+        self.leaves = leaves
+        self.nleaves = nleaves
+        self.nodes = DeviceBytes(planner, nleaves * 32)
+        planner.lib.check(planner.lib.ms_sha256_merkle(planner.handle, nleaves, leaves.ptr, self.nodes.ptr))
+
+    @classmethod
+    def from_matrix(cls, matrix):
+        return cls(matrix.planner, matrix.hash_rows(), matrix.num_rows())
+
+    def root(self):
+        out = np.empty(32, dtype=np.uint8)
+        self.planner.lib.check(self.planner.lib.ms_download(self.planner.handle, out.ctypes.data, self.nodes.ptr + 32, 32))
+        return out.tobytes()
+
+    def nodes_numpy(self):
+        return self.nodes.to_numpy().reshape(self.nleaves, 32)
+
+
 class Radix2EvaluationDomain:
     """ark_poly::Radix2EvaluationDomain over Goldilocks as the reference uses it
     (gpu/src/plan.rs:386-423): `new(n)` / `new_coset(n, offset)`; constants are canonical
@@ -315,6 +363,15 @@ class Matrix:
 
     def bit_reversed_evaluate(self, domain):           # src/matrix.rs:245-251
         return self.clone().into_bit_reversed_evaluations(domain)
+
+    def hash_rows(self):
+        """`hash_rows::<F, Sha256HashFn>` (src/merkle.rs:412-436, src/matrix.rs:254-280):
+        one SHA-256 digest per row -> DeviceBytes of num_rows x 32."""
+        pl = self.planner
+        n = self.num_rows()
+        leaves = DeviceBytes(pl, n * 32)
+        pl.lib.check(pl.lib.ms_sha256_rows(pl.handle, self.field, n, _ptr_array(self.columns), len(self.columns), leaves.ptr))
+        return leaves
 
     def lde(self, blowup, offset=GL_GENERATOR, bit_reversed=True):
         """Fused `interpolate(trace_domain)` + `bit_reversed_evaluate(lde_domain)`

@@ -15,6 +15,8 @@
 #include "../../include/ministark_hip.h"
 #include "gl.h"
 #include "ntt_kernels.h"
+#include "sha256_kernels.h"
+#include "stage_kernels.h"
 
 using msntt::MAXC;
 
@@ -549,4 +551,190 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         if (rc == MS_OK && bit_reversed) rc = bit_reverse_run(ctx, V, log_N, (const void* const*)d_out, d_out, ncols);
     }
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// SHA-256 commitments
+// ---------------------------------------------------------------------------------------
+extern "C" int ms_sha256_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_leaves) {
+    if (!ctx || (!d_cols && ncols) || !d_leaves) return fail(MS_ERR_INVALID, "ms_sha256_rows: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (ncols > (unsigned)mssha::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per commitment", mssha::MAXCOLS);
+    if (nrows == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    mssha::RowsParams P;
+    memset(&P, 0, sizeof P);
+    for (unsigned c = 0; c < ncols; c++) P.cols[c] = (const uint64_t*)d_cols[c];
+    P.leaves = (uint8_t*)d_leaves; P.nrows = nrows; P.ncols = ncols; P.V = V;
+    {
+        ProfScope ps(ctx, "sha256_rows", (double)nrows * ncols * V * 8 + 32.0 * nrows);
+        hipLaunchKernelGGL(mssha::sha256_rows, dim3((unsigned)((nrows + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, P);
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leaves, void* d_nodes) {
+    if (!ctx || !d_leaves || !d_nodes) return fail(MS_ERR_INVALID, "ms_sha256_merkle: null argument");
+    if (nleaves < 2 || (nleaves & (nleaves - 1))) return fail(MS_ERR_INVALID, "number of leaves must be a power of two >= 2");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    uint8_t* nodes = (uint8_t*)d_nodes;
+    HIPCHK(hipMemsetAsync(nodes, 0, 32, ctx->stream));
+    const uint8_t* src = (const uint8_t*)d_leaves;
+    for (size_t count = nleaves / 2; count >= 1; count >>= 1) {
+        uint8_t* dst = nodes + count * 32;
+        ProfScope ps(ctx, "sha256_merkle_level", 96.0 * count);
+        hipLaunchKernelGGL(mssha::sha256_merge_level, dim3((unsigned)((count + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, src, dst, count);
+        src = dst;
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// element-wise stages
+// ---------------------------------------------------------------------------------------
+static unsigned stream_grid(size_t n) { return (unsigned)std::max<size_t>(1, std::min<size_t>((n + msstage::NT - 1) / msstage::NT, 256 * 16)); }
+static int field_pair(int lf, int rf, unsigned* VL, unsigned* VR) {
+    MSCHK(field_words(lf, VL));
+    MSCHK(field_words(rf, VR));
+    if (*VR > *VL) return fail(MS_ERR_UNSUPPORTED, "rhs field must embed into the lhs field (Fp,Fp / Fq3,Fq3 / Fq3,Fp)");
+    return MS_OK;
+}
+static size_t norm_shift(long shift, size_t n) {
+    if (n == 0) return 0;
+    long long m = (long long)shift % (long long)n;
+    if (m < 0) m += (long long)n;
+    return (size_t)m;
+}
+extern "C" int ms_binary(ms_ctx* ctx, int op, int lf, int rf, size_t n, void* d_dst, const void* d_lhs, const void* d_rhs, long shift) {
+    if (!ctx || !d_dst || !d_lhs || !d_rhs) return fail(MS_ERR_INVALID, "ms_binary: null argument");
+    if (op != MS_ADD && op != MS_MUL) return fail(MS_ERR_INVALID, "unknown binary op %d", op);
+    unsigned VL = 0, VR = 0;
+    MSCHK(field_pair(lf, rf, &VL, &VR));
+    if (n == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t sh = norm_shift(shift, n);
+    uint64_t* dst = (uint64_t*)d_dst; const uint64_t* l = (const uint64_t*)d_lhs; const uint64_t* r = (const uint64_t*)d_rhs;
+    dim3 g(stream_grid(n)), b(msstage::NT);
+    ProfScope ps(ctx, op == MS_ADD ? "stage_add" : "stage_mul", 8.0 * n * (2 * VL + VR));
+    using namespace msstage;
+    if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
+    else if (VR == 3) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fq3T, Fq3T, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fq3T, Fq3T, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
+    else { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fq3T, FpT, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fq3T, FpT, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_binary_const(ms_ctx* ctx, int op, int lf, int rf, size_t n, void* d_dst, const void* d_lhs, const void* h_const) {
+    if (!ctx || !d_dst || !d_lhs || !h_const) return fail(MS_ERR_INVALID, "ms_binary_const: null argument");
+    if (op != MS_ADD && op != MS_MUL) return fail(MS_ERR_INVALID, "unknown binary op %d", op);
+    unsigned VL = 0, VR = 0;
+    MSCHK(field_pair(lf, rf, &VL, &VR));
+    if (n == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    msstage::Const3 c = {{0, 0, 0}};
+    memcpy(c.w, h_const, VR * 8);
+    uint64_t* dst = (uint64_t*)d_dst; const uint64_t* l = (const uint64_t*)d_lhs;
+    dim3 g(stream_grid(n)), b(msstage::NT);
+    ProfScope ps(ctx, op == MS_ADD ? "stage_add_const" : "stage_mul_const", 16.0 * n * VL);
+    using namespace msstage;
+    if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
+    else if (VR == 3) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fq3T, Fq3T, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fq3T, Fq3T, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
+    else { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fq3T, FpT, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fq3T, FpT, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_mul_pow(ms_ctx* ctx, int lf, int rf, size_t n, void* d_dst, const void* d_lhs, const void* d_rhs, unsigned power, long shift) {
+    if (!ctx || !d_dst || !d_lhs || !d_rhs) return fail(MS_ERR_INVALID, "ms_mul_pow: null argument");
+    unsigned VL = 0, VR = 0;
+    MSCHK(field_pair(lf, rf, &VL, &VR));
+    if (n == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t sh = norm_shift(shift, n);
+    uint64_t* dst = (uint64_t*)d_dst; const uint64_t* l = (const uint64_t*)d_lhs; const uint64_t* r = (const uint64_t*)d_rhs;
+    dim3 g(stream_grid(n)), b(msstage::NT);
+    ProfScope ps(ctx, "stage_mul_pow", 8.0 * n * (2 * VL + VR));
+    using namespace msstage;
+    if (VL == 1) hipLaunchKernelGGL((k_mul_pow<FpT, FpT>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
+    else if (VR == 3) hipLaunchKernelGGL((k_mul_pow<Fq3T, Fq3T>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
+    else hipLaunchKernelGGL((k_mul_pow<Fq3T, FpT>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_unary(ms_ctx* ctx, int op, int field, size_t n, void* d_dst, const void* d_src, unsigned exponent) {
+    if (!ctx || !d_dst || !d_src) return fail(MS_ERR_INVALID, "ms_unary: null argument");
+    if (op != MS_NEG && op != MS_INV && op != MS_EXP) return fail(MS_ERR_INVALID, "unknown unary op %d", op);
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (n == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t* dst = (uint64_t*)d_dst; const uint64_t* src = (const uint64_t*)d_src;
+    dim3 g(stream_grid(n)), b(msstage::NT);
+    ProfScope ps(ctx, op == MS_NEG ? "stage_neg" : op == MS_INV ? "stage_inverse" : "stage_exp", 16.0 * n * V);
+    using namespace msstage;
+    if (V == 1) {
+        if (op == MS_NEG) hipLaunchKernelGGL((k_unary<FpT, 0>), g, b, 0, ctx->stream, dst, src, n, exponent);
+        else if (op == MS_INV) hipLaunchKernelGGL((k_unary<FpT, 1>), g, b, 0, ctx->stream, dst, src, n, exponent);
+        else hipLaunchKernelGGL((k_unary<FpT, 2>), g, b, 0, ctx->stream, dst, src, n, exponent);
+    } else {
+        if (op == MS_NEG) hipLaunchKernelGGL((k_unary<Fq3T, 0>), g, b, 0, ctx->stream, dst, src, n, exponent);
+        else if (op == MS_INV) hipLaunchKernelGGL((k_unary<Fq3T, 1>), g, b, 0, ctx->stream, dst, src, n, exponent);
+        else hipLaunchKernelGGL((k_unary<Fq3T, 2>), g, b, 0, ctx->stream, dst, src, n, exponent);
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_convert(ms_ctx* ctx, int dst_field, int src_field, size_t n, void* d_dst, const void* d_src) {
+    if (!ctx || !d_dst || !d_src) return fail(MS_ERR_INVALID, "ms_convert: null argument");
+    unsigned VD = 0, VS = 0;
+    MSCHK(field_pair(dst_field, src_field, &VD, &VS));
+    if (n == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (VD == VS) {
+        if (d_dst != d_src) HIPCHK(hipMemcpyAsync(d_dst, d_src, n * VD * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return MS_OK;
+    }
+    ProfScope ps(ctx, "stage_convert", 8.0 * n * (VD + VS));
+    hipLaunchKernelGGL(msstage::k_convert_fp_fq3, dim3(stream_grid(n)), dim3(msstage::NT), 0, ctx->stream, (uint64_t*)d_dst, (const uint64_t*)d_src, n);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_fill(ms_ctx* ctx, int field, size_t n, void* d_dst, const void* h_value) {
+    if (!ctx || !d_dst || !h_value) return fail(MS_ERR_INVALID, "ms_fill: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (n == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    msstage::Const3 c = {{0, 0, 0}};
+    memcpy(c.w, h_value, V * 8);
+    ProfScope ps(ctx, "stage_fill", 8.0 * n * V);
+    hipLaunchKernelGGL(msstage::k_fill, dim3(stream_grid(n * V)), dim3(msstage::NT), 0, ctx->stream, (uint64_t*)d_dst, c, n * V, V);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_sum_columns(ms_ctx* ctx, int field, size_t n, const void* const* d_cols, unsigned ncols, void* d_dst) {
+    if (!ctx || !d_cols || !d_dst) return fail(MS_ERR_INVALID, "ms_sum_columns: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (ncols == 0) return fail(MS_ERR_INVALID, "sum of zero columns");
+    if (ncols > (unsigned)msstage::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per call", msstage::MAXCOLS);
+    if (n == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    msstage::SumParams P;
+    memset(&P, 0, sizeof P);
+    for (unsigned c = 0; c < ncols; c++) P.cols[c] = (const uint64_t*)d_cols[c];
+    P.dst = (uint64_t*)d_dst; P.nwords = n * V; P.ncols = ncols;
+    ProfScope ps(ctx, "sum_columns", 8.0 * n * V * (ncols + 1));
+    hipLaunchKernelGGL(msstage::k_sum_columns, dim3(stream_grid(n * V)), dim3(msstage::NT), 0, ctx->stream, P);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
 }

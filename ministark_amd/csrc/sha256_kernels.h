@@ -1,0 +1,142 @@
+// SHA-256 Merkle commitments for gfx950.
+//
+// Replaces the reference's CPU path (the reference has no GPU SHA-256):
+//   hash_rows           src/merkle.rs:412-436 + Sha256HashFn::hash_elements src/hash.rs:92-99
+//                       leaf[r] = SHA-256( ||_c serialize_uncompressed(M[c][r]) ), i.e. the
+//                       canonical (non-Montgomery) integer of every limb, little-endian, 8 bytes
+//                       per Goldilocks word (Fq3 = c0||c1||c2)
+//   build_merkle_nodes  src/merkle.rs:438-508: nodes[k] = SHA-256(nodes[2k] || nodes[2k+1]),
+//                       leaf pairs hash into nodes[n/2 .. n), nodes[1] is the root, nodes[0] unused.
+// One row (or node) per lane: the matrix is column-major so a wave reads 64 consecutive rows of a
+// column in one coalesced 512 B access, converts out of Montgomery form in registers and feeds
+// the words straight into the message schedule -- the rows are never materialised.
+// This phase is integer-ALU bound (64 rounds per 64-byte block), not HBM bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.h"
+#include "gl_dev.h"
+
+namespace mssha {
+
+static constexpr int MAXCOLS = 128;
+static constexpr int NT = 256;
+
+__device__ static const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) {
+    return (x >> 24) | ((x >> 8) & 0xFF00u) | ((x << 8) & 0xFF0000u) | (x << 24);
+}
+
+struct Sha {
+    uint32_t h[8];
+    uint32_t w[16];
+    __device__ __forceinline__ void init() {
+        h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+        h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+    }
+    // one compression of the 16 big-endian words in w[]
+    __device__ __forceinline__ void compress() {
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        #pragma unroll
+        for (int i = 0; i < 64; i++) {
+            uint32_t wi;
+            if (i < 16) wi = w[i];
+            else {
+                const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+                const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+                wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+                w[i & 15] = wi;
+            }
+            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+            const uint32_t ch = (e & f) ^ (~e & g);
+            const uint32_t t1 = hh + S1 + ch + K256[i] + wi;
+            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+            const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+};
+
+struct RowsParams {
+    const uint64_t* cols[MAXCOLS];
+    uint8_t* leaves;          // nrows x 32 bytes
+    size_t nrows;
+    unsigned ncols;
+    unsigned V;               // u64 words per element
+};
+
+// One row per lane.  Message word stream: for each column, for each limb v: the canonical value x
+// contributes bswap32(lo32(x)), bswap32(hi32(x)) (little-endian bytes read as big-endian words).
+__global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
+    const size_t r = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (r >= P.nrows) return;
+    Sha s;
+    s.init();
+    const unsigned words_per_row = P.ncols * P.V;          // u64 words
+    unsigned wpos = 0;                                      // position in the 16-word block
+    for (unsigned c = 0; c < P.ncols; c++) {
+        const uint64_t* __restrict__ col = P.cols[c];
+        for (unsigned v = 0; v < P.V; v++) {
+            const uint64_t x = gld::mmul(col[r * P.V + v], 1);     // out of Montgomery form, canonical
+            // wpos is always even here
+            #pragma unroll
+            for (int q = 0; q < 16; q += 2) if ((int)wpos == q) { s.w[q] = bswap32((uint32_t)x); s.w[q + 1] = bswap32((uint32_t)(x >> 32)); }
+            wpos += 2;
+            if (wpos == 16) { s.compress(); wpos = 0; }
+        }
+    }
+    // padding: 0x80, zeros, 64-bit big-endian bit length
+    const uint64_t bits = (uint64_t)words_per_row * 64;
+    #pragma unroll
+    for (int q = 0; q < 16; q += 2) if ((int)wpos == q) { s.w[q] = 0x80000000u; s.w[q + 1] = 0; }
+    #pragma unroll
+    for (int q = 2; q < 16; q += 2) if (q > (int)wpos) { s.w[q] = 0; s.w[q + 1] = 0; }
+    if (wpos + 2 > 14) {          // no room for the length in this block
+        s.compress();
+        #pragma unroll
+        for (int q = 0; q < 14; q++) s.w[q] = 0;
+    }
+    s.w[14] = (uint32_t)(bits >> 32);
+    s.w[15] = (uint32_t)bits;
+    s.compress();
+    uint32_t* out = (uint32_t*)(P.leaves + r * 32);
+    #pragma unroll
+    for (int q = 0; q < 8; q++) out[q] = bswap32(s.h[q]);
+}
+
+// nodes[out0 + i] = SHA-256(src[2i] || src[2i+1]) for i < count; digests are 32 raw bytes
+__global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t count) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= count) return;
+    Sha s;
+    s.init();
+    const uint4* in = (const uint4*)(src + i * 64);
+    #pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = in[q];
+        s.w[4 * q] = bswap32(v.x); s.w[4 * q + 1] = bswap32(v.y); s.w[4 * q + 2] = bswap32(v.z); s.w[4 * q + 3] = bswap32(v.w);
+    }
+    s.compress();
+    s.w[0] = 0x80000000u;
+    #pragma unroll
+    for (int q = 1; q < 15; q++) s.w[q] = 0;
+    s.w[15] = 512;
+    s.compress();
+    uint4* out = (uint4*)(dst + i * 32);
+    out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
+    out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
+}
+
+}  // namespace mssha

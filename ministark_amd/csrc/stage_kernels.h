@@ -1,0 +1,143 @@
+// Element-wise "stage" kernels for gfx950: the reference's 17 *Stage wrappers
+// (gpu/src/stage.rs:115-1155) over the kernels of gpu/src/metal/evaluation_shaders.h.metal:11-168,
+// instantiated there per field pair by host_name strings (:172-513).  Here one template per
+// operation, dispatched on (lhs field, rhs field); all values are Montgomery residues.
+//   {Add,Mul}{Assign,Into}       dst[i] = lhs[i] (+|*) rhs[(i + shift) mod n]     (:58-99)
+//   {Add,Mul}{Assign,Into}Const  dst[i] = lhs[i] (+|*) c                          (:101-145)
+//   MulPow                       dst[i] = lhs[i] * rhs[(i + shift) mod n]^e        (:149-161)
+//   {Neg,Inverse,Exp}{InPlace,Into}                                                (:11-56)
+//   ConvertInto (Fp -> Fq3 embedding), FillBuff                                    (:121-127,163-168)
+//   sum of columns (Matrix::sum_columns, src/matrix.rs:357-394, an AddAssign tree there)
+// dst may alias lhs ("Assign"/"InPlace" forms).  The Fq3 inverse the reference leaves as todo!()
+// (evaluation_shaders.h.metal:393,401; src/eval_gpu.rs:338) is provided.
+// Pure streaming kernels: HBM-bound for add/neg/convert/fill, ALU-bound for inverse/exp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.h"
+#include "gl_dev.h"
+
+namespace msstage {
+
+static constexpr int NT = 256;
+static constexpr int MAXCOLS = 128;
+
+struct FpT {
+    using T = uint64_t;
+    static constexpr int V = 1;
+    static __device__ __forceinline__ T load(const uint64_t* p, size_t i) { return p[i]; }
+    static __device__ __forceinline__ void store(uint64_t* p, size_t i, T x) { p[i] = x; }
+    static __device__ __forceinline__ T add(T a, T b) { return gl::add(a, b); }
+    static __device__ __forceinline__ T neg(T a) { return gl::neg(a); }
+    static __device__ __forceinline__ T mul(T a, T b) { return gld::mmul(a, b); }
+    static __device__ __forceinline__ T one() { return gl::ONE_MONT; }
+    static __device__ __forceinline__ T inv(T a) {
+        // x^(p-2), the 72-multiplication chain of felt_u64.h.metal:97-109
+        auto sqn = [](T x, int n) { for (int i = 0; i < n; i++) x = gld::mmul(x, x); return x; };
+        T t2 = gld::mmul(sqn(a, 1), a), t3 = gld::mmul(sqn(t2, 1), a), t6 = gld::mmul(sqn(t3, 3), t3);
+        T t12 = gld::mmul(sqn(t6, 6), t6), t24 = gld::mmul(sqn(t12, 12), t12), t30 = gld::mmul(sqn(t24, 6), t6);
+        T t31 = gld::mmul(sqn(t30, 1), a), t63 = gld::mmul(sqn(t31, 32), t31);
+        return gld::mmul(sqn(t63, 1), a);
+    }
+};
+struct Fq3T {
+    using T = gl::Fq3;
+    static constexpr int V = 3;
+    static __device__ __forceinline__ T load(const uint64_t* p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+    static __device__ __forceinline__ void store(uint64_t* p, size_t i, T x) { p[3 * i] = x.c0; p[3 * i + 1] = x.c1; p[3 * i + 2] = x.c2; }
+    static __device__ __forceinline__ T add(T a, T b) { return gl::add(a, b); }
+    static __device__ __forceinline__ T neg(T a) { return gl::neg(a); }
+    static __device__ __forceinline__ T mul(T a, T b) {
+        // 6 base multiplications (felt_u64.h.metal:205-231); the non-residue 2 is a doubling
+        const uint64_t ad = gld::mmul(a.c0, b.c0), be = gld::mmul(a.c1, b.c1), cf = gld::mmul(a.c2, b.c2);
+        const uint64_t x = gl::sub(gl::sub(gld::mmul(gl::add(a.c1, a.c2), gl::add(b.c1, b.c2)), be), cf);
+        const uint64_t y = gl::sub(gl::sub(gld::mmul(gl::add(a.c0, a.c1), gl::add(b.c0, b.c1)), ad), be);
+        const uint64_t z = gl::add(gl::sub(gl::sub(gld::mmul(gl::add(a.c0, a.c2), gl::add(b.c0, b.c2)), ad), cf), be);
+        return {gl::add(ad, gl::dbl(x)), gl::add(y, gl::dbl(cf)), z};
+    }
+    static __device__ __forceinline__ T one() { return {gl::ONE_MONT, 0, 0}; }
+    static __device__ __forceinline__ T inv(T a) {
+        const uint64_t s0 = gl::sub(gld::mmul(a.c0, a.c0), gl::dbl(gld::mmul(a.c1, a.c2)));
+        const uint64_t s1 = gl::sub(gl::dbl(gld::mmul(a.c2, a.c2)), gld::mmul(a.c0, a.c1));
+        const uint64_t s2 = gl::sub(gld::mmul(a.c1, a.c1), gld::mmul(a.c0, a.c2));
+        const uint64_t n = gl::add(gld::mmul(a.c0, s0), gl::dbl(gl::add(gld::mmul(a.c2, s1), gld::mmul(a.c1, s2))));
+        const uint64_t ni = FpT::inv(n);
+        return {gld::mmul(s0, ni), gld::mmul(s1, ni), gld::mmul(s2, ni)};
+    }
+};
+
+// mixed-field operations: rhs in Fp acts on an Fq3 lhs as in gpu/src/fields.rs:99-188
+template <class L, class R> struct Mix;
+template <> struct Mix<FpT, FpT> {
+    static __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) { return gl::add(a, b); }
+    static __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) { return gld::mmul(a, b); }
+};
+template <> struct Mix<Fq3T, Fq3T> {
+    static __device__ __forceinline__ gl::Fq3 add(gl::Fq3 a, gl::Fq3 b) { return gl::add(a, b); }
+    static __device__ __forceinline__ gl::Fq3 mul(gl::Fq3 a, gl::Fq3 b) { return Fq3T::mul(a, b); }
+};
+template <> struct Mix<Fq3T, FpT> {
+    static __device__ __forceinline__ gl::Fq3 add(gl::Fq3 a, uint64_t b) { return {gl::add(a.c0, b), a.c1, a.c2}; }
+    static __device__ __forceinline__ gl::Fq3 mul(gl::Fq3 a, uint64_t b) { return {gld::mmul(a.c0, b), gld::mmul(a.c1, b), gld::mmul(a.c2, b)}; }
+};
+
+template <class F>
+__device__ __forceinline__ typename F::T powu(typename F::T a, unsigned e) {
+    typename F::T r = F::one();
+    while (e) { if (e & 1) r = F::mul(r, a); e >>= 1; if (e) a = F::mul(a, a); }
+    return r;
+}
+
+// shift already normalised to [0, n)
+template <class L, class R, int OP>
+__global__ void __launch_bounds__(NT) k_binary(uint64_t* dst, const uint64_t* lhs, const uint64_t* rhs, size_t n, size_t shift) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        size_t j = i + shift; if (j >= n) j -= n;
+        const auto a = L::load(lhs, i);
+        const auto b = R::load(rhs, j);
+        L::store(dst, i, OP == 0 ? Mix<L, R>::add(a, b) : Mix<L, R>::mul(a, b));
+    }
+}
+struct Const3 { uint64_t w[3]; };
+template <class L, class R, int OP>
+__global__ void __launch_bounds__(NT) k_binary_const(uint64_t* dst, const uint64_t* lhs, Const3 c, size_t n) {
+    const auto b = R::load(c.w, 0);
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const auto a = L::load(lhs, i);
+        L::store(dst, i, OP == 0 ? Mix<L, R>::add(a, b) : Mix<L, R>::mul(a, b));
+    }
+}
+template <class L, class R>
+__global__ void __launch_bounds__(NT) k_mul_pow(uint64_t* dst, const uint64_t* lhs, const uint64_t* rhs, size_t n, size_t shift, unsigned e) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        size_t j = i + shift; if (j >= n) j -= n;
+        L::store(dst, i, Mix<L, R>::mul(L::load(lhs, i), powu<R>(R::load(rhs, j), e)));
+    }
+}
+// OP: 0 neg, 1 inverse, 2 exp
+template <class F, int OP>
+__global__ void __launch_bounds__(NT) k_unary(uint64_t* dst, const uint64_t* src, size_t n, unsigned e) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const auto a = F::load(src, i);
+        F::store(dst, i, OP == 0 ? F::neg(a) : OP == 1 ? F::inv(a) : powu<F>(a, e));
+    }
+}
+__global__ void __launch_bounds__(NT) k_convert_fp_fq3(uint64_t* dst, const uint64_t* src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const uint64_t x = src[i];
+        dst[3 * i] = x; dst[3 * i + 1] = 0; dst[3 * i + 2] = 0;
+    }
+}
+// word-granular fill: element pattern c.w[0..V)
+__global__ void __launch_bounds__(NT) k_fill(uint64_t* dst, Const3 c, size_t nwords, unsigned V) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nwords; i += (size_t)gridDim.x * NT) dst[i] = c.w[i % V];
+}
+struct SumParams { const uint64_t* cols[MAXCOLS]; uint64_t* dst; size_t nwords; unsigned ncols; };
+__global__ void __launch_bounds__(NT) k_sum_columns(SumParams P) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < P.nwords; i += (size_t)gridDim.x * NT) {
+        uint64_t acc = P.cols[0][i];                         // canonical
+        for (unsigned c = 1; c < P.ncols; c++) acc = gl::add(acc, P.cols[c][i]);
+        P.dst[i] = acc;
+    }
+}
+
+}  // namespace msstage

@@ -86,6 +86,8 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
 
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 // device intrinsics used by the kernels
 static inline unsigned __brev(unsigned x) {
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);

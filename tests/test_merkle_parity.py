@@ -1,0 +1,69 @@
+"""SHA-256 row hashing + Merkle tree (src/merkle.rs:412-508, src/hash.rs:58-100): device vs oracle,
+byte-exact.  Shapes follow benches/merkle_tree.rs:17-45 (3 Goldilocks columns, depth 14-17) plus
+ragged block boundaries (1..9 columns cross the 55/56/64-byte padding edges) and Fq3 rows."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from tests import backends
+from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3, Matrix, MerkleTree
+
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _commit(kind, field, log_rows, ncols, seed=3):
+    pl = backends.planner(kind)
+    V = 3 if field == GOLDILOCKS_FQ3 else 1
+    n = 1 << log_rows
+    cols = [cref.random_elements(n * V, seed + c) for c in range(ncols)]
+    m = Matrix.from_numpy(pl, cols, field)
+    leaves = m.hash_rows().to_numpy().reshape(n, 32)
+    want_leaves = cref.sha256_rows(cols, V)
+    assert np.array_equal(leaves, want_leaves), "row digests differ"
+    if n >= 2:
+        tree = MerkleTree.from_matrix(m)
+        want_nodes = cref.sha256_merkle(want_leaves)
+        assert np.array_equal(tree.nodes_numpy(), want_nodes), "merkle nodes differ"
+        assert tree.root() == want_nodes[1].tobytes()
+
+
+@pytest.mark.parametrize("ncols", [1, 2, 3, 6, 7, 8, 9, 15, 16, 17, 32])
+def test_rows_block_edges_emu(ncols):
+    _commit("emu", GOLDILOCKS_FP, 5, ncols)
+
+
+def test_fq3_rows_emu():
+    _commit("emu", GOLDILOCKS_FQ3, 6, 3)
+    _commit("emu", GOLDILOCKS_FQ3, 4, 9)
+
+
+def test_single_row_and_known_digest_emu():
+    # one element == 1 (Montgomery 2^32-1): the leaf is SHA-256 of 01 00 00 00 00 00 00 00
+    pl = backends.planner("emu")
+    m = Matrix.from_numpy(pl, [np.array([4294967295], dtype=np.uint64)])
+    leaf = m.hash_rows().to_numpy().tobytes()
+    assert leaf == hashlib.sha256((1).to_bytes(8, "little")).digest()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [14, 15, 16, 17])
+def test_merkle_tree_bench_shapes_hip(depth):            # benches/merkle_tree.rs:17-45
+    _commit("hip", GOLDILOCKS_FP, depth, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncols", [1, 7, 8, 9, 17, 26, 32, 100])
+def test_rows_block_edges_hip(ncols):
+    _commit("hip", GOLDILOCKS_FP, 10, ncols)
+
+
+@pytest.mark.gpu
+def test_fq3_rows_hip():
+    _commit("hip", GOLDILOCKS_FQ3, 12, 9)
+
+
+@pytest.mark.gpu
+def test_commit_2_20_x_32_hip():
+    _commit("hip", GOLDILOCKS_FP, 20, 32)
