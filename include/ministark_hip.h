@@ -134,6 +134,44 @@ int ms_sum_columns(ms_ctx* ctx, int field, size_t n, const void* const* d_cols, 
 int ms_sha256_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_leaves);
 int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leaves, void* d_nodes);
 
+/* ---- fused constraint evaluation: eval_gpu::eval / eval_cpu::eval
+ * (src/eval_gpu.rs:46-131, src/eval_cpu.rs:33-150; called from AirConfig::eval_constraint,
+ * src/air.rs:86-128).  The `Expr<AlgebraicItem<..>>` DAG (src/expression.rs:33-40,
+ * src/constraints.rs:21-28) is lowered by the host to a typed register program:
+ *
+ *   constraint program = ninstr x { u32 op, dst, a, b }, executed in order at every point i < 2^log_n.
+ *   Two register files per point: P (Fp, 8 B) and Q (Fq3, 24 B); register numbers < 256 / < 128.
+ *     0 X_P        P[dst] = x_i = offset * w^i                  (AlgebraicItem::X)
+ *     1 CONST_P    P[dst] = consts[a]          2 CONST_Q    Q[dst] = consts[a..a+3)
+ *                  (Constant / Challenge / Hint; `a` indexes u64 words of h_consts)
+ *     3 TRACE_P    P[dst] = base_col[a][(i + lde_step * (int32)b) mod n]        (Trace(col, offset))
+ *     4 TRACE_Q    Q[dst] = ext_col [a][(i + lde_step * (int32)b) mod n]
+ *     5 PERIODIC_P P[dst] = periodic[a][i mod periodic_len[a]]     6 PERIODIC_Q likewise
+ *     7 NEG_P  8 NEG_Q      dst = -a
+ *     9 ADD_PP 10 ADD_QQ 11 ADD_QP (Q[a] + P[b] -> Q)     12 MUL_PP 13 MUL_QQ 14 MUL_QP
+ *     15 INV_P 16 INV_Q     dst = a^-1, 0^-1 = 0 (Div(x, y) = MUL(x, INV(y)), eval_cpu.rs:440-442)
+ *     17 POW_P 18 POW_Q     dst = a^b  (b: u32 exponent)
+ *     19 EMBED              Q[dst] = (P[a], 0, 0)
+ *     20 STORE_Q            out[i] = Q[a]  (out_field = MS_GOLDILOCKS_FQ3)
+ *     21 STORE_P            out[i] = P[a]  (out_field = MS_GOLDILOCKS_FP, i.e. Fq = Fp AIRs)
+ *   The program is validated on the host (MS_ERR_INVALID on any out-of-range operand).
+ * d_x_lde may be NULL (x generated on the fly from h_domain_offset); d_out has 2^log_n elements
+ * of out_field.  Asynchronous. */
+int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                    unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                    const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                    const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                    int out_field, void* d_out);
+
+/* ---- FRI fold: apply_drp (src/fri.rs:526-567) as called by FriProver::build_layer
+ * (src/fri.rs:199-231).  d_evals holds 2^log_n elements in bit-reversed order (the layer that
+ * was just committed); d_out receives 2^log_n / folding_factor elements, bit-reversed, the next
+ * layer's evaluations.  folding_factor in {2,4,8,16} (src/fri.rs:186-192); h_alpha = the drawn
+ * challenge (one element of `field`); h_offset = domain_offset (Fp, NULL = 1 as build_layer
+ * passes).  Bit-identical to bit_reverse + ifft + fold + fft + bit_reverse.  Asynchronous. */
+int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
+                const void* h_offset, const void* d_evals, void* d_out);
+
 #ifdef __cplusplus
 }
 #endif

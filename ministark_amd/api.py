@@ -385,3 +385,18 @@ class Matrix:
                          _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
         self.planner.sync()
         return Matrix(outs)
+
+
+def apply_drp(evals, alpha, folding_factor, domain_offset=1):
+    """`apply_drp(evals, domain_offset, alpha, folding_factor)` (src/fri.rs:526-567): `evals`
+    is a GpuVec in bit-reversed order; returns the next layer's evaluations (bit-reversed).
+    `alpha`: numpy u64 limbs (Montgomery) of one element of the column's field."""
+    pl = evals.planner
+    n = len(evals)
+    out = GpuVec(pl, n // folding_factor, evals.field)
+    al = np.ascontiguousarray(alpha, dtype=np.uint64).ravel()
+    assert al.size == FIELD_WORDS[evals.field]
+    off = ctypes.c_uint64(gl_to_mont(domain_offset))
+    pl.lib.check(pl.lib.ms_fri_fold(pl.handle, evals.field, n.bit_length() - 1, folding_factor, al.ctypes.data,
+                                    ctypes.byref(off), evals.ptr, out.ptr))
+    return out

@@ -168,10 +168,11 @@ MS_HD void bfly(uint64_t& u, uint64_t& v) {
 
 // In-register DFT of N <= 16 values, natural order in and out.  Inputs CANONICAL, outputs WEAK.
 //   X[c] = sum_a x[a] w_N^(a c),   w_N = w_16^(16/N)   (INV: the inverse root)
-template <int N, bool INV>
+// PREBITREV: x[] already holds the inputs in bit-reversed index order (skip the renaming).
+template <int N, bool INV, bool PREBITREV = false>
 MS_HD void dft_lazy(uint64_t* x) {
     if constexpr (N == 1) return;
-    bitrev_regs<N>(x);
+    if constexpr (!PREBITREV) bitrev_regs<N>(x);
     // stage 1: all twiddles 1, inputs canonical
     #pragma unroll
     for (int blk = 0; blk < N; blk += 2) bfly<INV, 0, true>(x[blk], x[blk + 1]);

@@ -17,6 +17,8 @@
 #include "ntt_kernels.h"
 #include "sha256_kernels.h"
 #include "stage_kernels.h"
+#include "fri_kernels.h"
+#include "eval_kernels.h"
 
 using msntt::MAXC;
 
@@ -74,6 +76,8 @@ struct ms_ctx {
     size_t scratch_bytes = 0;
     size_t group_bytes = (size_t)32 << 20;   // columns are processed in groups of about this size
     std::mutex mu;
+    void* prog_buf = nullptr;                // device copy of the current constraint program + constants
+    size_t prog_bytes = 0;
     // optional per-launch timing (ms_profile_*): hipEvent pairs around every kernel launch
     bool profiling = false;
     struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes; };
@@ -131,6 +135,7 @@ extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->plan_cache) ms_ntt_plan_destroy(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MS_OK;
@@ -735,6 +740,147 @@ extern "C" int ms_sum_columns(ms_ctx* ctx, int field, size_t n, const void* cons
     P.dst = (uint64_t*)d_dst; P.nwords = n * V; P.ncols = ncols;
     ProfScope ps(ctx, "sum_columns", 8.0 * n * V * (ncols + 1));
     hipLaunchKernelGGL(msstage::k_sum_columns, dim3(stream_grid(n * V)), dim3(msstage::NT), 0, ctx->stream, P);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// FRI fold
+// ---------------------------------------------------------------------------------------
+template <int V>
+static void launch_fold(unsigned ff, dim3 g, hipStream_t st, const msfri::FoldParams& P) {
+    switch (ff) {
+    case 2: hipLaunchKernelGGL((msfri::fri_fold<2, V>), g, dim3(msfri::NT), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((msfri::fri_fold<4, V>), g, dim3(msfri::NT), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((msfri::fri_fold<8, V>), g, dim3(msfri::NT), 0, st, P); break;
+    default: hipLaunchKernelGGL((msfri::fri_fold<16, V>), g, dim3(msfri::NT), 0, st, P); break;
+    }
+}
+extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
+                           const void* h_offset, const void* d_evals, void* d_out) {
+    if (!ctx || !h_alpha || !d_evals || !d_out) return fail(MS_ERR_INVALID, "ms_fri_fold: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (folding_factor != 2 && folding_factor != 4 && folding_factor != 8 && folding_factor != 16)
+        return fail(MS_ERR_UNSUPPORTED, "folding factor %u not supported (2, 4, 8, 16)", folding_factor);   // src/fri.rs:186-192
+    unsigned log_ff = 0;
+    while ((1u << log_ff) < folding_factor) log_ff++;
+    if (log_n < log_ff || log_n > 32) return fail(MS_ERR_INVALID, "bad layer size 2^%u for folding factor %u", log_n, folding_factor);
+    uint64_t h = 1;
+    if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
+    if (h == 0) return fail(MS_ERR_INVALID, "domain offset must be non-zero");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    // powers of w_n^-1: the tables of the size-n inverse plan (multi-pass layout needs log_n >= 12;
+    // smaller layers get a dedicated two-level table through a plan of size max(n, 4096))
+    ms_ntt_plan* plan = nullptr;
+    const unsigned tl = std::max(log_n, 12u);
+    MSCHK(ctx_plan(ctx, 1, tl, true, 1, &plan));
+    msfri::FoldParams P;
+    memset(&P, 0, sizeof P);
+    P.src = (const uint64_t*)d_evals; P.dst = (uint64_t*)d_out;
+    P.tw_lo = plan->d_tw_lo; P.tw_hi = plan->d_tw_hi; P.lo_bits = plan->lo_bits;
+    P.log_m = log_n - log_ff;
+    P.hinv = gl::to_mont(gl::inv(h));
+    memcpy(P.alpha, h_alpha, V * 8);
+    // table exponent scale: w_n = w_(2^tl)^(2^(tl-log_n)); fold it into the index below
+    P.log_m |= (tl - log_n) << 8;
+    const size_t m = (size_t)1 << (log_n - log_ff);
+    dim3 g((unsigned)((m + msfri::NT - 1) / msfri::NT));
+    ProfScope ps(ctx, "fri_fold", 8.0 * V * (((size_t)1 << log_n) + m));
+    if (V == 1) launch_fold<1>(folding_factor, g, ctx->stream, P); else launch_fold<3>(folding_factor, g, ctx->stream, P);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused constraint evaluation
+// ---------------------------------------------------------------------------------------
+extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                               unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                               const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                               const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                               int out_field, void* d_out) {
+    using namespace mseval;
+    if (!ctx || !h_prog || !d_out || (nconst_words && !h_consts)) return fail(MS_ERR_INVALID, "ms_eval_program: null argument");
+    if (nbase > (unsigned)MAXCOLS || next > (unsigned)MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d base and %d extension columns", MAXCOLS, MAXCOLS);
+    if (nperiodic > (unsigned)MAXPERIODIC) return fail(MS_ERR_UNSUPPORTED, "at most %d periodic columns", MAXPERIODIC);
+    if ((nbase && !d_base_cols) || (next && !d_ext_cols) || (nperiodic && (!d_periodic || !periodic_len))) return fail(MS_ERR_INVALID, "ms_eval_program: null column table");
+    if (log_n > 32) return fail(MS_ERR_INVALID, "log_n too large");
+    if (lde_step == 0) return fail(MS_ERR_INVALID, "lde_step must be positive");
+    if (out_field != MS_GOLDILOCKS_FP && out_field != MS_GOLDILOCKS_FQ3) return fail(MS_ERR_UNSUPPORTED, "output field must be Fp or Fq3");
+    // ---- validate: every register is written before it is read, all operands are in range
+    unsigned maxp = 0, maxq = 0;
+    std::vector<char> pw(256, 0), qw(128, 0);
+    bool stored = false;
+    const Instr* prog = (const Instr*)h_prog;
+    auto P_ok = [&](uint32_t r) { return r < 256 && pw[r]; };
+    auto Q_ok = [&](uint32_t r) { return r < 128 && qw[r]; };
+    for (unsigned k = 0; k < ninstr; k++) {
+        const Instr I = prog[k];
+        bool ok = true, dp = false, dq = false;
+        switch (I.op) {
+        case OP_X_P: dp = true; break;
+        case OP_CONST_P: ok = I.a < nconst_words; dp = true; break;
+        case OP_CONST_Q: ok = (uint64_t)I.a + 3 <= nconst_words; dq = true; break;
+        case OP_TRACE_P: ok = I.a < nbase; dp = true; break;
+        case OP_TRACE_Q: ok = I.a < next; dq = true; break;
+        case OP_PERIODIC_P: ok = I.a < nperiodic && periodic_len[I.a] > 0; dp = true; break;
+        case OP_PERIODIC_Q: ok = I.a < nperiodic && periodic_len[I.a] > 0; dq = true; break;
+        case OP_NEG_P: case OP_INV_P: case OP_POW_P: ok = P_ok(I.a); dp = true; break;
+        case OP_NEG_Q: case OP_INV_Q: case OP_POW_Q: ok = Q_ok(I.a); dq = true; break;
+        case OP_ADD_PP: case OP_MUL_PP: ok = P_ok(I.a) && P_ok(I.b); dp = true; break;
+        case OP_ADD_QQ: case OP_MUL_QQ: ok = Q_ok(I.a) && Q_ok(I.b); dq = true; break;
+        case OP_ADD_QP: case OP_MUL_QP: ok = Q_ok(I.a) && P_ok(I.b); dq = true; break;
+        case OP_EMBED: ok = P_ok(I.a); dq = true; break;
+        case OP_STORE_Q: ok = Q_ok(I.a) && out_field == MS_GOLDILOCKS_FQ3; stored = true; break;
+        case OP_STORE_P: ok = P_ok(I.a) && out_field == MS_GOLDILOCKS_FP; stored = true; break;
+        default: ok = false;
+        }
+        if (dp) { if (I.dst >= 256) ok = false; else { pw[I.dst] = 1; maxp = std::max(maxp, I.dst + 1); } }
+        if (dq) { if (I.dst >= 128) ok = false; else { qw[I.dst] = 1; maxq = std::max(maxq, I.dst + 1); } }
+        if (!ok) return fail(MS_ERR_INVALID, "constraint program: invalid instruction %u (op %u dst %u a %u b %u)", k, I.op, I.dst, I.a, I.b);
+    }
+    if (!stored) return fail(MS_ERR_INVALID, "constraint program never stores a result");
+    const size_t n = (size_t)1 << log_n;
+    uint64_t h = 1;
+    if (h_domain_offset) { uint64_t h_m; memcpy(&h_m, h_domain_offset, 8); h = gl::from_mont(h_m); }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    // program + constants -> device
+    const size_t pbytes = (size_t)ninstr * sizeof(Instr), cbytes = (size_t)nconst_words * 8, total = pbytes + cbytes + 64;
+    if (ctx->prog_bytes < total) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->prog_buf) HIPCHK(hipFree(ctx->prog_buf));
+        ctx->prog_buf = nullptr; ctx->prog_bytes = 0;
+        if (hipMalloc(&ctx->prog_buf, total) != hipSuccess) return fail(MS_ERR_NOMEM, "program buffer");
+        ctx->prog_bytes = total;
+    } else {
+        HIPCHK(hipStreamSynchronize(ctx->stream));           // a previous evaluation may still read the buffer
+    }
+    const size_t coff = (pbytes + 15) & ~(size_t)15;
+    HIPCHK(hipMemcpy(ctx->prog_buf, h_prog, pbytes, hipMemcpyHostToDevice));
+    if (cbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + coff, h_consts, cbytes, hipMemcpyHostToDevice));
+    EvalParams E;
+    memset(&E, 0, sizeof E);
+    E.prog = (const Instr*)ctx->prog_buf;
+    E.consts = (const uint64_t*)((char*)ctx->prog_buf + coff);
+    for (unsigned c = 0; c < nbase; c++) E.base_cols[c] = (const uint64_t*)d_base_cols[c];
+    for (unsigned c = 0; c < next; c++) E.ext_cols[c] = (const uint64_t*)d_ext_cols[c];
+    for (unsigned c = 0; c < nperiodic; c++) { E.periodic[c] = (const uint64_t*)d_periodic[c]; E.periodic_len[c] = periodic_len[c]; }
+    E.out = (uint64_t*)d_out; E.x_lde = (const uint64_t*)d_x_lde;
+    E.h_mont = gl::to_mont(h); E.n = n; E.ninstr = ninstr; E.lde_step = lde_step; E.log_n = log_n;
+    if (!d_x_lde) {
+        ms_ntt_plan* plan = nullptr;
+        const unsigned tl = std::max(log_n, 12u);
+        MSCHK(ctx_plan(ctx, 1, tl, false, 1, &plan));
+        E.tw_lo = plan->d_tw_lo; E.tw_hi = plan->d_tw_hi; E.lo_bits = plan->lo_bits; E.xshift = tl - log_n;
+    }
+    dim3 g((unsigned)((n + NT - 1) / NT));
+    ProfScope ps(ctx, "eval_program", 8.0 * n * (nbase + 3.0 * next + (out_field == MS_GOLDILOCKS_FQ3 ? 3 : 1)));
+    if (maxp <= 16 && maxq <= 8) hipLaunchKernelGGL((eval_program<16, 8>), g, dim3(NT), 0, ctx->stream, E);
+    else if (maxp <= 64 && maxq <= 32) hipLaunchKernelGGL((eval_program<64, 32>), g, dim3(NT), 0, ctx->stream, E);
+    else hipLaunchKernelGGL((eval_program<256, 128>), g, dim3(NT), 0, ctx->stream, E);
     HIPCHK(hipGetLastError());
     return MS_OK;
 }

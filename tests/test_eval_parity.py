@@ -1,0 +1,130 @@
+"""Fused constraint evaluation vs the oracle, bit-exact.  Cases follow the reference's
+eval_gpu unit tests (src/eval_gpu.rs:917-1082): an X-only expression with pow and div; mixed
+Fp/Fq3 columns with curr/next offsets; 1/X; the Fibonacci AIR (examples/fib/main.rs:73-140);
+plus rotations with lde_step > 1 and wrap-around, periodic columns, challenges and hints."""
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle.pyref import evalexpr
+from oracle.pyref.fields import GL
+from tests import backends
+from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3, GpuVec
+from ministark_amd import expr as E
+
+P = cref.GL_P
+KINDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+sys.setrecursionlimit(10000)
+
+
+def _canon(arr, V=1):
+    a = [GL.from_mont(int(x)) for x in arr]
+    return a if V == 1 else [tuple(a[3 * i:3 * i + 3]) for i in range(len(a) // 3)]
+
+
+def _check(kind, expr, log_n, lde_step, nbase, next_, nch=0, nh=0, fq_is_ext=True, offset=7, npoints=48, seed=1):
+    pl = backends.planner(kind)
+    n = 1 << log_n
+    base = [cref.random_elements(n, seed + c) for c in range(nbase)]
+    ext = [cref.random_elements(3 * n, seed + 50 + c) for c in range(next_)]
+    qw = 3 if fq_is_ext else 1
+    ch = cref.random_elements(max(nch, 1) * qw, seed + 90).reshape(-1, qw)
+    hi = cref.random_elements(max(nh, 1) * qw, seed + 91).reshape(-1, qw)
+    prog = E.compile_expr(expr, nbase, fq_is_ext)
+    out = E.eval(prog, pl, ch, hi, lde_step, offset, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
+                 [GpuVec.from_numpy(pl, c, FQ3) for c in ext]).to_numpy()
+    rng = np.random.default_rng(seed)
+    pts = sorted(set([0, 1, n - 1, n - 2, n // 2] + [int(x) for x in rng.integers(0, n, size=npoints)]))
+    qc = (lambda r: tuple(GL.from_mont(int(x)) for x in r)) if fq_is_ext else (lambda r: GL.from_mont(int(r[0])))
+    want = evalexpr.eval_points(expr, pts, n, lde_step, offset, [_canon(c) for c in base], [_canon(c, 3) for c in ext],
+                                [qc(r) for r in ch], [qc(r) for r in hi], fq_is_ext)
+    V = 3 if fq_is_ext else 1
+    for i, w in zip(pts, want):
+        got = tuple(GL.from_mont(int(x)) for x in out[V * i:V * i + V])
+        assert got == (w if fq_is_ext else (w,)), f"point {i}"
+    return prog
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_x_only_pow_div(kind):                     # src/eval_gpu.rs:917-950
+    x = E.X()
+    expr = (x ** 9 - 1) / (x - E.Constant(3)) + x * x ** 3 + 5
+    _check(kind, expr, 12, 1, 0, 0)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_one_over_x(kind):                         # src/eval_gpu.rs:993-1020
+    _check(kind, E.Constant(1) / E.X(), 12, 1, 0, 0)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("lde_step", [1, 4])
+def test_mixed_fields_curr_next(kind, lde_step):   # src/eval_gpu.rs:953-990 scaled up
+    x = E.X()
+    b0, b1, b2 = (lambda o=0, c=c: E.Trace(c, o) for c in range(3))
+    e0, e1 = (lambda o=0, c=c: E.Trace(3 + c, o) for c in range(2))
+    expr = (b0(1) - b0() * b1() + e0(1) * e1() - e0() * b2(-1)) * (x - 1) / (x ** 8 - 1) \
+        + E.Challenge(0) * e1(2) + E.Hint(1) * b1(1) + e0() ** 3 + (b2() + E.Challenge(1)) / (e1() - E.Hint(0))
+    prog = _check(kind, expr, 12, lde_step, 3, 2, nch=2, nh=2)
+    assert prog.max_p <= 16 and prog.max_q <= 8
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fibonacci_air(kind):                      # examples/fib/main.rs:73-140 shape: Fq = Fp, 8 columns
+    x = E.X()
+    c = [lambda o=0, k=k: E.Trace(k, o) for k in range(8)]
+    cons = [c[0](1) - (c[6]() + c[7]()), c[1](1) - (c[7]() + c[0](1))]
+    cons += [c[k]() - (c[k - 2]() + c[k - 1]()) for k in range(2, 8)]
+    n_trace = 1 << 10
+    g_inv = pow(GL.root_of_unity(n_trace), -1, P)
+    zer = (x - E.Constant(g_inv)) / (x ** n_trace - 1)
+    comp = None
+    for k, cn in enumerate(cons):
+        term = cn * zer * (E.Challenge(2 * k) * x ** 3 + E.Challenge(2 * k + 1))
+        comp = term if comp is None else comp + term
+    comp = comp + (c[0]() - 1) / (x - 1) * E.Challenge(16)
+    _check(kind, comp, 12, 4, 8, 0, nch=17, fq_is_ext=False)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_periodic_column_and_const_fq(kind):
+    x = E.X()
+    per = E.Periodic([3, 1, 4, 1, 5, 9, 2, 6], 8)
+    expr = per * E.Trace(0) + E.Constant((5, 6, 7)) * x - per ** 2 + E.Trace(1, 3)
+    _check(kind, expr, 12, 2, 1, 1)
+
+
+def test_many_registers_emu():
+    # a wide sum of products keeps many values alive -> larger register files
+    terms = [E.Trace(k) * E.Trace(k + 1, 1) for k in range(0, 40, 2)]
+    prods = [E.Trace(k) for k in range(40)]
+    expr = terms[0]
+    for t in terms[1:]:
+        expr = expr + t
+    keep = [p * p for p in prods]            # 40 squares kept alive until the end
+    tail = keep[0]
+    for kq in keep[1:]:
+        tail = tail * kq + expr
+    _check("emu", tail, 8, 1, 40, 0, npoints=6)
+
+
+def test_invalid_programs_rejected_emu():
+    import ctypes
+    pl = backends.planner("emu")
+    L = pl.lib
+    out = GpuVec(pl, 16, FP)
+    bad = np.array([[E.OP_ADD_PP, 0, 1, 2], [E.OP_STORE_P, 0, 0, 0]], dtype=np.uint32)   # reads unwritten registers
+    rc = L.ms_eval_program(pl.handle, bad.ctypes.data, 2, None, 0, 4, 1, None, out.ptr, None, 0, None, 0, None, None, 0, FP, out.ptr)
+    assert rc == -1 and b"invalid instruction" in L.ms_last_error()
+    bad = np.array([[E.OP_TRACE_P, 0, 3, 0], [E.OP_STORE_P, 0, 0, 0]], dtype=np.uint32)    # column out of range
+    rc = L.ms_eval_program(pl.handle, bad.ctypes.data, 2, None, 0, 4, 1, None, out.ptr, None, 0, None, 0, None, None, 0, FP, out.ptr)
+    assert rc == -1
+
+
+@pytest.mark.gpu
+def test_eval_2_20_vs_sampled_oracle_hip():
+    x = E.X()
+    expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) / (x ** 1024 - 1) + E.Trace(2) * E.Challenge(0) + E.Trace(3, -1) ** 5
+    _check("hip", expr, 20, 8, 2, 2, nch=1, npoints=24)
