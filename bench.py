@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--cols", type=int, default=8, help="columns of 2^24 per rank per step")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-json", default=None, help="JSON file with PMC-derived HBM bytes per transform")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
