@@ -1,0 +1,35 @@
+"""Worker for the world_size-2 tests: python tests/dist_worker.py <rank> <world> <port> <backend_kind> <outfile>"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world, port, kind, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo" if kind == "emu" else "nccl", rank=rank, world_size=world)
+    from oracle import cref
+    from tests import backends
+    from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3
+    from ministark_amd.distributed import lde_commit_sharded, owned_columns
+    pl = backends.planner(kind)
+    results = []
+    for field, V, total_cols, log_n, log_b in ((GOLDILOCKS_FP, 1, 5, 6, 2), (GOLDILOCKS_FQ3, 3, 3, 5, 3), (GOLDILOCKS_FP, 1, 1, 7, 1)):
+        allc = [cref.random_elements((1 << log_n) * V, 1000 + c) for c in range(total_cols)]
+        mine = [allc[c] for c in owned_columns(total_cols, rank, world)]
+        dev = torch.device("cpu") if kind == "emu" else torch.device("cuda", rank)
+        root, shard = lde_commit_sharded(pl, mine, total_cols, log_n, log_b, 7, field, device=dev)
+        results.append(root.hex())
+    with open(outfile, "w") as f:
+        f.write("\n".join(results))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
