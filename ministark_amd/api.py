@@ -31,6 +31,23 @@ def gl_from_mont(x):
     return (int(x) * pow(_GL_R, -1, GL_P)) % GL_P
 
 
+# the 252-bit StarkWare prime (gpu/src/fields.rs:239-264): generator 3, two-adicity 192, R = 2^256
+F252_P = (1 << 251) + 17 * (1 << 192) + 1
+_F252_R = (1 << 256) % F252_P
+F252_GENERATOR = 3
+
+
+def f252_to_mont_limbs(x):
+    """canonical int -> 4 little-endian u64 limbs of the Montgomery residue."""
+    m = (int(x) * _F252_R) % F252_P
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def f252_from_mont_limbs(limbs):
+    m = sum(int(v) << (64 * i) for i, v in enumerate(limbs))
+    return (m * pow(_F252_R, -1, F252_P)) % F252_P
+
+
 class Planner:
     """`Planner` / `get_planner()` (gpu/src/plan.rs:327-351, 464-469): owns the device,
     the kernel library and the command queue (here: a HIP stream)."""
@@ -190,34 +207,45 @@ class Radix2EvaluationDomain:
     (gpu/src/plan.rs:386-423): `new(n)` / `new_coset(n, offset)`; constants are canonical
     integers, `*_mont` the Montgomery words that cross the C ABI."""
 
-    def __init__(self, size, offset=1):
+    def __init__(self, size, offset=1, fft_field=GOLDILOCKS_FP):
         if size < 1 or size & (size - 1):
             raise ValueError("domain size must be a power of two")
         self.size = size
         self.log_size = size.bit_length() - 1
-        if self.log_size > 32:
+        self.fft_field = fft_field
+        if fft_field == STARK252_FP:
+            p, two_adicity, root = F252_P, 192, pow(F252_GENERATOR, (F252_P - 1) >> 192, F252_P)
+        else:
+            p, two_adicity, root = GL_P, 32, _GL_TWO_ADIC_ROOT
+        self.p = p
+        if self.log_size > two_adicity:
             raise ValueError("domain exceeds the two-adicity of the field")
-        self.group_gen = pow(_GL_TWO_ADIC_ROOT, 1 << (32 - self.log_size), GL_P)
-        self.group_gen_inv = pow(self.group_gen, -1, GL_P)
-        self.size_inv = pow(size % GL_P, -1, GL_P)
-        self.offset = offset % GL_P
-        self.offset_inv = pow(self.offset, -1, GL_P)
+        self.group_gen = pow(root, 1 << (two_adicity - self.log_size), p)
+        self.group_gen_inv = pow(self.group_gen, -1, p)
+        self.size_inv = pow(size % p, -1, p)
+        self.offset = offset % p
+        self.offset_inv = pow(self.offset, -1, p)
 
     @classmethod
-    def new(cls, size):
-        return cls(size)
+    def new(cls, size, fft_field=GOLDILOCKS_FP):
+        return cls(size, 1, fft_field)
 
     @classmethod
-    def new_coset(cls, size, offset):
-        return cls(size, offset)
+    def new_coset(cls, size, offset, fft_field=GOLDILOCKS_FP):
+        return cls(size, offset, fft_field)
+
+    def _limbs(self, x):
+        if self.fft_field == STARK252_FP:
+            return f252_to_mont_limbs(x)
+        return np.array([gl_to_mont(x)], dtype=np.uint64)
 
     @property
     def offset_mont(self):
-        return gl_to_mont(self.offset)
+        return gl_to_mont(self.offset) if self.fft_field != STARK252_FP else f252_to_mont_limbs(self.offset)
 
     @property
     def group_gen_mont(self):
-        return gl_to_mont(self.group_gen)
+        return gl_to_mont(self.group_gen) if self.fft_field != STARK252_FP else f252_to_mont_limbs(self.group_gen)
 
 
 def _ptr_array(vecs):
@@ -232,12 +260,14 @@ class _FftBase:
         self.planner = planner or get_planner()
         self.domain = domain
         self.field = field
-        off = ctypes.c_uint64(domain.offset_mont)
-        gen = ctypes.c_uint64(domain.group_gen_mont)
+        if (field == STARK252_FP) != (domain.fft_field == STARK252_FP):
+            raise ValueError("domain and column fields do not match")
+        off = domain._limbs(domain.offset)
+        gen = domain._limbs(domain.group_gen)
         h = ctypes.c_void_p()
         L = self.planner.lib
         L.check(L.ms_ntt_plan_create(self.planner.handle, field, domain.log_size, self._inverse,
-                                     ctypes.byref(off), ctypes.byref(gen), ctypes.byref(h)))
+                                     off.ctypes.data, gen.ctypes.data, ctypes.byref(h)))
         self.handle = h
         self._keep = []
 

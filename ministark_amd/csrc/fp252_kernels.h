@@ -1,0 +1,85 @@
+// NTT / iNTT over the 252-bit StarkWare field for gfx950 (a3 + the fp252 instantiations of
+// gpu/src/metal/fft_shaders.h.metal:108-119 and gpu/tests/shaders.rs:69-91).
+// The field is compute-bound (one Montgomery product = 20 64x64 multiplies), so the structure
+// is deliberately plain: bit-reverse, then radix-2 DIT stages -- the first nine inside LDS on
+// 512-element chunks, the rest one launch per stage in global memory -- with the coset /
+// normalisation scale fused into the first / last kernel.  Twiddles come from a two-level table.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fp252.h"
+
+namespace ms252 {
+
+static constexpr int NT = 256;
+static constexpr int CHUNK_LOG = 9;                    // 512 elements * 32 B = 16 KiB of LDS
+
+struct Params {
+    uint64_t* col;
+    const uint64_t* tw_lo;     // w^i, i < 2^lo_bits        (Montgomery, 4 limbs each)
+    const uint64_t* tw_hi;     // w^(i << lo_bits)
+    const uint64_t* sc_lo;     // scale powers c*g^i (forward coset: g = h; inverse: c = 1/n, g = 1/h)
+    const uint64_t* sc_hi;
+    unsigned log_n, lo_bits, stage;
+    int scale_in, scale_out;
+};
+__device__ __forceinline__ f252::E ld(const uint64_t* p, size_t i) { return {{p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]}}; }
+__device__ __forceinline__ void st(uint64_t* p, size_t i, const f252::E& x) { p[4 * i] = x.l[0]; p[4 * i + 1] = x.l[1]; p[4 * i + 2] = x.l[2]; p[4 * i + 3] = x.l[3]; }
+__device__ __forceinline__ f252::E pow2l(const uint64_t* lo, const uint64_t* hi, unsigned lo_bits, size_t e) {
+    f252::E r = ld(lo, e & ((1u << lo_bits) - 1));
+    if (e >> lo_bits) r = f252::mul(r, ld(hi, e >> lo_bits));
+    return r;
+}
+
+// stages 1..min(CHUNK_LOG, log_n) of a DIT transform whose input is already bit-reversed
+__global__ void __launch_bounds__(NT) ntt252_local(Params P) {
+    __shared__ uint64_t lds[4 << CHUNK_LOG];
+    const unsigned clog = P.log_n < (unsigned)CHUNK_LOG ? P.log_n : (unsigned)CHUNK_LOG;
+    const size_t chunk = (size_t)1 << clog, base = (size_t)blockIdx.x * chunk;
+    for (unsigned q = threadIdx.x; q < chunk; q += NT) {
+        f252::E x = ld(P.col, base + q);
+        if (P.scale_in) {
+            // element at bit-reversed position base+q is coefficient index rev(base+q)
+            const size_t j = P.log_n ? (size_t)(__brevll((unsigned long long)(base + q)) >> (64 - P.log_n)) : 0;
+            x = f252::mul(x, pow2l(P.sc_lo, P.sc_hi, P.lo_bits, j));
+        }
+        st(lds, q, x);
+    }
+    __syncthreads();
+    for (unsigned s = 1; s <= clog; s++) {
+        const unsigned half = 1u << (s - 1);
+        for (unsigned q = threadIdx.x; q < chunk / 2; q += NT) {
+            const unsigned i = q & (half - 1), lo = ((q >> (s - 1)) << s) + i, hi = lo + half;
+            const f252::E u = ld(lds, lo);
+            const f252::E t = f252::mul(ld(lds, hi), pow2l(P.tw_lo, P.tw_hi, P.lo_bits, (size_t)i << (P.log_n - s)));
+            st(lds, lo, f252::add(u, t));
+            st(lds, hi, f252::sub(u, t));
+        }
+        __syncthreads();
+    }
+    const bool last = P.log_n <= (unsigned)CHUNK_LOG;
+    for (unsigned q = threadIdx.x; q < chunk; q += NT) {
+        f252::E x = ld(lds, q);
+        if (last && P.scale_out) x = f252::mul(x, pow2l(P.sc_lo, P.sc_hi, P.lo_bits, base + q));
+        st(P.col, base + q, x);
+    }
+}
+// one global radix-2 DIT stage s (> CHUNK_LOG); the last stage applies the output scale
+__global__ void __launch_bounds__(NT) ntt252_stage(Params P) {
+    const size_t q = (size_t)blockIdx.x * NT + threadIdx.x;
+    const size_t n = (size_t)1 << P.log_n;
+    if (q >= n / 2) return;
+    const unsigned s = P.stage;
+    const size_t half = (size_t)1 << (s - 1);
+    const size_t i = q & (half - 1), lo = ((q >> (s - 1)) << s) + i, hi = lo + half;
+    const f252::E u = ld(P.col, lo);
+    const f252::E t = f252::mul(ld(P.col, hi), pow2l(P.tw_lo, P.tw_hi, P.lo_bits, i << (P.log_n - s)));
+    f252::E a = f252::add(u, t), b = f252::sub(u, t);
+    if (s == P.log_n && P.scale_out) {
+        a = f252::mul(a, pow2l(P.sc_lo, P.sc_hi, P.lo_bits, lo));
+        b = f252::mul(b, pow2l(P.sc_lo, P.sc_hi, P.lo_bits, hi));
+    }
+    st(P.col, lo, a);
+    st(P.col, hi, b);
+}
+
+}  // namespace ms252

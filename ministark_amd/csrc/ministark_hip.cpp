@@ -19,6 +19,7 @@
 #include "stage_kernels.h"
 #include "fri_kernels.h"
 #include "eval_kernels.h"
+#include "fp252_kernels.h"
 
 using msntt::MAXC;
 
@@ -59,7 +60,7 @@ extern "C" size_t ms_field_bytes(int field) {
 static int field_words(int field, unsigned* V) {
     if (field == MS_GOLDILOCKS_FP) { *V = 1; return MS_OK; }
     if (field == MS_GOLDILOCKS_FQ3) { *V = 3; return MS_OK; }
-    if (field == MS_STARK252_FP) return fail(MS_ERR_UNSUPPORTED, "Fp252 is not implemented yet on this path");
+    if (field == MS_STARK252_FP) { *V = 4; return MS_OK; }
     return fail(MS_ERR_INVALID, "unknown field id %d", field);
 }
 
@@ -225,6 +226,10 @@ struct ms_ntt_plan {
     int scale_mode = 0;                 // last pass: 0 none, 1 const, 2 table
     uint64_t* d_tables = nullptr;       // one allocation backing every table
     std::vector<void*> queue;
+    // Fp252 path (V == 4): plain radix-2 plan, see fp252_kernels.h
+    bool is252 = false;
+    uint64_t *d252_tw_lo = nullptr, *d252_tw_hi = nullptr, *d252_sc_lo = nullptr, *d252_sc_hi = nullptr;
+    int scale_in252 = 0, scale_out252 = 0;
 };
 
 static void powers(std::vector<uint64_t>& out, size_t count, uint64_t base, uint64_t first = 1) {
@@ -234,12 +239,14 @@ static void powers(std::vector<uint64_t>& out, size_t count, uint64_t base, uint
 }
 
 static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uint64_t h, ms_ntt_plan** out);
+static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* h_offset, const void* h_group_gen, ms_ntt_plan** out);
 
 extern "C" int ms_ntt_plan_create(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset,
                                   const void* h_group_gen, ms_ntt_plan** out) {
     if (!ctx || !out) return fail(MS_ERR_INVALID, "ms_ntt_plan_create: null argument");
     unsigned V = 0;
     MSCHK(field_words(field, &V));
+    if (V == 4) return plan_build252(ctx, log_n, inverse != 0, h_offset, h_group_gen, out);
     if (log_n > 32) return fail(MS_ERR_INVALID, "log_n = %u exceeds the field's two-adicity (32)", log_n);
     if (h_group_gen) {
         uint64_t g_m;
@@ -251,6 +258,50 @@ extern "C" int ms_ntt_plan_create(ms_ctx* ctx, int field, unsigned log_n, int in
     if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
     if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
     return plan_build(ctx, V, log_n, inverse != 0, h, out);
+}
+
+// ---- Fp252 plans ------------------------------------------------------------------------
+static void powers252(std::vector<uint64_t>& out, size_t count, f252::E base, f252::E first) {
+    out.resize(count * 4);
+    f252::E x = first;
+    for (size_t i = 0; i < count; i++) { memcpy(&out[4 * i], x.l, 32); x = f252::mul(x, base); }
+}
+static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* h_offset, const void* h_group_gen, ms_ntt_plan** out) {
+    if (log_n > 40) return fail(MS_ERR_INVALID, "log_n = %u too large", log_n);
+    HIPCHK(hipSetDevice(ctx->device));
+    const f252::E gen = f252::root_of_unity(log_n);
+    if (h_group_gen) {
+        f252::E g; memcpy(g.l, h_group_gen, 32);
+        if (!f252::eq(g, gen)) return fail(MS_ERR_UNSUPPORTED, "group_gen is not arkworks' get_root_of_unity(2^%u)", log_n);
+    }
+    f252::E h = f252::one();
+    if (h_offset) memcpy(h.l, h_offset, 32);
+    if (f252::is_zero(h) || f252::geq_p(h)) return fail(MS_ERR_INVALID, "coset offset must be a non-zero canonical element");
+    const bool coset = !f252::eq(h, f252::one());
+    ms_ntt_plan* p = new ms_ntt_plan();
+    p->ctx = ctx; p->V = 4; p->log_n = log_n; p->inverse = inverse; p->coset = coset; p->is252 = true;
+    const size_t n = (size_t)1 << log_n;
+    const f252::E w = inverse ? f252::inv(gen) : gen;
+    p->lo_bits = std::min(10u, log_n);
+    std::vector<uint64_t> host, t;
+    auto append = [&](const std::vector<uint64_t>& v) { size_t off = host.size(); host.insert(host.end(), v.begin(), v.end()); return off; };
+    powers252(t, (size_t)1 << p->lo_bits, w, f252::one()); const size_t o_lo = append(t);
+    powers252(t, std::max<size_t>(n >> p->lo_bits, 1), f252::pow_u64(w, (uint64_t)1 << p->lo_bits), f252::one()); const size_t o_hi = append(t);
+    size_t o_slo = 0, o_shi = 0;
+    const bool scale = inverse || coset;
+    if (scale) {
+        f252::E g = inverse ? f252::inv(h) : h, c = f252::one();
+        if (inverse) { f252::E nn = f252::to_mont(f252::E{{(uint64_t)n, 0, 0, 0}}); c = f252::inv(nn); }
+        powers252(t, (size_t)1 << p->lo_bits, g, c); o_slo = append(t);
+        powers252(t, std::max<size_t>(n >> p->lo_bits, 1), f252::pow_u64(g, (uint64_t)1 << p->lo_bits), f252::one()); o_shi = append(t);
+        if (inverse) p->scale_out252 = 1; else p->scale_in252 = 1;
+    }
+    if (hipMalloc(&p->d_tables, host.size() * 8) != hipSuccess) { delete p; return fail(MS_ERR_NOMEM, "Fp252 plan tables"); }
+    if (hipMemcpy(p->d_tables, host.data(), host.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->d_tables); delete p; return fail(MS_ERR_HIP, "Fp252 table upload"); }
+    p->d252_tw_lo = p->d_tables + o_lo; p->d252_tw_hi = p->d_tables + o_hi;
+    if (scale) { p->d252_sc_lo = p->d_tables + o_slo; p->d252_sc_hi = p->d_tables + o_shi; }
+    *out = p;
+    return MS_OK;
 }
 
 // plan owned by the context, reused by the fused entry points (ms_lde, ms_fri_fold)
@@ -383,9 +434,43 @@ static void launch_mid(bool inv, bool last, int scale, dim3 grid, hipStream_t st
     else     { if (last) launch_mid_scale<RB, false, true>(scale, grid, st, P); else launch_mid_scale<RB, false, false>(scale, grid, st, P); }
 }
 
+static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* const* src, void* const* dst, unsigned ncols);
+
+static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols) {
+    ms_ctx* ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << p->log_n;
+    for (unsigned c = 0; c < ncols; c++)
+        if (src[c] != dst[c]) HIPCHK(hipMemcpyAsync(dst[c], src[c], n * 32, hipMemcpyDeviceToDevice, st));
+    MSCHK(bit_reverse_run(ctx, 4, p->log_n, (const void* const*)dst, dst, ncols));
+    for (unsigned c = 0; c < ncols; c++) {
+        ms252::Params P;
+        memset(&P, 0, sizeof P);
+        P.col = (uint64_t*)dst[c]; P.tw_lo = p->d252_tw_lo; P.tw_hi = p->d252_tw_hi; P.sc_lo = p->d252_sc_lo; P.sc_hi = p->d252_sc_hi;
+        P.log_n = p->log_n; P.lo_bits = p->lo_bits; P.scale_in = p->scale_in252; P.scale_out = p->scale_out252;
+        const unsigned clog = std::min<unsigned>(p->log_n, ms252::CHUNK_LOG);
+        {
+            ProfScope ps(ctx, "ntt252_local", 64.0 * n);
+            hipLaunchKernelGGL(ms252::ntt252_local, dim3((unsigned)(n >> clog)), dim3(ms252::NT), 0, st, P);
+        }
+        for (unsigned s = clog + 1; s <= p->log_n; s++) {
+            P.stage = s;
+            ProfScope ps(ctx, "ntt252_stage", 64.0 * n);
+            hipLaunchKernelGGL(ms252::ntt252_stage, dim3((unsigned)((n / 2 + ms252::NT - 1) / ms252::NT)), dim3(ms252::NT), 0, st, P);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
 // Transform `ncols` columns: src[c] -> dst[c] (may alias).  valid_rows < 256 means the
 // source only holds the first valid_rows/256 of the domain, the rest is implicit zeros.
 static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows) {
+    if (p->is252) {
+        if (valid_rows != 256) return fail(MS_ERR_UNSUPPORTED, "zero-extended input is not implemented for Fp252");
+        return plan_run252(p, src, dst, ncols);
+    }
     ms_ctx* ctx = p->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -479,7 +564,7 @@ static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* 
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << log_n;
-    if (log_n >= 10) {
+    if (log_n >= 10 && V != 4) {
         for (unsigned c0 = 0; c0 < ncols; c0 += MAXC) {
             unsigned nc = std::min<unsigned>(MAXC, ncols - c0);
             msntt::BitrevParams B;
@@ -495,16 +580,18 @@ static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* 
         // tiny: out of place through scratch when aliased
         const size_t col_bytes = n * V * 8;
         void* scratch = nullptr;
-        MSCHK(ctx_scratch(ctx, (size_t)MAXC * col_bytes, &scratch));
-        for (unsigned c0 = 0; c0 < ncols; c0 += MAXC) {
-            unsigned nc = std::min<unsigned>(MAXC, ncols - c0);
+        const unsigned grp = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ((size_t)256 << 20) / col_bytes));
+        MSCHK(ctx_scratch(ctx, (size_t)grp * col_bytes, &scratch));
+        for (unsigned c0 = 0; c0 < ncols; c0 += grp) {
+            unsigned nc = std::min<unsigned>(grp, ncols - c0);
             msntt::BitrevParams B;
             memset(&B, 0, sizeof B);
             for (unsigned c = 0; c < nc; c++) { B.src[c] = (const uint64_t*)src[c0 + c]; B.dst[c] = (uint64_t*)((char*)scratch + c * col_bytes); }
             B.log_n = log_n;
             dim3 grid((unsigned)((n + msntt::NT - 1) / msntt::NT), nc);
             if (V == 1) hipLaunchKernelGGL(msntt::bit_reverse_simple<1>, grid, dim3(msntt::NT), 0, st, B);
-            else hipLaunchKernelGGL(msntt::bit_reverse_simple<3>, grid, dim3(msntt::NT), 0, st, B);
+            else if (V == 3) hipLaunchKernelGGL(msntt::bit_reverse_simple<3>, grid, dim3(msntt::NT), 0, st, B);
+            else hipLaunchKernelGGL(msntt::bit_reverse_simple<4>, grid, dim3(msntt::NT), 0, st, B);
             for (unsigned c = 0; c < nc; c++)
                 HIPCHK(hipMemcpyAsync(dst[c0 + c], (char*)scratch + c * col_bytes, col_bytes, hipMemcpyDeviceToDevice, st));
         }
@@ -529,6 +616,7 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
     if (!ctx || !d_in || !d_out) return fail(MS_ERR_INVALID, "ms_lde: null argument");
     unsigned V = 0;
     MSCHK(field_words(field, &V));
+    if (V == 4) return fail(MS_ERR_UNSUPPORTED, "fused LDE is not implemented for Fp252 (use two plans + ms_bit_reverse)");
     const unsigned log_N = log_n + log_blowup;
     if (log_N > 32) return fail(MS_ERR_INVALID, "LDE domain 2^%u exceeds the two-adicity", log_N);
     uint64_t h = 1;
@@ -605,7 +693,8 @@ static unsigned stream_grid(size_t n) { return (unsigned)std::max<size_t>(1, std
 static int field_pair(int lf, int rf, unsigned* VL, unsigned* VR) {
     MSCHK(field_words(lf, VL));
     MSCHK(field_words(rf, VR));
-    if (*VR > *VL) return fail(MS_ERR_UNSUPPORTED, "rhs field must embed into the lhs field (Fp,Fp / Fq3,Fq3 / Fq3,Fp)");
+    if (*VR > *VL || ((*VL == 4) != (*VR == 4)))
+        return fail(MS_ERR_UNSUPPORTED, "rhs field must embed into the lhs field (Fp,Fp / Fq3,Fq3 / Fq3,Fp / Fp252,Fp252)");
     return MS_OK;
 }
 static size_t norm_shift(long shift, size_t n) {
@@ -627,7 +716,8 @@ extern "C" int ms_binary(ms_ctx* ctx, int op, int lf, int rf, size_t n, void* d_
     dim3 g(stream_grid(n)), b(msstage::NT);
     ProfScope ps(ctx, op == MS_ADD ? "stage_add" : "stage_mul", 8.0 * n * (2 * VL + VR));
     using namespace msstage;
-    if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
+    if (VL == 4) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fp252T, Fp252T, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fp252T, Fp252T, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
+    else if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
     else if (VR == 3) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fq3T, Fq3T, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fq3T, Fq3T, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
     else { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fq3T, FpT, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fq3T, FpT, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
     HIPCHK(hipGetLastError());
@@ -641,13 +731,14 @@ extern "C" int ms_binary_const(ms_ctx* ctx, int op, int lf, int rf, size_t n, vo
     if (n == 0) return MS_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    msstage::Const3 c = {{0, 0, 0}};
+    msstage::Const3 c = {{0, 0, 0, 0}};
     memcpy(c.w, h_const, VR * 8);
     uint64_t* dst = (uint64_t*)d_dst; const uint64_t* l = (const uint64_t*)d_lhs;
     dim3 g(stream_grid(n)), b(msstage::NT);
     ProfScope ps(ctx, op == MS_ADD ? "stage_add_const" : "stage_mul_const", 16.0 * n * VL);
     using namespace msstage;
-    if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
+    if (VL == 4) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fp252T, Fp252T, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fp252T, Fp252T, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
+    else if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
     else if (VR == 3) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fq3T, Fq3T, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fq3T, Fq3T, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
     else { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fq3T, FpT, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fq3T, FpT, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
     HIPCHK(hipGetLastError());
@@ -665,7 +756,8 @@ extern "C" int ms_mul_pow(ms_ctx* ctx, int lf, int rf, size_t n, void* d_dst, co
     dim3 g(stream_grid(n)), b(msstage::NT);
     ProfScope ps(ctx, "stage_mul_pow", 8.0 * n * (2 * VL + VR));
     using namespace msstage;
-    if (VL == 1) hipLaunchKernelGGL((k_mul_pow<FpT, FpT>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
+    if (VL == 4) hipLaunchKernelGGL((k_mul_pow<Fp252T, Fp252T>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
+    else if (VL == 1) hipLaunchKernelGGL((k_mul_pow<FpT, FpT>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
     else if (VR == 3) hipLaunchKernelGGL((k_mul_pow<Fq3T, Fq3T>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
     else hipLaunchKernelGGL((k_mul_pow<Fq3T, FpT>), g, b, 0, ctx->stream, dst, l, r, n, sh, power);
     HIPCHK(hipGetLastError());
@@ -683,7 +775,11 @@ extern "C" int ms_unary(ms_ctx* ctx, int op, int field, size_t n, void* d_dst, c
     dim3 g(stream_grid(n)), b(msstage::NT);
     ProfScope ps(ctx, op == MS_NEG ? "stage_neg" : op == MS_INV ? "stage_inverse" : "stage_exp", 16.0 * n * V);
     using namespace msstage;
-    if (V == 1) {
+    if (V == 4) {
+        if (op == MS_NEG) hipLaunchKernelGGL((k_unary<Fp252T, 0>), g, b, 0, ctx->stream, dst, src, n, exponent);
+        else if (op == MS_INV) hipLaunchKernelGGL((k_unary<Fp252T, 1>), g, b, 0, ctx->stream, dst, src, n, exponent);
+        else hipLaunchKernelGGL((k_unary<Fp252T, 2>), g, b, 0, ctx->stream, dst, src, n, exponent);
+    } else if (V == 1) {
         if (op == MS_NEG) hipLaunchKernelGGL((k_unary<FpT, 0>), g, b, 0, ctx->stream, dst, src, n, exponent);
         else if (op == MS_INV) hipLaunchKernelGGL((k_unary<FpT, 1>), g, b, 0, ctx->stream, dst, src, n, exponent);
         else hipLaunchKernelGGL((k_unary<FpT, 2>), g, b, 0, ctx->stream, dst, src, n, exponent);
@@ -706,6 +802,7 @@ extern "C" int ms_convert(ms_ctx* ctx, int dst_field, int src_field, size_t n, v
         if (d_dst != d_src) HIPCHK(hipMemcpyAsync(d_dst, d_src, n * VD * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return MS_OK;
     }
+    if (VD != 3 || VS != 1) return fail(MS_ERR_UNSUPPORTED, "only the Fp -> Fq3 embedding exists");
     ProfScope ps(ctx, "stage_convert", 8.0 * n * (VD + VS));
     hipLaunchKernelGGL(msstage::k_convert_fp_fq3, dim3(stream_grid(n)), dim3(msstage::NT), 0, ctx->stream, (uint64_t*)d_dst, (const uint64_t*)d_src, n);
     HIPCHK(hipGetLastError());
@@ -718,7 +815,7 @@ extern "C" int ms_fill(ms_ctx* ctx, int field, size_t n, void* d_dst, const void
     if (n == 0) return MS_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    msstage::Const3 c = {{0, 0, 0}};
+    msstage::Const3 c = {{0, 0, 0, 0}};
     memcpy(c.w, h_value, V * 8);
     ProfScope ps(ctx, "stage_fill", 8.0 * n * V);
     hipLaunchKernelGGL(msstage::k_fill, dim3(stream_grid(n * V)), dim3(msstage::NT), 0, ctx->stream, (uint64_t*)d_dst, c, n * V, V);
@@ -739,7 +836,8 @@ extern "C" int ms_sum_columns(ms_ctx* ctx, int field, size_t n, const void* cons
     for (unsigned c = 0; c < ncols; c++) P.cols[c] = (const uint64_t*)d_cols[c];
     P.dst = (uint64_t*)d_dst; P.nwords = n * V; P.ncols = ncols;
     ProfScope ps(ctx, "sum_columns", 8.0 * n * V * (ncols + 1));
-    hipLaunchKernelGGL(msstage::k_sum_columns, dim3(stream_grid(n * V)), dim3(msstage::NT), 0, ctx->stream, P);
+    if (V == 4) { P.nwords = n; hipLaunchKernelGGL(msstage::k_sum_columns252, dim3(stream_grid(n)), dim3(msstage::NT), 0, ctx->stream, P); }
+    else hipLaunchKernelGGL(msstage::k_sum_columns, dim3(stream_grid(n * V)), dim3(msstage::NT), 0, ctx->stream, P);
     HIPCHK(hipGetLastError());
     return MS_OK;
 }
@@ -761,6 +859,7 @@ extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned fold
     if (!ctx || !h_alpha || !d_evals || !d_out) return fail(MS_ERR_INVALID, "ms_fri_fold: null argument");
     unsigned V = 0;
     MSCHK(field_words(field, &V));
+    if (V == 4) return fail(MS_ERR_UNSUPPORTED, "FRI fold is not implemented for Fp252");
     if (folding_factor != 2 && folding_factor != 4 && folding_factor != 8 && folding_factor != 16)
         return fail(MS_ERR_UNSUPPORTED, "folding factor %u not supported (2, 4, 8, 16)", folding_factor);   // src/fri.rs:186-192
     unsigned log_ff = 0;

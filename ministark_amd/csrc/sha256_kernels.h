@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include "gl.h"
 #include "gl_dev.h"
+#include "fp252.h"
 
 namespace mssha {
 
@@ -88,8 +89,11 @@ __global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
     unsigned wpos = 0;                                      // position in the 16-word block
     for (unsigned c = 0; c < P.ncols; c++) {
         const uint64_t* __restrict__ col = P.cols[c];
+        f252::E big = f252::zero();
+        if (P.V == 4) big = f252::from_mont(f252::E{{col[4 * r], col[4 * r + 1], col[4 * r + 2], col[4 * r + 3]}});
         for (unsigned v = 0; v < P.V; v++) {
-            const uint64_t x = gld::mmul(col[r * P.V + v], 1);     // out of Montgomery form, canonical
+            // out of Montgomery form, canonical; a 256-bit element is its 4 limbs, little-endian
+            const uint64_t x = (P.V == 4) ? big.l[v] : gld::mmul(col[r * P.V + v], 1);
             // wpos is always even here
             #pragma unroll
             for (int q = 0; q < 16; q += 2) if ((int)wpos == q) { s.w[q] = bswap32((uint32_t)x); s.w[q + 1] = bswap32((uint32_t)(x >> 32)); }

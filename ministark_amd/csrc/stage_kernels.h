@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include "gl.h"
 #include "gl_dev.h"
+#include "fp252.h"
 
 namespace msstage {
 
@@ -65,6 +66,18 @@ struct Fq3T {
     }
 };
 
+struct Fp252T {
+    using T = f252::E;
+    static constexpr int V = 4;
+    static __device__ __forceinline__ T load(const uint64_t* p, size_t i) { return {{p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]}}; }
+    static __device__ __forceinline__ void store(uint64_t* p, size_t i, const T& x) { p[4 * i] = x.l[0]; p[4 * i + 1] = x.l[1]; p[4 * i + 2] = x.l[2]; p[4 * i + 3] = x.l[3]; }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return f252::add(a, b); }
+    static __device__ __forceinline__ T neg(const T& a) { return f252::neg(a); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return f252::mul(a, b); }
+    static __device__ __forceinline__ T one() { return f252::one(); }
+    static __device__ __forceinline__ T inv(const T& a) { return f252::inv(a); }
+};
+
 // mixed-field operations: rhs in Fp acts on an Fq3 lhs as in gpu/src/fields.rs:99-188
 template <class L, class R> struct Mix;
 template <> struct Mix<FpT, FpT> {
@@ -74,6 +87,10 @@ template <> struct Mix<FpT, FpT> {
 template <> struct Mix<Fq3T, Fq3T> {
     static __device__ __forceinline__ gl::Fq3 add(gl::Fq3 a, gl::Fq3 b) { return gl::add(a, b); }
     static __device__ __forceinline__ gl::Fq3 mul(gl::Fq3 a, gl::Fq3 b) { return Fq3T::mul(a, b); }
+};
+template <> struct Mix<Fp252T, Fp252T> {
+    static __device__ __forceinline__ f252::E add(const f252::E& a, const f252::E& b) { return f252::add(a, b); }
+    static __device__ __forceinline__ f252::E mul(const f252::E& a, const f252::E& b) { return f252::mul(a, b); }
 };
 template <> struct Mix<Fq3T, FpT> {
     static __device__ __forceinline__ gl::Fq3 add(gl::Fq3 a, uint64_t b) { return {gl::add(a.c0, b), a.c1, a.c2}; }
@@ -97,7 +114,7 @@ __global__ void __launch_bounds__(NT) k_binary(uint64_t* dst, const uint64_t* lh
         L::store(dst, i, OP == 0 ? Mix<L, R>::add(a, b) : Mix<L, R>::mul(a, b));
     }
 }
-struct Const3 { uint64_t w[3]; };
+struct Const3 { uint64_t w[4]; };   // one element of any field (<= 4 words)
 template <class L, class R, int OP>
 __global__ void __launch_bounds__(NT) k_binary_const(uint64_t* dst, const uint64_t* lhs, Const3 c, size_t n) {
     const auto b = R::load(c.w, 0);
@@ -137,6 +154,14 @@ __global__ void __launch_bounds__(NT) k_sum_columns(SumParams P) {
         uint64_t acc = P.cols[0][i];                         // canonical
         for (unsigned c = 1; c < P.ncols; c++) acc = gl::add(acc, P.cols[c][i]);
         P.dst[i] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_sum_columns252(SumParams P) {      // nwords = number of elements here
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < P.nwords; i += (size_t)gridDim.x * NT) {
+        f252::E acc = Fp252T::load(P.cols[0], i);
+        for (unsigned c = 1; c < P.ncols; c++) acc = f252::add(acc, Fp252T::load(P.cols[c], i));
+        Fp252T::store(P.dst, i, acc);
     }
 }
 

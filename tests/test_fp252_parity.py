@@ -1,0 +1,113 @@
+"""The 252-bit StarkWare field (a3): NTT / iNTT / stages / row hashing vs the pure-Python big-int
+oracle, bit-exact.  Shapes follow gpu/tests/shaders.rs:69-91 (2048, 4096; subgroup and coset with
+offset = GENERATOR = 3) and src/eval_gpu.rs:1054-1082 (constants on Fp252)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle.pyref import fields as F
+from oracle.pyref import ntt as pyntt
+from tests import backends
+from ministark_amd import (STARK252_FP, F252_GENERATOR, GpuFft, GpuIfft, GpuVec, Matrix, Radix2EvaluationDomain,
+                           f252_from_mont_limbs, f252_to_mont_limbs)
+from ministark_amd import stages as S
+
+P = F.F252_P
+KINDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _rand_canon(n, seed):
+    rng = np.random.default_rng(seed)
+    vals = [int.from_bytes(rng.bytes(32), "little") % P for _ in range(n)]
+    vals[:3] = [0, 1, P - 1][: min(3, n)]
+    return vals
+
+
+def _to_dev(pl, vals):
+    return GpuVec.from_numpy(pl, np.concatenate([f252_to_mont_limbs(v) for v in vals]) if vals else np.zeros(0, np.uint64), STARK252_FP)
+
+
+def _from_dev(v):
+    a = v.to_numpy().reshape(-1, 4)
+    return [f252_from_mont_limbs(r) for r in a]
+
+
+def test_field_constants():
+    # felt_u256.h.metal:101-108
+    assert list(f252_to_mont_limbs(1)) == [18446744073709551585, 18446744073709551615, 18446744073709551615, 576460752303422960]
+    assert pow(F252_GENERATOR, (P - 1) // 2, P) == P - 1          # 3 is a non-residue: generates the 2-Sylow part
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("log_n,offset,inverse", [(11, 1, False), (12, 1, False), (11, 3, False), (12, 3, False), (11, 1, True), (12, 3, True), (5, 3, False), (9, 3, True)])
+def test_fft_with_256_bit_field(kind, log_n, offset, inverse):       # gpu/tests/shaders.rs:69-91
+    if kind == "emu" and log_n > 11:
+        pytest.skip("kept short under the simulator")
+    pl = backends.planner(kind)
+    n = 1 << log_n
+    vals = _rand_canon(n, log_n * 7 + offset)
+    dom = Radix2EvaluationDomain(n, offset, STARK252_FP)
+    v = _to_dev(pl, vals)
+    plan = (GpuIfft if inverse else GpuFft)(dom, STARK252_FP, pl)
+    plan.encode(v)
+    plan.execute()
+    d = pyntt.Domain(F.F252, n, offset)
+    want = pyntt.ifft(d, vals) if inverse else pyntt.fft(d, vals)
+    assert _from_dev(v) == want
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_stages_252(kind):
+    pl = backends.planner(kind)
+    n = 64
+    a, b = _rand_canon(n, 1), _rand_canon(n, 2)
+    A, B, D = _to_dev(pl, a), _to_dev(pl, b), GpuVec(pl, n, STARK252_FP)
+    S.MulIntoStage(pl, n, STARK252_FP).encode(D, A, B, 3)
+    assert _from_dev(D) == [(a[i] * b[(i + 3) % n]) % P for i in range(n)]
+    S.AddIntoStage(pl, n, STARK252_FP).encode(D, A, B, -1)
+    assert _from_dev(D) == [(a[i] + b[(i - 1) % n]) % P for i in range(n)]
+    S.NegIntoStage(pl, n, STARK252_FP).encode(D, A)
+    assert _from_dev(D) == [(-x) % P for x in a]
+    S.InverseIntoStage(pl, n, STARK252_FP).encode(D, A)
+    assert _from_dev(D) == [0 if x == 0 else pow(x, -1, P) for x in a]
+    S.ExpIntoStage(pl, n, STARK252_FP).encode(D, A, 13)
+    assert _from_dev(D) == [pow(x, 13, P) for x in a]
+    c = 123456789123456789123456789 % P
+    S.MulIntoConstStage(pl, n, STARK252_FP).encode(D, A, f252_to_mont_limbs(c))
+    assert _from_dev(D) == [(x * c) % P for x in a]
+    S.AddAssignConstStage(pl, n, STARK252_FP).encode(D, f252_to_mont_limbs(5))
+    assert _from_dev(D) == [(x * c + 5) % P for x in a]
+    L = _to_dev(pl, a)
+    S.MulPowStage(pl, n, STARK252_FP).encode(L, B, 3, 1)
+    assert _from_dev(L) == [(a[i] * pow(b[(i + 1) % n], 3, P)) % P for i in range(n)]
+    S.FillBuffStage(pl, n, STARK252_FP).encode(D, f252_to_mont_limbs(77))
+    assert _from_dev(D) == [77] * n
+    m = Matrix([_to_dev(pl, a), _to_dev(pl, b), _to_dev(pl, a)])
+    assert _from_dev(S.sum_columns(m)) == [(2 * a[i] + b[i]) % P for i in range(n)]
+    m.bit_reverse_rows()
+    assert _from_dev(m.columns[1]) == F.bit_reverse(b)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_hash_rows_252(kind):
+    pl = backends.planner(kind)
+    n = 16
+    a, b = _rand_canon(n, 3), _rand_canon(n, 4)
+    leaves = Matrix([_to_dev(pl, a), _to_dev(pl, b)]).hash_rows().to_numpy().reshape(n, 32)
+    for r in range(n):
+        assert leaves[r].tobytes() == hashlib.sha256(a[r].to_bytes(32, "little") + b[r].to_bytes(32, "little")).digest()
+
+
+@pytest.mark.gpu
+def test_roundtrip_2_16_252_hip():
+    pl = backends.planner("hip")
+    n = 1 << 16
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 1 << 59, size=4 * n, dtype=np.uint64)      # limbs < 2^59 => canonical (< p)
+    v = GpuVec.from_numpy(pl, x, STARK252_FP)
+    dom = Radix2EvaluationDomain(n, 3, STARK252_FP)
+    f = GpuFft(dom, STARK252_FP, pl); f.encode(v); f.execute()
+    assert not np.array_equal(v.to_numpy(), x)
+    g = GpuIfft(dom, STARK252_FP, pl); g.encode(v); g.execute()
+    assert np.array_equal(v.to_numpy(), x)
