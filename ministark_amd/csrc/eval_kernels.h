@@ -104,4 +104,44 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
     }
 }
 
+// Fp252 instantiation (Fq = Fp = the 252-bit field, src/eval_gpu.rs:1054-1082): only the P-typed
+// opcodes are legal; registers and constants are 4-limb elements (`a` of CONST_P indexes u64 words).
+template <int NP>
+__global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
+    using F = msstage::Fp252T;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= P.n) return;
+    f252::E rp[NP];
+    const size_t nmask = P.n - 1;
+    for (uint32_t pc = 0; pc < P.ninstr; pc++) {
+        const Instr I = P.prog[pc];
+        switch (I.op) {
+        case OP_X_P: {
+            f252::E x;
+            if (P.x_lde) x = F::load(P.x_lde, i);
+            else {
+                const size_t e = i << P.xshift;
+                x = F::load(P.tw_lo, e & ((1u << P.lo_bits) - 1));
+                if (e >> P.lo_bits) x = f252::mul(x, F::load(P.tw_hi, e >> P.lo_bits));
+                x = f252::mul(x, F::load(P.consts + P.h_mont, 0));      // h_mont = word index of the offset in consts
+            }
+            rp[I.dst] = x;
+        } break;
+        case OP_CONST_P: rp[I.dst] = f252::E{{P.consts[I.a], P.consts[I.a + 1], P.consts[I.a + 2], P.consts[I.a + 3]}}; break;
+        case OP_TRACE_P: {
+            const size_t j = (i + (size_t)((long long)(int32_t)I.b * (long long)P.lde_step)) & nmask;
+            rp[I.dst] = F::load(P.base_cols[I.a], j);
+        } break;
+        case OP_PERIODIC_P: rp[I.dst] = F::load(P.periodic[I.a], i % P.periodic_len[I.a]); break;
+        case OP_NEG_P: rp[I.dst] = f252::neg(rp[I.a]); break;
+        case OP_ADD_PP: rp[I.dst] = f252::add(rp[I.a], rp[I.b]); break;
+        case OP_MUL_PP: rp[I.dst] = f252::mul(rp[I.a], rp[I.b]); break;
+        case OP_INV_P: rp[I.dst] = f252::inv(rp[I.a]); break;
+        case OP_POW_P: rp[I.dst] = msstage::powu<F>(rp[I.a], I.b); break;
+        case OP_STORE_P: F::store(P.out, i, rp[I.a]); break;
+        default: break;
+        }
+    }
+}
+
 }  // namespace mseval

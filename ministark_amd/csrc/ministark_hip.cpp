@@ -907,7 +907,9 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
     if ((nbase && !d_base_cols) || (next && !d_ext_cols) || (nperiodic && (!d_periodic || !periodic_len))) return fail(MS_ERR_INVALID, "ms_eval_program: null column table");
     if (log_n > 32) return fail(MS_ERR_INVALID, "log_n too large");
     if (lde_step == 0) return fail(MS_ERR_INVALID, "lde_step must be positive");
-    if (out_field != MS_GOLDILOCKS_FP && out_field != MS_GOLDILOCKS_FQ3) return fail(MS_ERR_UNSUPPORTED, "output field must be Fp or Fq3");
+    const bool is252 = out_field == MS_STARK252_FP;          // Fq = Fp = Fp252: P-typed opcodes only, 4-word elements
+    if (out_field != MS_GOLDILOCKS_FP && out_field != MS_GOLDILOCKS_FQ3 && !is252) return fail(MS_ERR_UNSUPPORTED, "unknown output field");
+    const unsigned PW = is252 ? 4 : 1;
     // ---- validate: every register is written before it is read, all operands are in range
     unsigned maxp = 0, maxq = 0;
     std::vector<char> pw(256, 0), qw(128, 0);
@@ -920,7 +922,7 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
         bool ok = true, dp = false, dq = false;
         switch (I.op) {
         case OP_X_P: dp = true; break;
-        case OP_CONST_P: ok = I.a < nconst_words; dp = true; break;
+        case OP_CONST_P: ok = (uint64_t)I.a + PW <= nconst_words; dp = true; break;
         case OP_CONST_Q: ok = (uint64_t)I.a + 3 <= nconst_words; dq = true; break;
         case OP_TRACE_P: ok = I.a < nbase; dp = true; break;
         case OP_TRACE_Q: ok = I.a < next; dq = true; break;
@@ -933,9 +935,10 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
         case OP_ADD_QP: case OP_MUL_QP: ok = Q_ok(I.a) && P_ok(I.b); dq = true; break;
         case OP_EMBED: ok = P_ok(I.a); dq = true; break;
         case OP_STORE_Q: ok = Q_ok(I.a) && out_field == MS_GOLDILOCKS_FQ3; stored = true; break;
-        case OP_STORE_P: ok = P_ok(I.a) && out_field == MS_GOLDILOCKS_FP; stored = true; break;
+        case OP_STORE_P: ok = P_ok(I.a) && (out_field == MS_GOLDILOCKS_FP || is252); stored = true; break;
         default: ok = false;
         }
+        if (is252 && (dq || I.op == OP_STORE_Q)) ok = false;
         if (dp) { if (I.dst >= 256) ok = false; else { pw[I.dst] = 1; maxp = std::max(maxp, I.dst + 1); } }
         if (dq) { if (I.dst >= 128) ok = false; else { qw[I.dst] = 1; maxq = std::max(maxq, I.dst + 1); } }
         if (!ok) return fail(MS_ERR_INVALID, "constraint program: invalid instruction %u (op %u dst %u a %u b %u)", k, I.op, I.dst, I.a, I.b);
@@ -943,10 +946,20 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
     if (!stored) return fail(MS_ERR_INVALID, "constraint program never stores a result");
     const size_t n = (size_t)1 << log_n;
     uint64_t h = 1;
-    if (h_domain_offset) { uint64_t h_m; memcpy(&h_m, h_domain_offset, 8); h = gl::from_mont(h_m); }
+    if (h_domain_offset && !is252) { uint64_t h_m; memcpy(&h_m, h_domain_offset, 8); h = gl::from_mont(h_m); }
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    // program + constants -> device
+    // program + constants (+ the Fp252 domain offset as one more constant) -> device
+    std::vector<uint64_t> consts_ext;
+    if (is252) {
+        consts_ext.resize((size_t)nconst_words + 4);
+        if (nconst_words) memcpy(consts_ext.data(), h_consts, (size_t)nconst_words * 8);
+        f252::E ho = f252::one();
+        if (h_domain_offset) memcpy(ho.l, h_domain_offset, 32);
+        memcpy(consts_ext.data() + nconst_words, ho.l, 32);
+        h_consts = consts_ext.data();
+        nconst_words += 4;
+    }
     const size_t pbytes = (size_t)ninstr * sizeof(Instr), cbytes = (size_t)nconst_words * 8, total = pbytes + cbytes + 64;
     if (ctx->prog_bytes < total) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -969,13 +982,28 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
     for (unsigned c = 0; c < nperiodic; c++) { E.periodic[c] = (const uint64_t*)d_periodic[c]; E.periodic_len[c] = periodic_len[c]; }
     E.out = (uint64_t*)d_out; E.x_lde = (const uint64_t*)d_x_lde;
     E.h_mont = gl::to_mont(h); E.n = n; E.ninstr = ninstr; E.lde_step = lde_step; E.log_n = log_n;
+    dim3 g((unsigned)((n + NT - 1) / NT));
+    if (is252) {
+        if (!d_x_lde) {
+            ms_ntt_plan* plan = nullptr;
+            for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_n && !kv.first.inverse && kv.first.h == 1) plan = kv.second;
+            if (!plan) { MSCHK(plan_build252(ctx, log_n, false, nullptr, nullptr, &plan)); ctx->plan_cache.push_back({PlanKey{4, log_n, false, 1}, plan}); }
+            E.tw_lo = plan->d252_tw_lo; E.tw_hi = plan->d252_tw_hi; E.lo_bits = plan->lo_bits; E.xshift = 0;
+        }
+        E.h_mont = nconst_words - 4;           // word index of the offset inside consts
+        ProfScope ps(ctx, "eval_program252", 32.0 * n * (nbase + 1));
+        if (maxp <= 16) hipLaunchKernelGGL((eval_program252<16>), g, dim3(NT), 0, ctx->stream, E);
+        else if (maxp <= 64) hipLaunchKernelGGL((eval_program252<64>), g, dim3(NT), 0, ctx->stream, E);
+        else hipLaunchKernelGGL((eval_program252<256>), g, dim3(NT), 0, ctx->stream, E);
+        HIPCHK(hipGetLastError());
+        return MS_OK;
+    }
     if (!d_x_lde) {
         ms_ntt_plan* plan = nullptr;
         const unsigned tl = std::max(log_n, 12u);
         MSCHK(ctx_plan(ctx, 1, tl, false, 1, &plan));
         E.tw_lo = plan->d_tw_lo; E.tw_hi = plan->d_tw_hi; E.lo_bits = plan->lo_bits; E.xshift = tl - log_n;
     }
-    dim3 g((unsigned)((n + NT - 1) / NT));
     ProfScope ps(ctx, "eval_program", 8.0 * n * (nbase + 3.0 * next + (out_field == MS_GOLDILOCKS_FQ3 ? 3 : 1)));
     if (maxp <= 16 && maxq <= 8) hipLaunchKernelGGL((eval_program<16, 8>), g, dim3(NT), 0, ctx->stream, E);
     else if (maxp <= 64 && maxq <= 32) hipLaunchKernelGGL((eval_program<64, 32>), g, dim3(NT), 0, ctx->stream, E);

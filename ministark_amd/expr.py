@@ -12,7 +12,8 @@ import ctypes
 
 import numpy as np
 
-from .api import FIELD_WORDS, GOLDILOCKS_FP, GOLDILOCKS_FQ3, GL_P, GpuFft, GpuVec, Radix2EvaluationDomain, gl_to_mont
+from .api import (FIELD_WORDS, GOLDILOCKS_FP, GOLDILOCKS_FQ3, STARK252_FP, GL_P, F252_P, GpuFft, GpuVec, Radix2EvaluationDomain,
+                  gl_to_mont, f252_to_mont_limbs)
 
 FP, FQ = "fp", "fq"
 (OP_X_P, OP_CONST_P, OP_CONST_Q, OP_TRACE_P, OP_TRACE_Q, OP_PERIODIC_P, OP_PERIODIC_Q, OP_NEG_P, OP_NEG_Q,
@@ -48,10 +49,11 @@ def X():
 
 
 def Constant(value, field=FP):
-    """value: canonical int (Fp) or 3-tuple of canonical ints (Fq)."""
+    """value: canonical int (Fp) or 3-tuple of canonical ints (Fq).  Integers are kept as given
+    and reduced by the base field of the program they are compiled into."""
     if isinstance(value, tuple):
-        return Expr("const", FQ, tuple(int(v) % GL_P for v in value))
-    return Expr("const", field, int(value) % GL_P) if field == FP else Expr("const", FQ, (int(value) % GL_P, 0, 0))
+        return Expr("const", FQ, tuple(int(v) for v in value))
+    return Expr("const", field, int(value)) if field == FP else Expr("const", FQ, (int(value), 0, 0))
 
 
 def Challenge(i): return Expr("challenge", int(i))
@@ -82,11 +84,21 @@ class Program:
         self.max_q = 0
 
 
-def compile_expr(expr, num_base_columns, fq_is_ext=True):
+def compile_expr(expr, num_base_columns, fq_is_ext=True, base_field=GOLDILOCKS_FP):
     """Lower `expr` to a Program.  Trace columns < num_base_columns are Fp, the rest Fq
     (eval_cpu.rs:103-134).  Challenges and hints are Fq (eval_cpu.rs:111-113); with
-    fq_is_ext=False (Fq = Fp AIRs such as examples/fib) they are Fp."""
+    fq_is_ext=False (Fq = Fp AIRs such as examples/fib) they are Fp.  base_field = STARK252_FP
+    compiles for the 252-bit field (Fq = Fp, 4-word elements)."""
     prog = Program()
+    if base_field == STARK252_FP:
+        if fq_is_ext:
+            raise ValueError("the 252-bit field has no extension here: pass fq_is_ext=False")
+        pwords, pmod = 4, F252_P
+        to_words = lambda v: [int(w) for w in f252_to_mont_limbs(v % F252_P)]
+    else:
+        pwords, pmod = 1, GL_P
+        to_words = lambda v: [gl_to_mont(v % GL_P)]
+    prog.base_field = base_field
     memo = {}          # structural key -> (type, virtual register)
     nodes = []         # virtual instructions: [op, vdst, va, vb, type, imm]
     qtype = FQ if fq_is_ext else FP
@@ -135,14 +147,16 @@ def compile_expr(expr, num_base_columns, fq_is_ext=True):
             v = emit(OP_X_P, FP)
         elif kd == "const":
             if e.args[0] == FP:
-                v = emit(OP_CONST_P, FP, imm=const_slot([gl_to_mont(e.args[1])]))
+                v = emit(OP_CONST_P, FP, imm=const_slot(to_words(e.args[1])))
             else:
-                v = emit(OP_CONST_Q, FQ, imm=const_slot([gl_to_mont(c) for c in e.args[1]]))
+                if pwords != 1:
+                    raise ValueError("Fq constants need the Goldilocks extension")
+                v = emit(OP_CONST_Q, FQ, imm=const_slot([gl_to_mont(c % GL_P) for c in e.args[1]]))
         elif kd in ("challenge", "hint"):
             table = prog.challenge_slots if kd == "challenge" else prog.hint_slots
             idx = e.args[0]
             if idx not in table:
-                table[idx] = const_slot([0] * (3 if qtype == FQ else 1))
+                table[idx] = const_slot([0] * (3 if qtype == FQ else pwords))
             if kd == "challenge":
                 prog.nchallenges = max(prog.nchallenges, idx + 1)
             else:
@@ -195,7 +209,7 @@ def compile_expr(expr, num_base_columns, fq_is_ext=True):
     # result is always Fq (into_fq_array, eval_cpu.rs:262-275); for Fq = Fp AIRs that is Fp
     if qtype == FQ and nodes[root][4] == FP:
         root = emit(OP_EMBED, FQ, root)
-    prog.out_field = GOLDILOCKS_FQ3 if qtype == FQ else GOLDILOCKS_FP
+    prog.out_field = GOLDILOCKS_FQ3 if qtype == FQ else base_field
 
     # ---- register allocation: linear scan over the (already topological) node list
     last_use = {}
@@ -259,25 +273,28 @@ def eval(prog, planner, challenges, hints, lde_step, domain_offset, n, base_cols
     """`eval_cpu::eval(expr, challenges, hints, lde_step, domain_offset, x_lde, base, ext)`
     (src/eval_cpu.rs:33-42) -> one GpuVec of n elements of Fq.  challenges / hints: numpy u64
     limbs (Montgomery), one row per element."""
-    qwords = 3 if prog.out_field == GOLDILOCKS_FQ3 else 1
+    qwords = FIELD_WORDS[prog.out_field]
+    is252 = prog.out_field == STARK252_FP
     consts = np.array(prog.consts, dtype=np.uint64)
     for table, vals in ((prog.challenge_slots, challenges), (prog.hint_slots, hints)):
         vals = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1, qwords) if len(table) else None
         for idx, off in table.items():
             consts[off:off + qwords] = vals[idx]
     trace_len = n // lde_step
+    if is252 and prog.periodic:
+        raise ValueError("periodic columns are not implemented for the 252-bit field")
     per = [periodic_lde(planner, c, iv, domain_offset, trace_len, lde_step) for (c, iv) in prog.periodic]
     code = np.array(prog.instrs, dtype=np.uint32).reshape(-1, 4)
     out = GpuVec(planner, n, prog.out_field)
     L = planner.lib
-    off = ctypes.c_uint64(gl_to_mont(domain_offset))
+    off = f252_to_mont_limbs(domain_offset) if is252 else np.array([gl_to_mont(domain_offset)], dtype=np.uint64)
     VP = ctypes.c_void_p
     base_arr = (VP * max(1, len(base_cols)))(*[c.ptr for c in base_cols])
     ext_arr = (VP * max(1, len(ext_cols)))(*[c.ptr for c in ext_cols])
     per_arr = (VP * max(1, len(per)))(*[p.ptr for p in per])
     per_len = (ctypes.c_uint * max(1, len(per)))(*[len(p) for p in per])
     L.check(L.ms_eval_program(planner.handle, code.ctypes.data, len(code), consts.ctypes.data if consts.size else None, consts.size,
-                              n.bit_length() - 1, lde_step, ctypes.byref(off), x_lde.ptr if x_lde is not None else None,
+                              n.bit_length() - 1, lde_step, off.ctypes.data, x_lde.ptr if x_lde is not None else None,
                               base_arr, len(base_cols), ext_arr, len(ext_cols), per_arr, per_len, len(per),
                               prog.out_field, out.ptr))
     planner.sync()

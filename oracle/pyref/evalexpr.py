@@ -52,10 +52,13 @@ def _pow(a, e):
     return pow(a, e, P)
 
 
-def eval_points(expr, points, n, lde_step, domain_offset, base_cols, ext_cols, challenges, hints, fq_is_ext=True):
+def eval_points(expr, points, n, lde_step, domain_offset, base_cols, ext_cols, challenges, hints, fq_is_ext=True, field=GL):
     """Evaluate at each i in `points`.  Columns / challenges / hints are canonical (ints or
-    3-tuples).  Returns a list of Fq values (3-tuples, or ints when fq_is_ext is False)."""
-    w = GL.root_of_unity(n)
+    3-tuples).  Returns a list of Fq values (3-tuples, or ints when fq_is_ext is False).
+    `field`: the base PrimeField (GL, or F252 with fq_is_ext=False)."""
+    global P
+    P = field.p
+    w = field.root_of_unity(n)
     trace_len = n // lde_step
     periodic_cache = {}
 
@@ -63,7 +66,7 @@ def eval_points(expr, points, n, lde_step, domain_offset, base_cols, ext_cols, c
         k = (coeffs, interval)
         if k not in periodic_cache:
             size = interval * lde_step
-            d = Domain(GL, size, pow(domain_offset, trace_len // interval, P))
+            d = Domain(field, size, pow(domain_offset, trace_len // interval, P))
             periodic_cache[k] = fft(d, list(coeffs))
         return periodic_cache[k]
 
@@ -78,7 +81,7 @@ def eval_points(expr, points, n, lde_step, domain_offset, base_cols, ext_cols, c
             if k == "x":
                 r = (domain_offset * pow(w, i, P)) % P
             elif k == "const":
-                r = e.args[1]
+                r = tuple(c % P for c in e.args[1]) if isinstance(e.args[1], tuple) else e.args[1] % P
             elif k == "challenge":
                 r = challenges[e.args[0]]
             elif k == "hint":

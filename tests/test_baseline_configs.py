@@ -1,0 +1,100 @@
+"""BASELINE.json configs C3 / C4 at full size on the GPU, checked against the oracle.
+(C2 is tests/test_ntt_parity.py; C5's exchange step is tests/test_distributed.py.)"""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle.pyref import evalexpr
+from oracle.pyref.fields import GL
+from tests import backends
+from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3, GpuVec, Matrix, MerkleTree
+from ministark_amd import expr as E
+
+P = cref.GL_P
+
+
+@pytest.mark.gpu
+def test_c3_lde_2_20_x_32_blowup_8_and_commit():
+    # "Trace LDE: 2^20 rows x 32 columns, blowup 8, coset NTT + Merkle commit on 1 MI355X"
+    pl = backends.planner("hip")
+    log_n, log_b, ncols = 20, 3, 32
+    cols = [cref.random_elements(1 << log_n, 0x6D696E69 + c) for c in range(ncols)]
+    lde = Matrix.from_numpy(pl, cols, FP).lde(1 << log_b, 7, True)
+    tree = MerkleTree.from_matrix(lde)
+    root = tree.root()
+    want_cols = [cref.lde(c, log_n, log_b, 1, 7, True) for c in cols]
+    # 1000 sampled elements of the LDE, then the whole thing through the root
+    rng = np.random.default_rng(1)
+    got0 = lde.columns[0].to_numpy()
+    got31 = lde.columns[31].to_numpy()
+    idx = rng.integers(0, 1 << (log_n + log_b), size=1000)
+    assert np.array_equal(got0[idx], want_cols[0][idx]) and np.array_equal(got31[idx], want_cols[31][idx])
+    want_root = cref.sha256_merkle(cref.sha256_rows(want_cols, 1))[1].tobytes()
+    assert root == want_root
+
+
+def _sampled_eval(pl, expr, log_n, lde_step, base, ext, ch, fq_is_ext, npts=40):
+    n = 1 << log_n
+    prog = E.compile_expr(expr, len(base), fq_is_ext)
+    out = E.eval(prog, pl, ch, ch[:1], lde_step, 7, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
+                 [GpuVec.from_numpy(pl, c, FQ3) for c in ext]).to_numpy()
+    rng = np.random.default_rng(7)
+    pts = sorted(set([0, 1, n - 1] + [int(x) for x in rng.integers(0, n, size=npts)]))
+    canon = lambda col, V: _Lazy(col, V)
+    qc = (lambda r: tuple(GL.from_mont(int(x)) for x in r)) if fq_is_ext else (lambda r: GL.from_mont(int(r[0])))
+    want = evalexpr.eval_points(expr, pts, n, lde_step, 7, [canon(c, 1) for c in base], [canon(c, 3) for c in ext],
+                                [qc(r) for r in ch], [qc(r) for r in ch[:1]], fq_is_ext)
+    V = 3 if fq_is_ext else 1
+    for i, w in zip(pts, want):
+        got = tuple(GL.from_mont(int(x)) for x in out[V * i:V * i + V])
+        assert got == (w if fq_is_ext else (w,)), f"point {i}"
+
+
+class _Lazy:
+    """column view that converts out of Montgomery form on access (the oracle only touches a few rows)."""
+
+    def __init__(self, col, V):
+        self.col, self.V = col, V
+
+    def __getitem__(self, j):
+        if self.V == 1:
+            return GL.from_mont(int(self.col[j]))
+        return tuple(GL.from_mont(int(x)) for x in self.col[3 * j:3 * j + 3])
+
+
+@pytest.mark.gpu
+def test_c4_fib_air_2_23():
+    # "Constraint composition eval on 2^23-row synthetic AIR" (i): fib AIR, 8 Fp columns, Fq = Fp
+    pl = backends.planner("hip")
+    log_n, lde_step = 23, 4
+    x = E.X()
+    c = [lambda o=0, k=k: E.Trace(k, o) for k in range(8)]
+    cons = [c[0](1) - (c[6]() + c[7]()), c[1](1) - (c[7]() + c[0](1))] + [c[k]() - (c[k - 2]() + c[k - 1]()) for k in range(2, 8)]
+    n_trace = 1 << (log_n - 2)
+    zer = (x - E.Constant(pow(GL.root_of_unity(n_trace), -1, P))) / (x ** n_trace - 1)
+    comp = None
+    for k, cn in enumerate(cons):
+        term = cn * zer * (E.Challenge(2 * k) * x ** 3 + E.Challenge(2 * k + 1))
+        comp = term if comp is None else comp + term
+    base = [cref.random_elements(1 << log_n, 100 + k) for k in range(8)]
+    ch = cref.random_elements(16, 5).reshape(-1, 1)
+    _sampled_eval(pl, comp, log_n, lde_step, base, [], ch, False)
+
+
+@pytest.mark.gpu
+def test_c4_mixed_17_fp_9_fq3_2_20():
+    # (ii): the brainfuck shape, 17 Fp + 9 Fq3 columns (examples/brainfuck/air.rs:26-27)
+    pl = backends.planner("hip")
+    log_n, lde_step = 20, 2
+    x = E.X()
+    b = [lambda o=0, k=k: E.Trace(k, o) for k in range(17)]
+    e = [lambda o=0, k=k: E.Trace(17 + k, o) for k in range(9)]
+    expr = None
+    for k in range(9):
+        t = (e[k](1) - e[k]() * (E.Challenge(k % 4) - b[k]() * E.Challenge((k + 1) % 4) - b[k + 8](1))) * (x - 1) / (x ** 64 - 1)
+        expr = t if expr is None else expr + t * E.Challenge(k % 4)
+    expr = expr + (b[16]() ** 2 - b[16]()) * e[0]() / (x - E.Constant(3))
+    base = [cref.random_elements(1 << log_n, 200 + k) for k in range(17)]
+    ext = [cref.random_elements(3 << log_n, 300 + k) for k in range(9)]
+    ch = cref.random_elements(12, 6).reshape(-1, 3)
+    _sampled_eval(pl, expr, log_n, lde_step, base, ext, ch, True, npts=24)

@@ -128,3 +128,25 @@ def test_eval_2_20_vs_sampled_oracle_hip():
     x = E.X()
     expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) / (x ** 1024 - 1) + E.Trace(2) * E.Challenge(0) + E.Trace(3, -1) ** 5
     _check("hip", expr, 20, 8, 2, 2, nch=1, npoints=24)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fp252_program(kind):                      # src/eval_gpu.rs:1054-1082: constants / columns on Fp252
+    from oracle.pyref.fields import F252
+    from ministark_amd import STARK252_FP, f252_from_mont_limbs, f252_to_mont_limbs
+    pl = backends.planner(kind)
+    log_n, lde_step, ncols = 10, 2, 3
+    n = 1 << log_n
+    rng = np.random.default_rng(3)
+    cols = [[int.from_bytes(rng.bytes(32), "little") % F252.p for _ in range(n)] for _ in range(ncols)]
+    ch = [int.from_bytes(rng.bytes(32), "little") % F252.p for _ in range(2)]
+    x = E.X()
+    expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) / (x ** 4 - 1) + E.Trace(2, -1) ** 3 * E.Challenge(1) + E.Constant(12345678901234567890123) / x + E.Challenge(0)
+    prog = E.compile_expr(expr, ncols, fq_is_ext=False, base_field=STARK252_FP)
+    dev = [GpuVec.from_numpy(pl, np.concatenate([f252_to_mont_limbs(v) for v in c]), STARK252_FP) for c in cols]
+    chm = np.stack([f252_to_mont_limbs(v) for v in ch])
+    out = E.eval(prog, pl, chm, chm[:1], lde_step, 3, n, dev).to_numpy().reshape(n, 4)
+    pts = [0, 1, 5, n // 2, n - 1, 777]
+    want = evalexpr.eval_points(expr, pts, n, lde_step, 3, cols, [], ch, ch[:1], False, F252)
+    for i, w in zip(pts, want):
+        assert f252_from_mont_limbs(out[i]) == w, f"point {i}"
