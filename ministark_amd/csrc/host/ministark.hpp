@@ -1,0 +1,185 @@
+// ministark.hpp -- C++17 host mirror of the reference's gpu-poly interface over the C ABI
+// (include/ministark_hip.h).  The reference is Rust; this header stands where its
+// `cfg(feature = "hip")` arm would: same item names, argument meaning and
+// error behaviour -- the reference panics on GPU-side failures (gpu/src/plan.rs:248,255,360),
+// here every non-zero status becomes a std::runtime_error.
+//   Planner / get_planner()          gpu/src/plan.rs:327-351
+//   GpuVec<F>                        src/utils.rs:438-470
+//   Radix2EvaluationDomain           ark-poly, as consumed at gpu/src/plan.rs:386-423
+//   GpuFft<F> / GpuIfft<F>           gpu/src/plan.rs:236-325
+//   Matrix<F>                        src/matrix.rs:26-394
+//   MerkleTree                       src/merkle.rs:296-361 (MatrixMerkleTreeImpl<Sha256HashFn>)
+// Header-only; needs no HIP headers, link with -lministark_hip.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/ministark_hip.h"
+
+namespace ms {
+
+inline void check(int rc) {
+    if (rc != MS_OK) throw std::runtime_error("ministark_hip error " + std::to_string(rc) + ": " + ms_last_error());
+}
+
+// field tags = GpuField::field_name() (gpu/src/fields.rs)
+struct Fp { static constexpr int id = MS_GOLDILOCKS_FP; static constexpr unsigned words = 1; };
+struct Fq3 { static constexpr int id = MS_GOLDILOCKS_FQ3; static constexpr unsigned words = 3; };
+struct Fp252 { static constexpr int id = MS_STARK252_FP; static constexpr unsigned words = 4; };
+
+namespace gl {   // just enough Goldilocks host arithmetic to build domain constants
+constexpr uint64_t P = 0xFFFFFFFF00000001ull;
+inline uint64_t mul(uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % P); }
+inline uint64_t pow(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = mul(r, a); a = mul(a, a); e >>= 1; } return r; }
+inline uint64_t to_mont(uint64_t x) { return mul(x % P, 0xFFFFFFFFull); }
+}  // namespace gl
+
+class Planner {
+public:
+    explicit Planner(int device = 0) { check(ms_ctx_create(device, &ctx_)); }
+    ~Planner() { ms_ctx_destroy(ctx_); }
+    Planner(const Planner&) = delete;
+    Planner& operator=(const Planner&) = delete;
+    ms_ctx* ctx() const { return ctx_; }
+    void sync() const { check(ms_sync(ctx_)); }        // command_buffer.wait_until_completed()
+private:
+    ms_ctx* ctx_ = nullptr;
+};
+inline Planner& get_planner() { static Planner p(0); return p; }
+
+template <class F>
+class GpuVec {
+public:
+    GpuVec(Planner& pl, size_t n) : pl_(&pl), n_(n) { check(ms_alloc(pl.ctx(), n * F::words * 8 + 8, &ptr_)); }
+    GpuVec(Planner& pl, const std::vector<uint64_t>& host) : GpuVec(pl, host.size() / F::words) { upload(host); }
+    ~GpuVec() { if (ptr_) ms_free(pl_->ctx(), ptr_); }
+    GpuVec(GpuVec&& o) noexcept : pl_(o.pl_), n_(o.n_), ptr_(o.ptr_) { o.ptr_ = nullptr; }
+    GpuVec(const GpuVec&) = delete;
+    size_t len() const { return n_; }
+    void* ptr() const { return ptr_; }
+    Planner& planner() const { return *pl_; }
+    void upload(const std::vector<uint64_t>& host) { check(ms_upload(pl_->ctx(), ptr_, host.data(), n_ * F::words * 8)); }
+    std::vector<uint64_t> to_host() const {
+        std::vector<uint64_t> h(n_ * F::words);
+        check(ms_download(pl_->ctx(), h.data(), ptr_, h.size() * 8));
+        return h;
+    }
+    GpuVec clone() const { GpuVec c(*pl_, n_); c.upload(to_host()); return c; }
+private:
+    Planner* pl_; size_t n_; void* ptr_ = nullptr;
+};
+
+// Goldilocks domains only (Fp252 domains carry 4-limb constants; see the Python mirror)
+struct Radix2EvaluationDomain {
+    size_t size; unsigned log_size; uint64_t group_gen, offset;      // canonical integers
+    explicit Radix2EvaluationDomain(size_t n, uint64_t coset_offset = 1) : size(n), log_size(0), offset(coset_offset % gl::P) {
+        if (n == 0 || (n & (n - 1))) throw std::invalid_argument("domain size must be a power of two");
+        while (((size_t)1 << log_size) < n) log_size++;
+        if (log_size > 32) throw std::invalid_argument("domain exceeds the two-adicity");
+        group_gen = gl::pow(1753635133440165772ull, (uint64_t)1 << (32 - log_size));
+    }
+    static Radix2EvaluationDomain new_coset(size_t n, uint64_t off) { return Radix2EvaluationDomain(n, off); }
+};
+
+template <class F, int INVERSE>
+class FftBase {
+public:
+    static constexpr size_t MIN_SIZE = 1;      // 2048 in the reference (gpu/src/plan.rs:248,294)
+    FftBase(Planner& pl, const Radix2EvaluationDomain& d) : pl_(&pl), n_(d.size) {
+        const uint64_t off = gl::to_mont(d.offset), gen = gl::to_mont(d.group_gen);
+        check(ms_ntt_plan_create(pl.ctx(), F::id, d.log_size, INVERSE, &off, &gen, &plan_));
+    }
+    ~FftBase() { if (plan_) ms_ntt_plan_destroy(plan_); }
+    FftBase(const FftBase&) = delete;
+    void encode(GpuVec<F>& column) {            // plan.rs:254-263 / 300-309
+        if (column.len() != n_) throw std::invalid_argument("column length differs from the domain size");   // plan.rs:257 assert_eq!
+        check(ms_ntt_encode(plan_, column.ptr()));
+    }
+    void execute() { check(ms_ntt_execute(plan_)); }   // plan.rs:229-232 (blocks)
+private:
+    Planner* pl_; size_t n_; ms_ntt_plan* plan_ = nullptr;
+};
+template <class F> using GpuFft = FftBase<F, 0>;
+template <class F> using GpuIfft = FftBase<F, 1>;
+
+class MerkleTree;
+
+template <class F>
+class Matrix {
+public:
+    std::vector<GpuVec<F>> columns;
+    Matrix() = default;
+    explicit Matrix(std::vector<GpuVec<F>>&& cols) : columns(std::move(cols)) {}
+    size_t num_rows() const { return columns.empty() ? 0 : columns[0].len(); }
+    size_t num_cols() const { return columns.size(); }
+    Planner& planner() const { return columns.at(0).planner(); }
+    Matrix clone() const { Matrix m; for (auto& c : columns) m.columns.push_back(c.clone()); return m; }
+    Matrix& into_polynomials(const Radix2EvaluationDomain& d) {       // src/matrix.rs:102-116
+        GpuIfft<F> ifft(planner(), d);
+        for (auto& c : columns) ifft.encode(c);
+        ifft.execute();
+        return *this;
+    }
+    Matrix interpolate(const Radix2EvaluationDomain& d) const { Matrix m = clone(); m.into_polynomials(d); return m; }
+    Matrix& into_evaluations(const Radix2EvaluationDomain& d) {       // src/matrix.rs:193-208 (columns already of domain size)
+        GpuFft<F> fft(planner(), d);
+        for (auto& c : columns) fft.encode(c);
+        fft.execute();
+        return *this;
+    }
+    Matrix evaluate(const Radix2EvaluationDomain& d) const { Matrix m = clone(); m.into_evaluations(d); return m; }
+    Matrix& bit_reverse_rows() {                                       // src/matrix.rs:352-354
+        auto p = ptrs();
+        unsigned lg = 0; while (((size_t)1 << lg) < num_rows()) lg++;
+        check(ms_bit_reverse(planner().ctx(), F::id, lg, p.data(), (unsigned)p.size()));
+        planner().sync();
+        return *this;
+    }
+    // interpolate(trace_domain) + bit_reversed_evaluate(lde_domain), src/prover.rs:50-51, fused
+    Matrix lde(unsigned log_blowup, uint64_t offset = 7, bool bit_reversed = true) const {
+        Matrix out;
+        for (size_t c = 0; c < columns.size(); c++) out.columns.emplace_back(planner(), num_rows() << log_blowup);
+        std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
+        auto o = out.ptrs();
+        unsigned lg = 0; while (((size_t)1 << lg) < num_rows()) lg++;
+        const uint64_t off = gl::to_mont(offset);
+        check(ms_lde(planner().ctx(), F::id, lg, log_blowup, &off, in.data(), o.data(), (unsigned)in.size(), bit_reversed ? 1 : 0));
+        planner().sync();
+        return out;
+    }
+    GpuVec<F> sum_columns() const {                                    // src/matrix.rs:357-394
+        GpuVec<F> dst(planner(), num_rows());
+        std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
+        check(ms_sum_columns(planner().ctx(), F::id, num_rows(), in.data(), (unsigned)in.size(), dst.ptr()));
+        planner().sync();
+        return dst;
+    }
+    std::vector<void*> ptrs() const { std::vector<void*> p; for (auto& c : columns) p.push_back(c.ptr()); return p; }
+};
+
+class MerkleTree {
+public:
+    template <class F>
+    static MerkleTree from_matrix(const Matrix<F>& m) {                // src/merkle.rs:356-361
+        MerkleTree t(m.planner(), m.num_rows());
+        std::vector<const void*> in; for (auto& c : m.columns) in.push_back(c.ptr());
+        check(ms_sha256_rows(t.pl_->ctx(), F::id, t.n_, in.data(), (unsigned)in.size(), t.leaves_));
+        check(ms_sha256_merkle(t.pl_->ctx(), t.n_, t.leaves_, t.nodes_));
+        return t;
+    }
+    std::array<uint8_t, 32> root() const {                              // nodes[1], src/merkle.rs:145-147
+        std::array<uint8_t, 32> r{};
+        check(ms_download(pl_->ctx(), r.data(), (const char*)nodes_ + 32, 32));
+        return r;
+    }
+    ~MerkleTree() { if (leaves_) ms_free(pl_->ctx(), leaves_); if (nodes_) ms_free(pl_->ctx(), nodes_); }
+    MerkleTree(MerkleTree&& o) noexcept : pl_(o.pl_), n_(o.n_), leaves_(o.leaves_), nodes_(o.nodes_) { o.leaves_ = o.nodes_ = nullptr; }
+private:
+    MerkleTree(Planner& pl, size_t n) : pl_(&pl), n_(n) { check(ms_alloc(pl.ctx(), n * 32, &leaves_)); check(ms_alloc(pl.ctx(), n * 32, &nodes_)); }
+    Planner* pl_; size_t n_; void* leaves_ = nullptr; void* nodes_ = nullptr;
+};
+
+}  // namespace ms
