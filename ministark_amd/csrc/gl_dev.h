@@ -17,6 +17,7 @@
 // compiles the same source for the host-side simulator tests.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "gl.h"
 
 namespace gld {
@@ -205,5 +206,48 @@ MS_HD void dft_lazy(uint64_t* x) {
 }
 template <bool INV>
 MS_HD void dft16(uint64_t* x) { dft_lazy<16, INV>(x); }
+
+// Radix-16 network whose inputs x[a] are zero for a >= NA (zero-padded LDE input, NA in {1,2,4}):
+//   X[M c2 + c1] = sum_{a<NA} (x_a w^(a c1)) w_NA^(a c2),  M = 16/NA
+// i.e. M twisted size-NA transforms; each is a handful of the same butterflies.  x[0..NA) canonical
+// in, x[0..16) weak out (natural order).
+template <int NA, bool INV>
+MS_HD void dft16_pruned(uint64_t* x) {
+    static_assert(NA == 1 || NA == 2 || NA == 4, "prune factor");
+    if constexpr (NA == 1) {
+        #pragma unroll
+        for (int c = 1; c < 16; c++) x[c] = x[0];
+    } else if constexpr (NA == 2) {
+        const uint64_t x0 = x[0], x1 = x[1];
+        #pragma unroll
+        for (int c1 = 0; c1 < 8; c1++) {
+            uint64_t u = x0, v = x1;
+            if (c1 == 0) bfly<INV, 0, true>(u, v);
+            if (c1 == 1) bfly<INV, 1, true>(u, v);
+            if (c1 == 2) bfly<INV, 2, true>(u, v);
+            if (c1 == 3) bfly<INV, 3, true>(u, v);
+            if (c1 == 4) bfly<INV, 4, true>(u, v);
+            if (c1 == 5) bfly<INV, 5, true>(u, v);
+            if (c1 == 6) bfly<INV, 6, true>(u, v);
+            if (c1 == 7) bfly<INV, 7, true>(u, v);
+            x[c1] = u; x[c1 + 8] = v;
+        }
+    } else {
+        const uint64_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+        auto quad = [&](auto C1) {
+            constexpr int c1 = decltype(C1)::value;
+            uint64_t s0 = x0, s1 = x2, p = x1, q = x3;
+            bfly<INV, 2 * c1, true>(s0, s1);          // x0 +- w^(2 c1) x2
+            bfly<INV, 2 * c1, true>(p, q);            // x1 +- w^(2 c1) x3
+            bfly<INV, c1, false>(s0, p);              // X[c1], X[c1 + 8]
+            bfly<INV, c1 + 4, false>(s1, q);          // X[c1 + 4], X[c1 + 12]
+            x[c1] = s0; x[c1 + 8] = p; x[c1 + 4] = s1; x[c1 + 12] = q;
+        };
+        quad(std::integral_constant<int, 0>{});
+        quad(std::integral_constant<int, 1>{});
+        quad(std::integral_constant<int, 2>{});
+        quad(std::integral_constant<int, 3>{});
+    }
+}
 
 }  // namespace gld

@@ -419,8 +419,14 @@ extern "C" int ms_ntt_plan_destroy(ms_ntt_plan* plan) {
 }
 
 template <int RB, bool INV, bool LAST>
-static void launch_mid_scale(int scale, dim3 grid, hipStream_t st, const msntt::PassParams& P) {
+static void launch_mid_scale(int scale, bool bitrev, dim3 grid, hipStream_t st, const msntt::PassParams& P) {
     if constexpr (LAST) {
+        if (bitrev) {      // fused bit-reversed store (LDE): forward transforms only carry scale 0
+            if (scale == 1) hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 1, true>), grid, dim3(msntt::NT), 0, st, P);
+            else if (scale == 2) hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 2, true>), grid, dim3(msntt::NT), 0, st, P);
+            else hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 0, true>), grid, dim3(msntt::NT), 0, st, P);
+            return;
+        }
         if (scale == 1) hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 1>), grid, dim3(msntt::NT), 0, st, P);
         else if (scale == 2) hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 2>), grid, dim3(msntt::NT), 0, st, P);
         else hipLaunchKernelGGL((msntt::ntt_mid_pass<RB, INV, true, 0>), grid, dim3(msntt::NT), 0, st, P);
@@ -429,9 +435,9 @@ static void launch_mid_scale(int scale, dim3 grid, hipStream_t st, const msntt::
     }
 }
 template <int RB>
-static void launch_mid(bool inv, bool last, int scale, dim3 grid, hipStream_t st, const msntt::PassParams& P) {
-    if (inv) { if (last) launch_mid_scale<RB, true, true>(scale, grid, st, P); else launch_mid_scale<RB, true, false>(scale, grid, st, P); }
-    else     { if (last) launch_mid_scale<RB, false, true>(scale, grid, st, P); else launch_mid_scale<RB, false, false>(scale, grid, st, P); }
+static void launch_mid(bool inv, bool last, int scale, bool bitrev, dim3 grid, hipStream_t st, const msntt::PassParams& P) {
+    if (inv) { if (last) launch_mid_scale<RB, true, true>(scale, bitrev, grid, st, P); else launch_mid_scale<RB, true, false>(scale, false, grid, st, P); }
+    else     { if (last) launch_mid_scale<RB, false, true>(scale, bitrev, grid, st, P); else launch_mid_scale<RB, false, false>(scale, false, grid, st, P); }
 }
 
 static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* const* src, void* const* dst, unsigned ncols);
@@ -466,11 +472,12 @@ static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst,
 
 // Transform `ncols` columns: src[c] -> dst[c] (may alias).  valid_rows < 256 means the
 // source only holds the first valid_rows/256 of the domain, the rest is implicit zeros.
-static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows) {
+static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows, bool bitrev_out = false) {
     if (p->is252) {
-        if (valid_rows != 256) return fail(MS_ERR_UNSUPPORTED, "zero-extended input is not implemented for Fp252");
+        if (valid_rows != 256 || bitrev_out) return fail(MS_ERR_UNSUPPORTED, "zero-extended input / fused bit reversal are not implemented for Fp252");
         return plan_run252(p, src, dst, ncols);
     }
+    if (bitrev_out && p->small) return fail(MS_ERR_INVALID, "internal: fused bit reversal needs the multi-pass path");
     ms_ctx* ctx = p->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -518,16 +525,25 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             if (q == 0) {
                 const bool cos = (!p->inverse && p->coset);
                 if (p->inverse) hipLaunchKernelGGL((msntt::ntt_first_pass<true, false>), grid, dim3(msntt::NT), 0, st, P);
-                else if (cos) hipLaunchKernelGGL((msntt::ntt_first_pass<false, true>), grid, dim3(msntt::NT), 0, st, P);
-                else hipLaunchKernelGGL((msntt::ntt_first_pass<false, false>), grid, dim3(msntt::NT), 0, st, P);
+                else if (cos) {
+                    if (valid_rows == 64) hipLaunchKernelGGL((msntt::ntt_first_pass<false, true, 4>), grid, dim3(msntt::NT), 0, st, P);
+                    else if (valid_rows == 32) hipLaunchKernelGGL((msntt::ntt_first_pass<false, true, 2>), grid, dim3(msntt::NT), 0, st, P);
+                    else if (valid_rows == 16) hipLaunchKernelGGL((msntt::ntt_first_pass<false, true, 1>), grid, dim3(msntt::NT), 0, st, P);
+                    else hipLaunchKernelGGL((msntt::ntt_first_pass<false, true>), grid, dim3(msntt::NT), 0, st, P);
+                } else {
+                    if (valid_rows == 64) hipLaunchKernelGGL((msntt::ntt_first_pass<false, false, 4>), grid, dim3(msntt::NT), 0, st, P);
+                    else if (valid_rows == 32) hipLaunchKernelGGL((msntt::ntt_first_pass<false, false, 2>), grid, dim3(msntt::NT), 0, st, P);
+                    else if (valid_rows == 16) hipLaunchKernelGGL((msntt::ntt_first_pass<false, false, 1>), grid, dim3(msntt::NT), 0, st, P);
+                    else hipLaunchKernelGGL((msntt::ntt_first_pass<false, false>), grid, dim3(msntt::NT), 0, st, P);
+                }
             } else {
                 const int scale = last ? p->scale_mode : 0;
                 switch (p->lr[q]) {
-                case 4: launch_mid<1>(p->inverse, last, scale, grid, st, P); break;
-                case 5: launch_mid<2>(p->inverse, last, scale, grid, st, P); break;
-                case 6: launch_mid<4>(p->inverse, last, scale, grid, st, P); break;
-                case 7: launch_mid<8>(p->inverse, last, scale, grid, st, P); break;
-                case 8: launch_mid<16>(p->inverse, last, scale, grid, st, P); break;
+                case 4: launch_mid<1>(p->inverse, last, scale, bitrev_out, grid, st, P); break;
+                case 5: launch_mid<2>(p->inverse, last, scale, bitrev_out, grid, st, P); break;
+                case 6: launch_mid<4>(p->inverse, last, scale, bitrev_out, grid, st, P); break;
+                case 7: launch_mid<8>(p->inverse, last, scale, bitrev_out, grid, st, P); break;
+                case 8: launch_mid<16>(p->inverse, last, scale, bitrev_out, grid, st, P); break;
                 default: return fail(MS_ERR_INVALID, "internal: bad pass radix 2^%u", p->lr[q]);
                 }
             }
@@ -633,7 +649,9 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
         if (rc == MS_OK) {
             if (!fwd->small && log_blowup <= 4) {
-                rc = plan_run(fwd, (const void* const*)d_out, d_out, ncols, 256u >> log_blowup);
+                // zero padding is implicit in pass 1, the bit reversal is fused into the last pass
+                rc = plan_run(fwd, (const void* const*)d_out, d_out, ncols, 256u >> log_blowup, bit_reversed != 0);
+                bit_reversed = 0;
             } else {
                 for (unsigned c = 0; c < ncols && rc == MS_OK; c++)
                     if (hipMemsetAsync((char*)d_out[c] + n * V * 8, 0, (N - n) * V * 8, ctx->stream) != hipSuccess)

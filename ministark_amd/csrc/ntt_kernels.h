@@ -84,7 +84,9 @@ __device__ __forceinline__ unsigned digit_rev(const PassParams& P, unsigned x) {
 
 // ---- pass 1 ----------------------------------------------------------------------
 // grid = (n*V/256/16, columns).  COSET: input scaled by h^j (offset != 1, forward).
-template <bool INV, bool COSET>
+// NA: 16 = dense input; 1 / 2 / 4 = only rows j1 < 16*NA are non-zero (LDE blow-up 16 / 8 / 4): the
+// zero rows are neither loaded nor multiplied and the first network collapses (gld::dft16_pruned).
+template <bool INV, bool COSET, int NA = 16>
 __global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
     const unsigned V = P.V;
     __shared__ uint64_t lds[TILE];
@@ -98,14 +100,24 @@ __global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
     {
         const unsigned t = tid & 15, b = tid >> 4;
         uint64_t x[16];
-        #pragma unroll
-        for (int a = 0; a < 16; a++)
-            x[a] = (16u * a + b < P.valid_rows) ? src[(size_t)(16 * a + b) * row_words + w0 + t] : 0;
-        if constexpr (COSET) {
+        if constexpr (NA == 16) {
             #pragma unroll
-            for (int a = 0; a < 16; a++) x[a] = gld::mmul(x[a], P.gtab[16 * a + b]);
+            for (int a = 0; a < 16; a++)
+                x[a] = (16u * a + b < P.valid_rows) ? src[(size_t)(16 * a + b) * row_words + w0 + t] : 0;
+            if constexpr (COSET) {
+                #pragma unroll
+                for (int a = 0; a < 16; a++) x[a] = gld::mmul(x[a], P.gtab[16 * a + b]);
+            }
+            gld::dft_lazy<16, INV>(x);
+        } else {
+            #pragma unroll
+            for (int a = 0; a < NA; a++) x[a] = src[(size_t)(16 * a + b) * row_words + w0 + t];
+            if constexpr (COSET) {
+                #pragma unroll
+                for (int a = 0; a < NA; a++) x[a] = gld::mmul(x[a], P.gtab[16 * a + b]);
+            }
+            gld::dft16_pruned<NA, INV>(x);
         }
-        gld::dft_lazy<16, INV>(x);
         // internal twiddle w_256^(b c) (also canonicalises: wr[0] = 1), then exchange so that
         // thread (c, t) gets all b
         #pragma unroll
@@ -141,9 +153,14 @@ __global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
 // ---- passes 2..m -------------------------------------------------------------------
 // R = 16*RB rows at element stride s = 2^log_s, T = 4096/R = 256/RB consecutive words.
 // SCALE (last pass only): 0 none, 1 multiply by scale_const, 2 multiply by c*hinv^k (aux tables)
-template <int RB, bool INV, bool LAST, int SCALE>
+// BITREV (last pass only): store element k at position bitrev(k) -- Matrix::bit_reverse_rows
+// (src/matrix.rs:352-354) fused into the transform: the tile is transposed through LDS so that
+// each wave still writes runs of R consecutive elements.
+template <int RB, bool INV, bool LAST, int SCALE, bool BITREV = false>
 __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
     constexpr int R = 16 * RB, T = 256 / RB, G = 16 / RB;
+    constexpr int LOGR = (RB == 1) ? 4 : (RB == 2) ? 5 : (RB == 4) ? 6 : (RB == 8) ? 7 : 8;
+    static_assert(!BITREV || LAST, "bit-reversed store only exists for the last pass");
     const unsigned V = P.V;
     __shared__ uint64_t lds[16 * LDS_PAD_CS];
     __shared__ uint64_t twl[R];
@@ -197,6 +214,7 @@ __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
     // outputs: thread (t, cl) holds k = c + 16 d, c = cl*G + g, d = 0..RB-1 in y[g*RB + d]
     {
         const unsigned t = tid % T, cl = tid / T;
+        if constexpr (BITREV) __syncthreads();               // phase 2 has finished reading lds
         #pragma unroll
         for (int g = 0; g < G; g++) {
             #pragma unroll
@@ -213,7 +231,21 @@ __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
                 } else {
                     val = gld::canon(val);
                 }
-                dst[pos] = val;
+                if constexpr (BITREV) lds[t * (R + 1) + (__brev(k) >> (32 - LOGR))] = val;
+                else dst[pos] = val;
+            }
+        }
+        if constexpr (BITREV) {
+            __syncthreads();
+            // lanes run along the bit-reversed k: runs of R consecutive elements per low word
+            #pragma unroll 4
+            for (unsigned idx = tid; idx < (unsigned)TILE; idx += NT) {
+                const unsigned kk = idx % R, tt = idx / R;
+                const size_t w = lo0 + tt;                            // word inside the low block (U = 0 in the last pass)
+                const size_t e_low = w / V;
+                const unsigned v = (unsigned)(w % V);
+                const size_t e_rev = P.log_s ? (size_t)(__brevll((unsigned long long)e_low) >> (64 - P.log_s)) : 0;
+                dst[((e_rev << LOGR) + kk) * V + v] = lds[tt * (R + 1) + kk];
             }
         }
     }

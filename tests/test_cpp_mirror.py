@@ -29,5 +29,7 @@ def test_cpp_mirror_compiles_and_links():
 @pytest.mark.gpu
 def test_cpp_mirror_parity_on_gpu():
     exe = _build()
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    from oracle import cref
+    env = dict(os.environ, OMP_NUM_THREADS=str(cref._cpu_budget()))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "cpp host mirror ok" in out.stdout, out.stdout + out.stderr

@@ -157,18 +157,30 @@ def _lde(kind, field, log_n, log_b, ncols=2, bit_reversed=True):
         assert np.array_equal(got, cref.lde(c, log_n, log_b, V, 7, bit_reversed))
 
 
-@pytest.mark.parametrize("log_n,log_b", [(4, 1), (8, 3), (9, 3), (10, 4), (12, 1), (13, 3)])
+@pytest.mark.parametrize("log_n,log_b", [(4, 1), (8, 3), (9, 3), (10, 4), (12, 1), (13, 3), (12, 3), (14, 3), (10, 2), (11, 4), (12, 0)])
 def test_lde_emu(log_n, log_b):
     _lde("emu", GOLDILOCKS_FP, log_n, log_b)
 
 
+@pytest.mark.parametrize("offset", [1, 7])
+@pytest.mark.parametrize("log_b", [2, 3, 4])
+def test_lde_pruned_first_pass_emu(offset, log_b):
+    # blow-up 4 / 8 / 16 take the pruned radix-16 network; offset 1 the non-coset instantiation
+    pl = backends.planner("emu")
+    c = _rand(1 << 10, 91)
+    out = Matrix.from_numpy(pl, [c]).lde(1 << log_b, offset, False).to_numpy()[0]
+    assert np.array_equal(out, cref.lde(c, 10, log_b, 1, offset, False))
+
+
 def test_lde_fq3_emu():
     _lde("emu", GOLDILOCKS_FQ3, 10, 3)
+    _lde("emu", GOLDILOCKS_FQ3, 11, 3)
+    _lde("emu", GOLDILOCKS_FQ3, 12, 2)
     _lde("emu", GOLDILOCKS_FP, 10, 2, bit_reversed=False)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n,log_b", [(9, 4), (11, 3), (16, 3), (20, 3), (18, 0)])
+@pytest.mark.parametrize("log_n,log_b", [(9, 4), (11, 3), (16, 3), (20, 3), (18, 0), (15, 2), (14, 4), (17, 1), (13, 3)])
 def test_lde_hip(log_n, log_b):
     _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=3)
 
