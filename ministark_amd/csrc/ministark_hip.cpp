@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -77,6 +78,12 @@ struct ms_ctx {
     size_t scratch_bytes = 0;
     size_t group_bytes = (size_t)32 << 20;   // columns are processed in groups of about this size
     std::mutex mu;
+    // freed device blocks, by size: GpuVec churn (clone / resize in src/matrix.rs:155-208, the LdeCache of
+    // src/eval_gpu.rs:857-898) must not cost a hipMalloc + hipFree pair per column.  All work is ordered on
+    // one stream, so a block can be handed out again without synchronising.
+    std::multimap<size_t, void*> pool;
+    size_t pool_bytes = 0, pool_cap = (size_t)96 << 30;
+    std::map<void*, size_t> live;            // size of every block handed out by ms_alloc
     void* prog_buf = nullptr;                // device copy of the current constraint program + constants
     size_t prog_bytes = 0;
     // optional per-launch timing (ms_profile_*): hipEvent pairs around every kernel launch
@@ -127,6 +134,7 @@ extern "C" int ms_ctx_create(int device, ms_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(MS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     if (const char* g = getenv("MS_NTT_GROUP_BYTES")) ctx->group_bytes = (size_t)strtoull(g, nullptr, 10);
+    if (const char* g = getenv("MS_POOL_BYTES")) ctx->pool_cap = (size_t)strtoull(g, nullptr, 10);
     *out = ctx;
     return MS_OK;
 }
@@ -136,6 +144,7 @@ extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->plan_cache) ms_ntt_plan_destroy(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -180,12 +189,35 @@ extern "C" int ms_profile_read(ms_ctx* ctx, char* buf, size_t cap) {
 extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {
     if (!ctx || !d_ptr) return fail(MS_ERR_INVALID, "ms_alloc: null argument");
     HIPCHK(hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(d_ptr, bytes);
-    if (e != hipSuccess) return fail(MS_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = ctx->pool.find(bytes);
+    if (it != ctx->pool.end()) {
+        *d_ptr = it->second;
+        ctx->pool_bytes -= bytes;
+        ctx->pool.erase(it);
+    } else {
+        hipError_t e = hipMalloc(d_ptr, bytes);
+        if (e != hipSuccess && !ctx->pool.empty()) {          // give cached blocks back and retry
+            (void)hipStreamSynchronize(ctx->stream);
+            for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+            ctx->pool.clear(); ctx->pool_bytes = 0;
+            e = hipMalloc(d_ptr, bytes);
+        }
+        if (e != hipSuccess) return fail(MS_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    ctx->live[*d_ptr] = bytes;
     return MS_OK;
 }
 extern "C" int ms_free(ms_ctx* ctx, void* d_ptr) {
     if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    if (!d_ptr) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->live.find(d_ptr);
+    if (it == ctx->live.end()) return fail(MS_ERR_INVALID, "ms_free: pointer was not returned by ms_alloc on this context");
+    const size_t bytes = it->second;
+    ctx->live.erase(it);
+    if (ctx->pool_bytes + bytes <= ctx->pool_cap) { ctx->pool.insert({bytes, d_ptr}); ctx->pool_bytes += bytes; return MS_OK; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(d_ptr));
     return MS_OK;

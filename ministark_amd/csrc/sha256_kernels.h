@@ -32,10 +32,8 @@ __device__ static const uint32_t K256[64] = {
     0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
     0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
-__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-__device__ __forceinline__ uint32_t bswap32(uint32_t x) {
-    return (x >> 24) | ((x >> 8) & 0xFF00u) | ((x << 8) & 0xFF0000u) | (x << 24);
-}
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }   // -> v_alignbit_b32
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }                  // -> v_perm_b32
 
 struct Sha {
     uint32_t h[8];
@@ -78,46 +76,48 @@ struct RowsParams {
     unsigned V;               // u64 words per element
 };
 
-// One row per lane.  Message word stream: for each column, for each limb v: the canonical value x
-// contributes bswap32(lo32(x)), bswap32(hi32(x)) (little-endian bytes read as big-endian words).
+// One row per lane.  The message is a stream of 8-byte slots: slot i < nslots is limb (i % V) of the
+// element of column i / V, as its canonical value x, contributing the big-endian words
+// bswap32(lo32(x)), bswap32(hi32(x)) (little-endian bytes); slot nslots holds the 0x80 pad, the last
+// slot of the last block the bit length.  Blocks of 8 slots are filled with compile-time register
+// indices (no dynamic indexing of the schedule).
 __global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
     const size_t r = (size_t)blockIdx.x * NT + threadIdx.x;
     if (r >= P.nrows) return;
     Sha s;
     s.init();
-    const unsigned words_per_row = P.ncols * P.V;          // u64 words
-    unsigned wpos = 0;                                      // position in the 16-word block
-    for (unsigned c = 0; c < P.ncols; c++) {
-        const uint64_t* __restrict__ col = P.cols[c];
-        f252::E big = f252::zero();
-        if (P.V == 4) big = f252::from_mont(f252::E{{col[4 * r], col[4 * r + 1], col[4 * r + 2], col[4 * r + 3]}});
-        for (unsigned v = 0; v < P.V; v++) {
-            // out of Montgomery form, canonical; a 256-bit element is its 4 limbs, little-endian
-            const uint64_t x = (P.V == 4) ? big.l[v] : gld::mmul(col[r * P.V + v], 1);
-            // wpos is always even here
-            #pragma unroll
-            for (int q = 0; q < 16; q += 2) if ((int)wpos == q) { s.w[q] = bswap32((uint32_t)x); s.w[q + 1] = bswap32((uint32_t)(x >> 32)); }
-            wpos += 2;
-            if (wpos == 16) { s.compress(); wpos = 0; }
-        }
-    }
-    // padding: 0x80, zeros, 64-bit big-endian bit length
-    const uint64_t bits = (uint64_t)words_per_row * 64;
-    #pragma unroll
-    for (int q = 0; q < 16; q += 2) if ((int)wpos == q) { s.w[q] = 0x80000000u; s.w[q + 1] = 0; }
-    #pragma unroll
-    for (int q = 2; q < 16; q += 2) if (q > (int)wpos) { s.w[q] = 0; s.w[q + 1] = 0; }
-    if (wpos + 2 > 14) {          // no room for the length in this block
-        s.compress();
+    const unsigned V = P.V;
+    const unsigned nslots = P.ncols * V;
+    const unsigned nblocks = (nslots + 2 + 7) / 8;
+    const uint64_t bits = (uint64_t)nslots * 64;
+    f252::E big = f252::zero();
+    for (unsigned blk = 0; blk < nblocks; blk++) {
         #pragma unroll
-        for (int q = 0; q < 14; q++) s.w[q] = 0;
+        for (int j = 0; j < 8; j++) {
+            const unsigned i = blk * 8 + j;
+            uint32_t w0 = 0, w1 = 0;
+            if (i < nslots) {
+                const unsigned c = i / V, v = i - c * V;
+                const uint64_t* __restrict__ col = P.cols[c];
+                uint64_t x;
+                if (V == 4) {
+                    if (v == 0) big = f252::from_mont(f252::E{{col[4 * r], col[4 * r + 1], col[4 * r + 2], col[4 * r + 3]}});
+                    x = v == 0 ? big.l[0] : v == 1 ? big.l[1] : v == 2 ? big.l[2] : big.l[3];
+                } else {
+                    x = gld::mmul(col[r * V + v], 1);       // out of Montgomery form, canonical
+                }
+                w0 = bswap32((uint32_t)x); w1 = bswap32((uint32_t)(x >> 32));
+            } else if (i == nslots) {
+                w0 = 0x80000000u;
+            }
+            if (j == 7 && blk == nblocks - 1) { w0 = (uint32_t)(bits >> 32); w1 = (uint32_t)bits; }
+            s.w[2 * j] = w0; s.w[2 * j + 1] = w1;
+        }
+        s.compress();
     }
-    s.w[14] = (uint32_t)(bits >> 32);
-    s.w[15] = (uint32_t)bits;
-    s.compress();
-    uint32_t* out = (uint32_t*)(P.leaves + r * 32);
-    #pragma unroll
-    for (int q = 0; q < 8; q++) out[q] = bswap32(s.h[q]);
+    uint4* out = (uint4*)(P.leaves + r * 32);
+    out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
+    out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
 }
 
 // nodes[out0 + i] = SHA-256(src[2i] || src[2i+1]) for i < count; digests are 32 raw bytes
