@@ -67,6 +67,10 @@ int ms_profile_read(ms_ctx* ctx, char* buf, size_t cap);
  * columns live in HBM and are mirrored explicitly. */
 int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr);
 int ms_free(ms_ctx* ctx, void* d_ptr);
+/* ms_alloc / ms_free recycle device blocks through a per-context pool (a freed block may be handed
+ * out again without a hipFree: all work is ordered on the context's stream).
+ * ms_copy = GpuVec clone on device (Matrix::clone in interpolate/evaluate, src/matrix.rs:155-163,237-243). */
+int ms_copy(ms_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);      /* asynchronous */
 int ms_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* blocks */
 int ms_download(ms_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* blocks */
 
@@ -133,6 +137,10 @@ int ms_sum_columns(ms_ctx* ctx, int field, size_t n, const void* const* d_cols, 
  *                  (MerkleTreeImpl::new -> build_merkle_nodes).  nleaves = 2^k >= 2. */
 int ms_sha256_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_leaves);
 int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leaves, void* d_nodes);
+/* Row hashing of a ROW-MAJOR matrix [nrows][ncols] of `field` elements: the FRI layer commitment,
+ * Matrix::from_arrays(evaluations.as_chunks::<N>()) + from_matrix (src/fri.rs:213-216) -- row r is the
+ * coset of ncols = folding_factor consecutive evaluations; no de-interleaving copy is made. */
+int ms_sha256_rows_row_major(ms_ctx* ctx, int field, size_t nrows, unsigned ncols, const void* d_matrix, void* d_leaves);
 
 /* ---- fused constraint evaluation: eval_gpu::eval / eval_cpu::eval
  * (src/eval_gpu.rs:46-131, src/eval_cpu.rs:33-150; called from AirConfig::eval_constraint,

@@ -44,6 +44,7 @@ class Lib:
             "ms_profile_read": (i, [vp, ctypes.c_char_p, sz]),
             "ms_alloc": (i, [vp, sz, c_void_pp]),
             "ms_free": (i, [vp, vp]),
+            "ms_copy": (i, [vp, vp, vp, sz]),
             "ms_upload": (i, [vp, vp, vp, sz]),
             "ms_download": (i, [vp, vp, vp, sz]),
             "ms_ntt_plan_create": (i, [vp, i, u, i, vp, vp, c_void_pp]),
@@ -64,6 +65,7 @@ class Lib:
             "ms_fri_fold": (i, [vp, i, u, u, vp, vp, vp, vp]),
             "ms_sha256_rows": (i, [vp, i, sz, c_void_pp, u, vp]),
             "ms_sha256_merkle": (i, [vp, sz, vp, vp]),
+            "ms_sha256_rows_row_major": (i, [vp, i, sz, u, vp, vp]),
         }
         self.optional = {}
         for name, (res, args) in sigs.items():

@@ -137,7 +137,9 @@ class GpuVec:
         return out
 
     def clone(self):
-        return GpuVec.from_numpy(self.planner, self.to_numpy(), self.field)
+        out = GpuVec(self.planner, self.n, self.field)
+        self.planner.lib.check(self.planner.lib.ms_copy(self.planner.handle, out.ptr, self.ptr, self.words * 8))
+        return out
 
     def free(self):
         if self.owner and self.ptr:
@@ -192,6 +194,16 @@ class MerkleTree:
     @classmethod
     def from_matrix(cls, matrix):
         return cls(matrix.planner, matrix.hash_rows(), matrix.num_rows())
+
+    @classmethod
+    def from_fri_layer(cls, evaluations, folding_factor):
+        """`Matrix::from_arrays(evaluations.as_chunks::<N>())` + `M::from_matrix` (src/fri.rs:213-216):
+        commit to a bit-reversed FRI layer whose rows are the cosets of N consecutive evaluations."""
+        pl = evaluations.planner
+        nrows = len(evaluations) // folding_factor
+        leaves = DeviceBytes(pl, nrows * 32)
+        pl.lib.check(pl.lib.ms_sha256_rows_row_major(pl.handle, evaluations.field, nrows, folding_factor, evaluations.ptr, leaves.ptr))
+        return cls(pl, leaves, nrows)
 
     def root(self):
         out = np.empty(32, dtype=np.uint8)

@@ -222,6 +222,12 @@ extern "C" int ms_free(ms_ctx* ctx, void* d_ptr) {
     HIPCHK(hipFree(d_ptr));
     return MS_OK;
 }
+extern "C" int ms_copy(ms_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !d_src))) return fail(MS_ERR_INVALID, "ms_copy: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (bytes && d_dst != d_src) HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MS_OK;
+}
 extern "C" int ms_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     if (!ctx) return fail(MS_ERR_INVALID, "null context");
     HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -710,7 +716,26 @@ extern "C" int ms_sha256_rows(ms_ctx* ctx, int field, size_t nrows, const void* 
     mssha::RowsParams P;
     memset(&P, 0, sizeof P);
     for (unsigned c = 0; c < ncols; c++) P.cols[c] = (const uint64_t*)d_cols[c];
-    P.leaves = (uint8_t*)d_leaves; P.nrows = nrows; P.ncols = ncols; P.V = V;
+    P.leaves = (uint8_t*)d_leaves; P.nrows = nrows; P.ncols = ncols; P.V = V; P.row_stride = V;
+    {
+        ProfScope ps(ctx, "sha256_rows", (double)nrows * ncols * V * 8 + 32.0 * nrows);
+        hipLaunchKernelGGL(mssha::sha256_rows, dim3((unsigned)((nrows + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, P);
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_sha256_rows_row_major(ms_ctx* ctx, int field, size_t nrows, unsigned ncols, const void* d_matrix, void* d_leaves) {
+    if (!ctx || !d_matrix || !d_leaves) return fail(MS_ERR_INVALID, "ms_sha256_rows_row_major: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (ncols == 0 || ncols > (unsigned)mssha::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "1..%d columns per row", mssha::MAXCOLS);
+    if (nrows == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    mssha::RowsParams P;
+    memset(&P, 0, sizeof P);
+    for (unsigned c = 0; c < ncols; c++) P.cols[c] = (const uint64_t*)d_matrix + (size_t)c * V;
+    P.leaves = (uint8_t*)d_leaves; P.nrows = nrows; P.ncols = ncols; P.V = V; P.row_stride = ncols * V;
     {
         ProfScope ps(ctx, "sha256_rows", (double)nrows * ncols * V * 8 + 32.0 * nrows);
         hipLaunchKernelGGL(mssha::sha256_rows, dim3((unsigned)((nrows + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, P);

@@ -74,6 +74,7 @@ struct RowsParams {
     size_t nrows;
     unsigned ncols;
     unsigned V;               // u64 words per element
+    unsigned row_stride;      // words between consecutive rows of one column (V when columns are dense)
 };
 
 // One row per lane.  The message is a stream of 8-byte slots: slot i < nslots is limb (i % V) of the
@@ -101,10 +102,11 @@ __global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
                 const uint64_t* __restrict__ col = P.cols[c];
                 uint64_t x;
                 if (V == 4) {
-                    if (v == 0) big = f252::from_mont(f252::E{{col[4 * r], col[4 * r + 1], col[4 * r + 2], col[4 * r + 3]}});
+                    const uint64_t* e = col + r * P.row_stride;
+                    if (v == 0) big = f252::from_mont(f252::E{{e[0], e[1], e[2], e[3]}});
                     x = v == 0 ? big.l[0] : v == 1 ? big.l[1] : v == 2 ? big.l[2] : big.l[3];
                 } else {
-                    x = gld::mmul(col[r * V + v], 1);       // out of Montgomery form, canonical
+                    x = gld::mmul(col[r * P.row_stride + v], 1);       // out of Montgomery form, canonical
                 }
                 w0 = bswap32((uint32_t)x); w1 = bswap32((uint32_t)(x >> 32));
             } else if (i == nslots) {

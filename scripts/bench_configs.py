@@ -132,3 +132,43 @@ def fri():
 
 wall, k = timed(fri, reps=3)
 emit("FRI folds 2^23 -> 2^8 by 8 (Fq3), 5 layers", wall, k, first_layer_GBps=round((24 * (1 << 23) * 9 / 8) / (k.get("fri_fold", 1) * 1e-6) / 1e9, 1))
+
+# ---- C5-shaped pipeline on ONE GPU: the data-parallel phases of default_prove (src/prover.rs:25-174)
+# on a 2^22-row x 8-column fib-shaped trace, ProofOptions::new(32, 4, 8, 8, 64) (examples/fib/main.rs:225):
+# blow-up 4, FRI folding 8.  DEEP composition (src/composer.rs, host-side in the reference) is replaced by
+# taking the composition LDE as the FRI input; no channel / queries.  Timings only.
+del lde, state
+log_t, blow = 22, 4
+trace = Matrix.from_numpy(pl, [rand(1 << log_t) for _ in range(8)], FP)
+prog_c5 = E.compile_expr(comp, 8, False)
+phase = {}
+
+
+def c5():
+    t = time.perf_counter()
+    lde_t = trace.lde(blow, 7, True)                                   # prover.rs:50-51
+    tree_t = MerkleTree.from_matrix(lde_t); tree_t.root()              # prover.rs:52-55
+    phase["lde+commit base trace"] = time.perf_counter() - t; t = time.perf_counter()
+    nat = lde_t.clone().bit_reverse_rows()                             # prover.rs:88-91 (ce domain = lde domain here)
+    comp_evals = E.eval(prog_c5, pl, ch, ch[:1], blow, 7, 1 << (log_t + 2), nat.columns)   # prover.rs:98-107
+    phase["constraint evaluation"] = time.perf_counter() - t; t = time.perf_counter()
+    ifft = GpuIfft(Radix2EvaluationDomain(1 << (log_t + 2), 7), FP, pl)    # prover.rs:111-112
+    ifft.encode(comp_evals); ifft.execute(); ifft.close()
+    fft = GpuFft(Radix2EvaluationDomain(1 << (log_t + 2), 7), FP, pl)      # prover.rs:122-124 (one column of the split)
+    fft.encode(comp_evals); fft.execute(); fft.close()
+    cm = Matrix([comp_evals]).bit_reverse_rows()
+    MerkleTree.from_matrix(cm).root()
+    phase["composition iNTT + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
+    cur, n = cm.columns[0], 1 << (log_t + 2)                            # fri.rs:179-231
+    alpha1 = rand(1)
+    while n > 64 * blow:
+        MerkleTree.from_fri_layer(cur, 8).root()
+        cur = apply_drp(cur, alpha1, 8, 1)
+        n //= 8
+    pl.sync()
+    phase["FRI layers (commit + fold)"] = time.perf_counter() - t
+
+
+wall, k = timed(c5, reps=2)
+emit("C5-shaped single-GPU pipeline: 2^22 rows x 8 cols, blow-up 4, FRI fold 8 (no DEEP/channel)", wall, k,
+     phases_ms={kk: round(v * 1e3, 2) for kk, v in phase.items()})

@@ -67,3 +67,27 @@ def test_fq3_rows_hip():
 @pytest.mark.gpu
 def test_commit_2_20_x_32_hip():
     _commit("hip", GOLDILOCKS_FP, 20, 32)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("field,ff", [(GOLDILOCKS_FP, 2), (GOLDILOCKS_FP, 8), (GOLDILOCKS_FQ3, 4), (GOLDILOCKS_FQ3, 16)])
+def test_fri_layer_commit_row_major(kind, field, ff):       # src/fri.rs:213-216
+    from ministark_amd import GpuVec
+    pl = backends.planner(kind)
+    V = 3 if field == GOLDILOCKS_FQ3 else 1
+    n = 1 << 9
+    ev = cref.random_elements(n * V, 11)
+    tree = MerkleTree.from_fri_layer(GpuVec.from_numpy(pl, ev, field), ff)
+    rows = ev.reshape(n // ff, ff, V)
+    cols = [np.ascontiguousarray(rows[:, k, :]).ravel() for k in range(ff)]      # Matrix::from_arrays: column k = k-th element of every coset
+    want = cref.sha256_merkle(cref.sha256_rows(cols, V))
+    assert np.array_equal(tree.nodes_numpy(), want)
+
+
+def test_clone_is_device_side_emu():
+    from ministark_amd import GpuVec
+    pl = backends.planner("emu")
+    a = cref.random_elements(100, 3)
+    v = GpuVec.from_numpy(pl, a)
+    w = v.clone()
+    assert w.ptr != v.ptr and np.array_equal(w.to_numpy(), a)

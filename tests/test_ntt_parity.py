@@ -106,6 +106,21 @@ def test_many_columns_hip():
     _run("hip", GOLDILOCKS_FP, 16, False, 7, ncols=37)   # more than one launch group
 
 
+@pytest.mark.gpu
+def test_four_pass_sizes_hip():
+    # 2^25 and beyond take four passes (256 x ...): checked against the oracle at 2^25, round trip at 2^27
+    _run("hip", GOLDILOCKS_FP, 25, False, 7)
+    _run("hip", GOLDILOCKS_FP, 25, True, 7)
+    pl = backends.planner("hip")
+    n = 1 << 27
+    x = _rand(n, 123)
+    v = GpuVec.from_numpy(pl, x)
+    dom = Radix2EvaluationDomain(n, 7)
+    f = GpuFft(dom, GOLDILOCKS_FP, pl); f.encode(v); f.execute()
+    g = GpuIfft(dom, GOLDILOCKS_FP, pl); g.encode(v); g.execute()
+    assert np.array_equal(v.to_numpy(), x)
+
+
 # --- round trip / properties at BASELINE's full size ----------------------------------
 @pytest.mark.gpu
 def test_roundtrip_2_24_hip():
