@@ -180,6 +180,18 @@ int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const 
 int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
                 const void* h_offset, const void* d_evals, void* d_out);
 
+/* ---- RPO-256 commitments over Goldilocks Fp: GpuRpo256ColumnMajor / GpuRpo256RowMajor /
+ * gen_rpo_merkle_tree (gpu/src/plan.rs:32-174; kernels gpu/src/metal/hash_shaders.h.metal:215-380).
+ * Digests are 4 Fp elements (Montgomery form, 32 bytes).
+ * ms_rpo256_rows            = update(col) x ncols + finish(): digests[r] = RPO(row r of the columns), with
+ *                             the reference's padding rule when ncols is not a multiple of 8
+ * ms_rpo256_rows_row_major  = the same for a row-major matrix [nrows][ncols] (GpuRpo256RowMajor: ncols = 8)
+ * ms_rpo256_merkle          = gen_rpo_merkle_tree: nodes[k] = merge(nodes[2k], nodes[2k+1]), leaf pairs feed
+ *                             nodes[n/2 ..), nodes[1] = root, nodes[0] = zero */
+int ms_rpo256_rows(ms_ctx* ctx, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_digests);
+int ms_rpo256_rows_row_major(ms_ctx* ctx, size_t nrows, unsigned ncols, const void* d_matrix, void* d_digests);
+int ms_rpo256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leaves, void* d_nodes);
+
 #ifdef __cplusplus
 }
 #endif

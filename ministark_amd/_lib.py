@@ -65,6 +65,9 @@ class Lib:
             "ms_fri_fold": (i, [vp, i, u, u, vp, vp, vp, vp]),
             "ms_sha256_rows": (i, [vp, i, sz, c_void_pp, u, vp]),
             "ms_sha256_merkle": (i, [vp, sz, vp, vp]),
+            "ms_rpo256_rows": (i, [vp, sz, c_void_pp, u, vp]),
+            "ms_rpo256_rows_row_major": (i, [vp, sz, u, vp, vp]),
+            "ms_rpo256_merkle": (i, [vp, sz, vp, vp]),
             "ms_sha256_rows_row_major": (i, [vp, i, sz, u, vp, vp]),
         }
         self.optional = {}

@@ -442,3 +442,59 @@ def apply_drp(evals, alpha, folding_factor, domain_offset=1):
     pl.lib.check(pl.lib.ms_fri_fold(pl.handle, evals.field, n.bit_length() - 1, folding_factor, al.ctypes.data,
                                     ctypes.byref(off), evals.ptr, out.ptr))
     return out
+
+
+class GpuRpo256ColumnMajor:
+    """`GpuRpo256ColumnMajor::new(n, requires_padding)` / `update(col)` / `finish()` (gpu/src/plan.rs:32-107):
+    row-wise RPO-256 digests of equally long Fp columns.  `finish()` returns a GpuVec of n x 4 elements."""
+    RATE = 8
+
+    def __init__(self, n, requires_padding=None, planner=None):
+        self.n = n
+        self.planner = planner or get_planner()
+        self.cols = []
+        self.requires_padding = requires_padding
+
+    def update(self, col):
+        if len(col) != self.n or col.field != GOLDILOCKS_FP:
+            raise ValueError("column of the wrong length or field")
+        self.cols.append(col)
+
+    def finish(self):
+        if not self.cols:
+            raise ValueError("the zero-length input is not allowed")            # plan.rs:72
+        if self.requires_padding is not None and self.requires_padding != (len(self.cols) % self.RATE != 0):
+            raise ValueError("requires_padding does not match the number of columns absorbed")
+        pl = self.planner
+        out = GpuVec(pl, self.n * 4, GOLDILOCKS_FP)
+        pl.lib.check(pl.lib.ms_rpo256_rows(pl.handle, self.n, _ptr_array(self.cols), len(self.cols), out.ptr))
+        return out
+
+
+class GpuRpo256RowMajor:
+    """`GpuRpo256RowMajor` (gpu/src/plan.rs:109-148): rows of 8 Fp elements, one absorb per update."""
+
+    def __init__(self, n, requires_padding=False, planner=None):
+        self.n, self.planner, self.rows = n, planner or get_planner(), None
+
+    def update(self, rows):
+        if len(rows) != self.n * 8:
+            raise ValueError("expected n rows of 8 elements")
+        self.rows = rows
+
+    def finish(self):
+        if self.rows is None:
+            raise ValueError("the zero-length input is not allowed")            # plan.rs:141-146 panic!()
+        pl = self.planner
+        out = GpuVec(pl, self.n * 4, GOLDILOCKS_FP)
+        pl.lib.check(pl.lib.ms_rpo256_rows_row_major(pl.handle, self.n, 8, self.rows.ptr, out.ptr))
+        return out
+
+
+def gen_rpo_merkle_tree(leaves):
+    """`gen_rpo_merkle_tree(leaves: &[[F; 4]])` (gpu/src/plan.rs:150-174) -> GpuVec of n x 4 node elements."""
+    pl = leaves.planner
+    n = len(leaves) // 4
+    nodes = GpuVec(pl, n * 4, GOLDILOCKS_FP)
+    pl.lib.check(pl.lib.ms_rpo256_merkle(pl.handle, n, leaves.ptr, nodes.ptr))
+    return nodes

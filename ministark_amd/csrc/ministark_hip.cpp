@@ -21,6 +21,7 @@
 #include "fri_kernels.h"
 #include "eval_kernels.h"
 #include "fp252_kernels.h"
+#include "rpo_kernels.h"
 
 using msntt::MAXC;
 
@@ -1083,6 +1084,54 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
     if (maxp <= 16 && maxq <= 8) hipLaunchKernelGGL((eval_program<16, 8>), g, dim3(NT), 0, ctx->stream, E);
     else if (maxp <= 64 && maxq <= 32) hipLaunchKernelGGL((eval_program<64, 32>), g, dim3(NT), 0, ctx->stream, E);
     else hipLaunchKernelGGL((eval_program<256, 128>), g, dim3(NT), 0, ctx->stream, E);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// RPO-256 commitments
+// ---------------------------------------------------------------------------------------
+static int rpo_rows(ms_ctx* ctx, size_t nrows, const uint64_t* const* cols, unsigned ncols, unsigned stride, void* d_digests) {
+    if (ncols == 0) return fail(MS_ERR_INVALID, "the zero-length input is not allowed");          // plan.rs:72
+    if (ncols > (unsigned)msrpo::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per commitment", msrpo::MAXCOLS);
+    if (nrows == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    msrpo::RowsParams P;
+    memset(&P, 0, sizeof P);
+    for (unsigned c = 0; c < ncols; c++) P.cols[c] = cols[c];
+    P.digests = (uint64_t*)d_digests; P.nrows = nrows; P.ncols = ncols; P.row_stride = stride;
+    ProfScope ps(ctx, "rpo256_rows", 8.0 * nrows * (ncols + 4));
+    hipLaunchKernelGGL(msrpo::rpo256_rows, dim3((unsigned)((nrows + msrpo::NT - 1) / msrpo::NT)), dim3(msrpo::NT), 0, ctx->stream, P);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_rpo256_rows(ms_ctx* ctx, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_digests) {
+    if (!ctx || !d_cols || !d_digests) return fail(MS_ERR_INVALID, "ms_rpo256_rows: null argument");
+    std::vector<const uint64_t*> cols(ncols);
+    for (unsigned c = 0; c < ncols; c++) cols[c] = (const uint64_t*)d_cols[c];
+    return rpo_rows(ctx, nrows, cols.data(), ncols, 1, d_digests);
+}
+extern "C" int ms_rpo256_rows_row_major(ms_ctx* ctx, size_t nrows, unsigned ncols, const void* d_matrix, void* d_digests) {
+    if (!ctx || !d_matrix || !d_digests) return fail(MS_ERR_INVALID, "ms_rpo256_rows_row_major: null argument");
+    std::vector<const uint64_t*> cols(ncols);
+    for (unsigned c = 0; c < ncols; c++) cols[c] = (const uint64_t*)d_matrix + c;
+    return rpo_rows(ctx, nrows, cols.data(), ncols, ncols, d_digests);
+}
+extern "C" int ms_rpo256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leaves, void* d_nodes) {
+    if (!ctx || !d_leaves || !d_nodes) return fail(MS_ERR_INVALID, "ms_rpo256_merkle: null argument");
+    if (nleaves < 2 || (nleaves & (nleaves - 1))) return fail(MS_ERR_INVALID, "number of leaves must be a power of two >= 2");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t* nodes = (uint64_t*)d_nodes;
+    HIPCHK(hipMemsetAsync(nodes, 0, 32, ctx->stream));
+    const uint64_t* src = (const uint64_t*)d_leaves;
+    for (size_t count = nleaves / 2; count >= 1; count >>= 1) {
+        uint64_t* dst = nodes + count * 4;
+        ProfScope ps(ctx, "rpo256_merkle_level", 96.0 * count);
+        hipLaunchKernelGGL(msrpo::rpo256_merge_level, dim3((unsigned)((count + msrpo::NT - 1) / msrpo::NT)), dim3(msrpo::NT), 0, ctx->stream, src, dst, count);
+        src = dst;
+    }
     HIPCHK(hipGetLastError());
     return MS_OK;
 }

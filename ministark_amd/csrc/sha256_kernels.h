@@ -32,6 +32,18 @@ __device__ static const uint32_t K256[64] = {
     0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
     0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
+// K256[i] + W[i] for the second block of a 64-byte message (0x80, zeros, bit length 512): that
+// block is a constant, so its whole message schedule is folded into the round constants.
+__device__ static const uint32_t KW_PAD64[64] = {
+    0xc28a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf374,
+    0x649b69c1, 0xf0fe4786, 0x0fe1edc6, 0x240cf254, 0x4fe9346f, 0x6cc984be, 0x61b9411e, 0x16f988fa,
+    0xf2c65152, 0xa88e5a6d, 0xb019fc65, 0xb9d99ec7, 0x9a1231c3, 0xe70eeaa0, 0xfdb1232b, 0xc7353eb0,
+    0x3069bad5, 0xcb976d5f, 0x5a0f118f, 0xdc1eeefd, 0x0a35b689, 0xde0b7a04, 0x58f4ca9d, 0xe15d5b16,
+    0x007f3e86, 0x37088980, 0xa507ea32, 0x6fab9537, 0x17406110, 0x0d8cd6f1, 0xcdaa3b6d, 0xc0bbbe37,
+    0x83613bda, 0xdb48a363, 0x0b02e931, 0x6fd15ca7, 0x521afaca, 0x31338431, 0x6ed41a95, 0x6d437890,
+    0xc39c91f2, 0x9eccabbd, 0xb5c9a0e6, 0x532fb63c, 0xd2c741c6, 0x07237ea3, 0xa4954b68, 0x4c191d76,};
+
 __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }   // -> v_alignbit_b32
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }                  // -> v_perm_b32
 
@@ -59,6 +71,21 @@ struct Sha {
             const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
             const uint32_t ch = (e & f) ^ (~e & g);
             const uint32_t t1 = hh + S1 + ch + K256[i] + wi;
+            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+            const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    // compression of the constant padding block that follows a 64-byte message
+    __device__ __forceinline__ void compress_pad64() {
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        #pragma unroll
+        for (int i = 0; i < 64; i++) {
+            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+            const uint32_t ch = (e & f) ^ (~e & g);
+            const uint32_t t1 = hh + S1 + ch + KW_PAD64[i];
             const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
             const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
             const uint32_t t2 = S0 + mj;
@@ -135,11 +162,7 @@ __global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* __restri
         s.w[4 * q] = bswap32(v.x); s.w[4 * q + 1] = bswap32(v.y); s.w[4 * q + 2] = bswap32(v.z); s.w[4 * q + 3] = bswap32(v.w);
     }
     s.compress();
-    s.w[0] = 0x80000000u;
-    #pragma unroll
-    for (int q = 1; q < 15; q++) s.w[q] = 0;
-    s.w[15] = 512;
-    s.compress();
+    s.compress_pad64();
     uint4* out = (uint4*)(dst + i * 32);
     out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
     out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
