@@ -180,6 +180,27 @@ int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const 
 int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
                 const void* h_offset, const void* d_evals, void* d_out);
 
+/* ---- DEEP composition (host-side and sequential in the reference):
+ * DeepPolyComposer::get_ood_evals / into_deep_poly (src/composer.rs:43-188).  `point_field` is Fq
+ * (MS_GOLDILOCKS_FQ3, or MS_GOLDILOCKS_FP for Fq = Fp AIRs); every host array of points / alphas / values
+ * holds elements of point_field (3 or 1 Montgomery words each), packed.
+ * ms_horner_eval   out[q] = P_{qcol[q]}(qpoint[q]) for coefficient-form columns of `coeff_field`
+ *                  (horner_evaluate, src/utils.rs:124-133).  Blocks; results on the host.
+ * ms_deep_compose  coefficients (2^log_n elements of point_field, d_out) of
+ *                      (alpha + beta X) * sum_t alpha_t (P_ct(X) - ood_t) / (X - z_pt)
+ *                  where column ct < nbase is d_base_polys[ct] (Fp) and otherwise d_ext_polys[ct - nbase]
+ *                  (point_field; the caller appends the composition-trace polynomials there), ood_t must be
+ *                  P_ct(z_pt) (from ms_horner_eval).  Equals divide_out_point(s)_into + sum_columns + the
+ *                  degree adjustment of src/composer.rs:89-188, computed through n coset evaluations.
+ *                  h_offset: coset used internally (Fp, NULL = the generator 7).  Asynchronous. */
+int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, size_t n, const void* const* d_cols, unsigned ncols,
+                   const unsigned* h_qcol, const void* h_qpoints, unsigned nq, void* h_out);
+int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, const void* h_offset,
+                    const void* const* d_base_polys, unsigned nbase, const void* const* d_ext_polys, unsigned next,
+                    const void* h_points, unsigned npoints, const unsigned* h_term_col, const unsigned* h_term_point,
+                    const void* h_term_alpha, const void* h_term_ood, unsigned nterms,
+                    const void* h_degree_alpha, const void* h_degree_beta, void* d_out);
+
 /* ---- RPO-256 commitments over Goldilocks Fp: GpuRpo256ColumnMajor / GpuRpo256RowMajor /
  * gen_rpo_merkle_tree (gpu/src/plan.rs:32-174; kernels gpu/src/metal/hash_shaders.h.metal:215-380).
  * Digests are 4 Fp elements (Montgomery form, 32 bytes).

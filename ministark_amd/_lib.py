@@ -65,6 +65,8 @@ class Lib:
             "ms_fri_fold": (i, [vp, i, u, u, vp, vp, vp, vp]),
             "ms_sha256_rows": (i, [vp, i, sz, c_void_pp, u, vp]),
             "ms_sha256_merkle": (i, [vp, sz, vp, vp]),
+            "ms_horner_eval": (i, [vp, i, i, sz, c_void_pp, u, vp, vp, u, vp]),
+            "ms_deep_compose": (i, [vp, i, u, vp, c_void_pp, u, c_void_pp, u, vp, u, vp, vp, vp, vp, u, vp, vp, vp]),
             "ms_rpo256_rows": (i, [vp, sz, c_void_pp, u, vp]),
             "ms_rpo256_rows_row_major": (i, [vp, sz, u, vp, vp]),
             "ms_rpo256_merkle": (i, [vp, sz, vp, vp]),

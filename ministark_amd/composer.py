@@ -1,0 +1,128 @@
+"""`DeepPolyComposer` (src/composer.rs:17-188) over the device entry points ms_horner_eval /
+ms_deep_compose.  Same constructor arguments and method names; polynomials are coefficient-form
+`Matrix` objects on the device (what `interpolate` / `into_polynomials` return)."""
+import ctypes
+
+import numpy as np
+
+from .api import FIELD_WORDS, GOLDILOCKS_FP, GOLDILOCKS_FQ3, GL_P, GpuVec, Radix2EvaluationDomain, gl_from_mont, gl_to_mont
+
+
+def _q_mul_base(q, s):      # Fq element (canonical tuple or int) times canonical Fp scalar
+    return tuple((c * s) % GL_P for c in q) if isinstance(q, tuple) else (q * s) % GL_P
+
+
+def _q_pow(q, e):
+    """Fq3 = Fp[x]/(x^3 - 2) power on canonical tuples (host bookkeeping of points only)."""
+    if not isinstance(q, tuple):
+        return pow(q, e, GL_P)
+
+    def mul(a, b):
+        a0, a1, a2 = a
+        b0, b1, b2 = b
+        return ((a0 * b0 + 2 * (a1 * b2 + a2 * b1)) % GL_P, (a0 * b1 + a1 * b0 + 2 * a2 * b2) % GL_P, (a0 * b2 + a1 * b1 + a2 * b0) % GL_P)
+    r, base = (1, 0, 0), q
+    while e:
+        if e & 1:
+            r = mul(r, base)
+        base = mul(base, base)
+        e >>= 1
+    return r
+
+
+def _words(q):
+    return [gl_to_mont(c) for c in q] if isinstance(q, tuple) else [gl_to_mont(q)]
+
+
+def _from_words(w):
+    return tuple(gl_from_mont(int(x)) for x in w) if len(w) == 3 else gl_from_mont(int(w[0]))
+
+
+class DeepCompositionCoeffs:                      # src/composer.rs:191-198
+    def __init__(self, execution_trace, composition_trace, degree):
+        self.execution_trace, self.composition_trace, self.degree = execution_trace, composition_trace, degree
+
+
+class DeepPolyComposer:
+    """z and all coefficients are canonical Fq values: 3-tuples (Fq3) or ints (Fq = Fp AIRs).
+    trace_arguments: the AIR's list of (column, offset) pairs (air.trace_arguments())."""
+
+    def __init__(self, trace_arguments, trace_len, z, base_trace_polys, extension_trace_polys, composition_trace_polys):
+        self.args = list(trace_arguments)
+        self.z = z
+        self.base = base_trace_polys
+        self.ext = extension_trace_polys
+        self.comp = composition_trace_polys
+        self.n = trace_len
+        self.planner = base_trace_polys.planner
+        self.fq = GOLDILOCKS_FQ3 if isinstance(z, tuple) else GOLDILOCKS_FP
+        d = Radix2EvaluationDomain(trace_len)
+        self.g, self.g_inv = d.group_gen, d.group_gen_inv
+        self.nbase = base_trace_polys.num_cols()
+        self.next = extension_trace_polys.num_cols() if extension_trace_polys is not None else 0
+        self._ood = None
+
+    def _point(self, offset):
+        gen = self.g if offset >= 0 else self.g_inv
+        return _q_mul_base(self.z, pow(gen, abs(offset), GL_P))
+
+    def _horner(self, matrix, field, queries):
+        """queries: list of (column, point) -> list of Fq values."""
+        if not queries:
+            return []
+        pl, L = self.planner, self.planner.lib
+        pw = FIELD_WORDS[self.fq]
+        qcol = (ctypes.c_uint * len(queries))(*[c for c, _ in queries])
+        pts = np.array([w for _, p in queries for w in _words(p)], dtype=np.uint64)
+        out = np.zeros(len(queries) * pw, dtype=np.uint64)
+        arr = (ctypes.c_void_p * matrix.num_cols())(*[c.ptr for c in matrix.columns])
+        L.check(L.ms_horner_eval(pl.handle, field, self.fq, matrix.num_rows(), arr, matrix.num_cols(), qcol, pts.ctypes.data,
+                                 len(queries), out.ctypes.data))
+        return [_from_words(out[pw * i:pw * i + pw]) for i in range(len(queries))]
+
+    def get_ood_evals(self):                      # src/composer.rs:43-86
+        base_q = [(c, self._point(o)) for c, o in self.args if c < self.nbase]
+        ext_q = [(c - self.nbase, self._point(o)) for c, o in self.args if c >= self.nbase]
+        bv, ev = iter(self._horner(self.base, GOLDILOCKS_FP, base_q)), iter(self._horner(self.ext, self.fq, ext_q) if ext_q else [])
+        execution = [next(bv) if c < self.nbase else next(ev) for c, _ in self.args]
+        z_n = _q_pow(self.z, self.comp.num_cols())
+        composition = self._horner(self.comp, self.fq, [(c, z_n) for c in range(self.comp.num_cols())])
+        self._ood = (execution, composition)
+        return execution, composition
+
+    def into_deep_poly(self, coeffs):             # src/composer.rs:89-188
+        if self._ood is None:
+            self.get_ood_evals()
+        execution, composition = self._ood
+        pl, L = self.planner, self.planner.lib
+        pw = FIELD_WORDS[self.fq]
+        points, pindex = [], {}
+
+        def pid(p):
+            if p not in pindex:
+                pindex[p] = len(points)
+                points.append(p)
+            return pindex[p]
+        z_n = _q_pow(self.z, self.comp.num_cols())
+        ext_cols = (list(self.ext.columns) if self.ext is not None else []) + list(self.comp.columns)
+        tcol, tpoint, talpha, tood = [], [], [], []
+        for c in range(self.comp.num_cols()):
+            tcol.append(self.nbase + self.next + c); tpoint.append(pid(z_n)); talpha.append(coeffs.composition_trace[c]); tood.append(composition[c])
+        for (c, o), alpha, val in zip(self.args, coeffs.execution_trace, execution):
+            tcol.append(c); tpoint.append(pid(self._point(o))); talpha.append(alpha); tood.append(val)
+        if self.fq == GOLDILOCKS_FP:
+            base_cols, ext_list = list(self.base.columns) + ext_cols, []      # Fq = Fp: everything is a base column
+        else:
+            base_cols, ext_list = list(self.base.columns), ext_cols
+        VP = ctypes.c_void_p
+        out = GpuVec(pl, self.n, self.fq)
+        flat = lambda qs: np.array([w for q in qs for w in _words(q)], dtype=np.uint64)
+        pts, al, od = flat(points), flat(talpha), flat(tood)
+        da, db = flat([coeffs.degree[0]]), flat([coeffs.degree[1]])
+        L.check(L.ms_deep_compose(pl.handle, self.fq, self.n.bit_length() - 1, None,
+                                  (VP * max(1, len(base_cols)))(*[c.ptr for c in base_cols]), len(base_cols),
+                                  (VP * max(1, len(ext_list)))(*[c.ptr for c in ext_list]), len(ext_list),
+                                  pts.ctypes.data, len(points), (ctypes.c_uint * len(tcol))(*tcol), (ctypes.c_uint * len(tpoint))(*tpoint),
+                                  al.ctypes.data, od.ctypes.data, len(tcol), da.ctypes.data, db.ctypes.data, out.ptr))
+        pl.sync()
+        return out

@@ -1,0 +1,167 @@
+// DEEP composition on device: DeepPolyComposer::{get_ood_evals, into_deep_poly}
+// (src/composer.rs:43-188), which the reference runs on the host, sequentially per column
+// (horner_evaluate src/utils.rs:124-133, divide_out_point(s)_into src/utils.rs:151-175).
+//
+//  * horner_blocks: out-of-domain evaluations P_c(x) for (column, point) queries.  One workgroup per
+//    4096 coefficients and query: each lane runs Horner over 16 consecutive coefficients, the
+//    workgroup combines with powers of x^16 in LDS; the <= n/4096 block values are combined on the host.
+//  * deep_points: the reference builds  Q(X) = sum_t alpha_t (P_ct(X) - P_ct(z_t)) / (X - z_t)  by synthetic
+//    division in coefficient space.  Q has degree <= n-2, so it is determined by its values on any n
+//    points: this kernel evaluates the sum at the n points of the coset offset*<w_n> from coset
+//    evaluations of the P_c (one lane per point, the few 1/(x - z_k) by one batched Fq3 inversion), and
+//    an inverse coset NTT returns exactly the coefficients synthetic division produces (exact field
+//    arithmetic, hence bit-identical).
+//  * deep_degree_adjust: coefficients of Q(X) * (alpha + beta X)  (src/composer.rs:164-185).
+// Points and results live in Fq3 (or in Fp for Fq = Fp AIRs: PW = 1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.h"
+#include "gl_dev.h"
+#include "stage_kernels.h"
+
+namespace msdeep {
+
+static constexpr int NT = 256;
+static constexpr int MAXCOLS = 96;
+static constexpr int MAXPOINTS = 8;
+
+using F1 = msstage::FpT;
+using F3 = msstage::Fq3T;
+
+// element of the point field: PW = 1 (Fp) or 3 (Fq3), stored in 3 words
+struct Q { uint64_t w[3]; };
+template <int PW> __device__ __forceinline__ Q q_zero() { return {{0, 0, 0}}; }
+template <int PW> __device__ __forceinline__ Q q_add(const Q& a, const Q& b) {
+    if constexpr (PW == 1) return {{gl::add(a.w[0], b.w[0]), 0, 0}};
+    else return {{gl::add(a.w[0], b.w[0]), gl::add(a.w[1], b.w[1]), gl::add(a.w[2], b.w[2])}};
+}
+template <int PW> __device__ __forceinline__ Q q_sub(const Q& a, const Q& b) {
+    if constexpr (PW == 1) return {{gl::sub(a.w[0], b.w[0]), 0, 0}};
+    else return {{gl::sub(a.w[0], b.w[0]), gl::sub(a.w[1], b.w[1]), gl::sub(a.w[2], b.w[2])}};
+}
+template <int PW> __device__ __forceinline__ Q q_mul(const Q& a, const Q& b) {
+    if constexpr (PW == 1) return {{gld::mmul(a.w[0], b.w[0]), 0, 0}};
+    else { const gl::Fq3 r = F3::mul({a.w[0], a.w[1], a.w[2]}, {b.w[0], b.w[1], b.w[2]}); return {{r.c0, r.c1, r.c2}}; }
+}
+template <int PW> __device__ __forceinline__ Q q_inv(const Q& a) {
+    if constexpr (PW == 1) return {{F1::inv(a.w[0]), 0, 0}};
+    else { const gl::Fq3 r = F3::inv({a.w[0], a.w[1], a.w[2]}); return {{r.c0, r.c1, r.c2}}; }
+}
+// load a coefficient / evaluation of a CW-word column as an element of the point field
+template <int CW> __device__ __forceinline__ Q q_load(const uint64_t* col, size_t i) {
+    if constexpr (CW == 1) return {{col[i], 0, 0}};
+    else return {{col[3 * i], col[3 * i + 1], col[3 * i + 2]}};
+}
+
+struct HornerParams {
+    const uint64_t* cols[MAXCOLS];
+    const uint32_t* qcol;      // device: column of each query
+    const uint64_t* qpoint;    // device: 3 words per query (Montgomery)
+    uint64_t* partial;         // device: [nq][nblocks][3]
+    size_t n;
+    unsigned nblocks;
+};
+// CW: words per coefficient (1 Fp, 3 Fq3); PW: words of the point field (PW >= CW)
+template <int CW, int PW>
+__global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
+    __shared__ uint64_t sh[NT * 3];
+    const unsigned q = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const uint64_t* col = P.cols[P.qcol[q]];
+    const Q x = {{P.qpoint[3 * q], P.qpoint[3 * q + 1], P.qpoint[3 * q + 2]}};
+    const size_t start = (size_t)b * 4096 + (size_t)t * 16;
+    Q acc = q_zero<PW>();
+    #pragma unroll 4
+    for (int j = 15; j >= 0; j--) {
+        const size_t i = start + j;
+        Q c = q_zero<PW>();
+        if (i < P.n) c = q_load<CW>(col, i);
+        acc = q_add<PW>(q_mul<PW>(acc, x), c);
+    }
+    // combine: value_t * (x^16)^t, pairwise with pw = x^(16 * 2^l)
+    Q pw = x;
+    for (int s = 0; s < 4; s++) pw = q_mul<PW>(pw, pw);
+    for (unsigned l = 0; l < 8; l++) {
+        sh[3 * t] = acc.w[0]; sh[3 * t + 1] = acc.w[1]; sh[3 * t + 2] = acc.w[2];
+        __syncthreads();
+        const unsigned step = 1u << l;
+        if ((t & (2 * step - 1)) == 0) {
+            const Q other = {{sh[3 * (t + step)], sh[3 * (t + step) + 1], sh[3 * (t + step) + 2]}};
+            acc = q_add<PW>(acc, q_mul<PW>(other, pw));
+        }
+        pw = q_mul<PW>(pw, pw);
+        __syncthreads();
+    }
+    if (t == 0) {
+        uint64_t* o = P.partial + ((size_t)q * P.nblocks + b) * 3;
+        o[0] = acc.w[0]; o[1] = acc.w[1]; o[2] = acc.w[2];
+    }
+}
+
+struct Term { uint32_t col, point; uint64_t alpha[3]; uint64_t ood[3]; };   // col: < nbase base, else ext
+struct DeepParams {
+    const uint64_t* base[MAXCOLS];     // coset evaluations, natural order, n x Fp
+    const uint64_t* ext[MAXCOLS];      //                                  n x Fq3
+    const Term* terms;                 // device
+    const uint64_t* tw_lo;             // w_n^i two-level table (Montgomery)
+    const uint64_t* tw_hi;
+    uint64_t points[MAXPOINTS][3];
+    uint64_t* out;                     // n x PW words
+    uint64_t h_mont;
+    size_t n;
+    unsigned nbase, nterms, npoints, lo_bits, xshift;
+};
+template <int PW>
+__global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= P.n) return;
+    const size_t e = i << P.xshift;
+    uint64_t xs = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+    if (e >> P.lo_bits) xs = gld::mmul(xs, P.tw_hi[e >> P.lo_bits]);
+    xs = gld::mmul(xs, P.h_mont);
+    const Q x = {{xs, 0, 0}};
+    // 1 / (x - z_k) for every point: one inversion (Montgomery's trick)
+    Q d[MAXPOINTS], pre[MAXPOINTS];
+    Q run = {{gl::ONE_MONT, 0, 0}};
+    #pragma unroll
+    for (int k = 0; k < MAXPOINTS; k++) if (k < (int)P.npoints) {
+        d[k] = q_sub<PW>(x, Q{{P.points[k][0], P.points[k][1], P.points[k][2]}});
+        pre[k] = run;
+        run = q_mul<PW>(run, d[k]);
+    }
+    Q inv = q_inv<PW>(run);
+    #pragma unroll
+    for (int k = MAXPOINTS - 1; k >= 0; k--) if (k < (int)P.npoints) {
+        const Q dk = d[k];
+        d[k] = q_mul<PW>(inv, pre[k]);        // now 1 / (x - z_k)
+        inv = q_mul<PW>(inv, dk);
+    }
+    Q acc = q_zero<PW>();
+    for (unsigned t = 0; t < P.nterms; t++) {
+        const Term T = P.terms[t];
+        Q v;
+        if (T.col < P.nbase) v = q_load<1>(P.base[T.col], i);
+        else { if constexpr (PW == 3) v = q_load<3>(P.ext[T.col - P.nbase], i); else v = q_zero<PW>(); }
+        v = q_sub<PW>(v, Q{{T.ood[0], T.ood[1], T.ood[2]}});
+        Q dk = d[0];
+        #pragma unroll
+        for (int k = 1; k < MAXPOINTS; k++) if ((int)T.point == k) dk = d[k];
+        acc = q_add<PW>(acc, q_mul<PW>(q_mul<PW>(v, dk), Q{{T.alpha[0], T.alpha[1], T.alpha[2]}}));
+    }
+    #pragma unroll
+    for (int w = 0; w < PW; w++) P.out[PW * i + w] = acc.w[w];
+}
+
+// out_i = alpha * c_i + beta * c_(i-1)   (c_-1 = 0), in place over a separate copy
+template <int PW>
+__global__ void __launch_bounds__(NT) deep_degree_adjust(uint64_t* dst, const uint64_t* src, size_t n, Q alpha, Q beta) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    Q c = q_zero<PW>(), prev = q_zero<PW>();
+    #pragma unroll
+    for (int w = 0; w < PW; w++) { c.w[w] = src[PW * i + w]; if (i) prev.w[w] = src[PW * (i - 1) + w]; }
+    const Q r = q_add<PW>(q_mul<PW>(c, alpha), q_mul<PW>(prev, beta));
+    #pragma unroll
+    for (int w = 0; w < PW; w++) dst[PW * i + w] = r.w[w];
+}
+
+}  // namespace msdeep

@@ -1,0 +1,78 @@
+"""DEEP composition on device vs the oracle's literal restatement of src/composer.rs (synthetic
+division per column, sum, degree adjustment), bit-exact; Horner OOD evaluations likewise."""
+import numpy as np
+import pytest
+
+from oracle.pyref import deep as pydeep
+from oracle.pyref.fields import GL
+from tests import backends
+from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3, Matrix, Radix2EvaluationDomain
+from ministark_amd.composer import DeepCompositionCoeffs, DeepPolyComposer
+
+P = GL.p
+KINDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _rq(rng, ext):
+    v = tuple(int(x) for x in rng.integers(0, P, size=3, dtype=np.uint64))
+    return v if ext else v[0]
+
+
+def _mat(pl, cols, field):
+    arrs = []
+    for c in cols:
+        flat = [w for e in c for w in (e if isinstance(e, tuple) else (e,))]
+        arrs.append(np.array([GL.to_mont(x) for x in flat], dtype=np.uint64))
+    return Matrix.from_numpy(pl, arrs, field)
+
+
+def _canon_col(vec, ext):
+    a = [GL.from_mont(int(x)) for x in vec.to_numpy()]
+    return [tuple(a[3 * i:3 * i + 3]) for i in range(len(a) // 3)] if ext else a
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("log_n,ext,beta_zero", [(6, True, False), (8, True, True), (7, False, False), (13, True, False)])
+def test_deep_matches_composer(kind, log_n, ext, beta_zero):
+    if kind == "emu" and log_n > 8:
+        pytest.skip("kept short under the simulator")
+    pl = backends.planner(kind)
+    rng = np.random.default_rng(log_n + ext)
+    n = 1 << log_n
+    nbase, next_, ncomp = 3, (2 if ext else 0), 2
+    base = [[int(x) for x in rng.integers(0, P, size=n, dtype=np.uint64)] for _ in range(nbase)]
+    extp = [[_rq(rng, True) for _ in range(n)] for _ in range(next_)]
+    comp = [[_rq(rng, ext) for _ in range(n)] for _ in range(ncomp)]
+    args = [(0, 0), (0, 1), (1, 0), (2, 1), (2, -1)] + ([(3, 0), (4, 1), (3, 1)] if ext else [])
+    z = _rq(rng, ext)
+    d = Radix2EvaluationDomain(n)
+    g, g_inv = d.group_gen, d.group_gen_inv
+    comp_field = FQ3 if ext else FP
+    composer = DeepPolyComposer(args, n, z, _mat(pl, base, FP), _mat(pl, extp, FQ3) if ext else None, _mat(pl, comp, comp_field))
+    got_exec, got_comp = composer.get_ood_evals()
+    want_exec, want_comp = pydeep.get_ood_evals(z, g, g_inv, args, base, extp, comp)
+    assert got_exec == want_exec and got_comp == want_comp
+    ea = [_rq(rng, ext) for _ in args]
+    ca = [_rq(rng, ext) for _ in range(ncomp)]
+    zero = (0, 0, 0) if ext else 0
+    degree = (_rq(rng, ext), zero if beta_zero else _rq(rng, ext))
+    out = composer.into_deep_poly(DeepCompositionCoeffs(ea, ca, degree))
+    want = pydeep.into_deep_poly(z, g, g_inv, args, base, extp, comp, ea, ca, degree)
+    assert _canon_col(out, ext) == want
+
+
+@pytest.mark.gpu
+def test_horner_large_hip():
+    # 2^20 coefficients: multi-block reduction + host combine
+    pl = backends.planner("hip")
+    rng = np.random.default_rng(1)
+    n = 1 << 20
+    col = rng.integers(0, P, size=n, dtype=np.uint64)
+    m = Matrix.from_numpy(pl, [col], FP)
+    z = _rq(rng, True)
+    comp = DeepPolyComposer([(0, 0), (0, 1)], n, z, m, None, m)
+    ex, _ = comp.get_ood_evals()
+    canon = [GL.from_mont(int(x)) for x in col]
+    d = Radix2EvaluationDomain(n)
+    assert ex[0] == pydeep.horner_evaluate(canon, z)
+    assert ex[1] == pydeep.horner_evaluate(canon, pydeep.point_for(z, d.group_gen, d.group_gen_inv, 1))
