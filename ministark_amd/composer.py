@@ -70,6 +70,8 @@ class DeepPolyComposer:
         """queries: list of (column, point) -> list of Fq values."""
         if not queries:
             return []
+        if matrix.field != field:
+            raise ValueError("polynomial matrix is not over the expected field")
         pl, L = self.planner, self.planner.lib
         pw = FIELD_WORDS[self.fq]
         qcol = (ctypes.c_uint * len(queries))(*[c for c, _ in queries])

@@ -70,8 +70,11 @@ def test_horner_large_hip():
     col = rng.integers(0, P, size=n, dtype=np.uint64)
     m = Matrix.from_numpy(pl, [col], FP)
     z = _rq(rng, True)
-    comp = DeepPolyComposer([(0, 0), (0, 1)], n, z, m, None, m)
-    ex, _ = comp.get_ood_evals()
+    cq = rng.integers(0, P, size=3 * 4096, dtype=np.uint64)
+    comp = DeepPolyComposer([(0, 0), (0, 1)], n, z, m, None, Matrix.from_numpy(pl, [cq], FQ3))
+    ex, cv = comp.get_ood_evals()
+    cc = [GL.from_mont(int(x)) for x in cq]
+    assert cv[0] == pydeep.horner_evaluate([tuple(cc[3 * i:3 * i + 3]) for i in range(4096)], z)
     canon = [GL.from_mont(int(x)) for x in col]
     d = Radix2EvaluationDomain(n)
     assert ex[0] == pydeep.horner_evaluate(canon, z)
