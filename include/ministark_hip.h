@@ -201,6 +201,13 @@ int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, const void* h_
                     const void* h_term_alpha, const void* h_term_ood, unsigned nterms,
                     const void* h_degree_alpha, const void* h_degree_beta, void* d_out);
 
+/* ---- proof-of-work grinding: PublicCoin::grind_proof_of_work with Sha256HashFn
+ * (src/random.rs:48-58,129-132; src/hash.rs:84-89): *nonce = the smallest n >= 1 such that
+ * SHA-256(seed32 || n as 8 big-endian bytes) has at least `bits` leading zero bits (what the reference's
+ * sequential search returns; its rayon path returns any valid nonce).  Blocks.  MS_ERR_INVALID if
+ * bits > 64 or no nonce exists below max_nonce. */
+int ms_sha256_pow_grind(ms_ctx* ctx, const void* h_seed32, unsigned bits, uint64_t max_nonce, uint64_t* nonce);
+
 /* ---- RPO-256 commitments over Goldilocks Fp: GpuRpo256ColumnMajor / GpuRpo256RowMajor /
  * gen_rpo_merkle_tree (gpu/src/plan.rs:32-174; kernels gpu/src/metal/hash_shaders.h.metal:215-380).
  * Digests are 4 Fp elements (Montgomery form, 32 bytes).

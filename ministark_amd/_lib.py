@@ -67,6 +67,7 @@ class Lib:
             "ms_sha256_merkle": (i, [vp, sz, vp, vp]),
             "ms_horner_eval": (i, [vp, i, i, sz, c_void_pp, u, vp, vp, u, vp]),
             "ms_deep_compose": (i, [vp, i, u, vp, c_void_pp, u, c_void_pp, u, vp, u, vp, vp, vp, vp, u, vp, vp, vp]),
+            "ms_sha256_pow_grind": (i, [vp, vp, u, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
             "ms_rpo256_rows": (i, [vp, sz, c_void_pp, u, vp]),
             "ms_rpo256_rows_row_major": (i, [vp, sz, u, vp, vp]),
             "ms_rpo256_merkle": (i, [vp, sz, vp, vp]),

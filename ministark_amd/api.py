@@ -498,3 +498,14 @@ def gen_rpo_merkle_tree(leaves):
     nodes = GpuVec(pl, n * 4, GOLDILOCKS_FP)
     pl.lib.check(pl.lib.ms_rpo256_merkle(pl.handle, n, leaves.ptr, nodes.ptr))
     return nodes
+
+
+def grind_proof_of_work(planner, seed, proof_of_work_bits, max_nonce=(1 << 40)):
+    """`PublicCoin::grind_proof_of_work(bits)` (src/random.rs:48-55): the smallest nonce >= 1 whose
+    SHA-256(seed || nonce_be) has `bits` leading zero bits.  seed: 32 bytes."""
+    seed = bytes(seed)
+    assert len(seed) == 32
+    out = ctypes.c_uint64(0)
+    buf = ctypes.create_string_buffer(seed, 32)
+    planner.lib.check(planner.lib.ms_sha256_pow_grind(planner.handle, buf, proof_of_work_bits, max_nonce, ctypes.byref(out)))
+    return out.value

@@ -1278,3 +1278,41 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
     ms_free(ctx, d_terms); ms_free(ctx, d_q);
     return MS_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// proof-of-work grinding
+// ---------------------------------------------------------------------------------------
+extern "C" int ms_sha256_pow_grind(ms_ctx* ctx, const void* h_seed32, unsigned bits, uint64_t max_nonce, uint64_t* nonce) {
+    if (!ctx || !h_seed32 || !nonce) return fail(MS_ERR_INVALID, "ms_sha256_pow_grind: null argument");
+    if (bits > 64) return fail(MS_ERR_INVALID, "proof-of-work bits must be <= 64");
+    void* d_found = nullptr;
+    MSCHK(ms_alloc(ctx, 8, &d_found));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    mssha::PowParams P;
+    const uint8_t* sb = (const uint8_t*)h_seed32;
+    for (int q = 0; q < 8; q++) P.seed[q] = ((uint32_t)sb[4 * q] << 24) | ((uint32_t)sb[4 * q + 1] << 16) | ((uint32_t)sb[4 * q + 2] << 8) | sb[4 * q + 3];
+    P.bits = bits; P.found = (unsigned long long*)d_found;
+    unsigned long long window = 1ull << 12;             // grows to 2^24 nonces per launch
+    unsigned long long none = ~0ull, found = ~0ull;
+    int rc = MS_OK;
+    for (unsigned long long base = 1; base <= max_nonce && rc == MS_OK; base += P.count, window = std::min(window * 4, 1ull << 24)) {
+        P.base = base; P.count = std::min<unsigned long long>(window, max_nonce - base + 1);
+        if (hipMemcpyAsync(d_found, &none, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = fail(MS_ERR_HIP, "pow: memcpy"); break; }
+        {
+            ProfScope ps(ctx, "sha256_pow_grind", 0.0);
+            hipLaunchKernelGGL(mssha::sha256_pow_grind, dim3((unsigned)((P.count + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, P);
+        }
+        if (hipMemcpyAsync(&found, d_found, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail(MS_ERR_HIP, "pow: readback"); break; }
+        if (found != none) break;
+    }
+    // d_found goes back to the pool (cannot call ms_free here: it takes the same mutex)
+    {
+        auto it = ctx->live.find(d_found);
+        if (it != ctx->live.end()) { ctx->pool.insert({it->second, d_found}); ctx->pool_bytes += it->second; ctx->live.erase(it); }
+    }
+    if (rc != MS_OK) return rc;
+    if (found == none) return fail(MS_ERR_INVALID, "no nonce below %llu has %u leading zero bits", (unsigned long long)max_nonce, bits);
+    *nonce = found;
+    return MS_OK;
+}

@@ -168,4 +168,35 @@ __global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* __restri
     out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
 }
 
+// Proof-of-work grinding: PublicCoin::grind_proof_of_work (src/random.rs:48-55)
+// = the smallest nonce >= 1 with leading_zeros(SHA-256(seed || nonce.to_be_bytes())) >= bits
+// (verify_proof_of_work src/random.rs:129-132, merge_with_int src/hash.rs:84-89, leading_zeros :181-192).
+// One nonce per lane over a window [base, base + count); the minimum hit is kept with atomicMin.
+// The 40-byte message is one block: seed words are loaded once (wave-uniform).
+struct PowParams { uint32_t seed[8]; unsigned long long base; unsigned long long count; unsigned bits; unsigned long long* found; };
+__global__ void __launch_bounds__(NT) sha256_pow_grind(PowParams P) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * NT + threadIdx.x;
+    if (i >= P.count) return;
+    const unsigned long long nonce = P.base + i;
+    Sha s;
+    s.init();
+    #pragma unroll
+    for (int q = 0; q < 8; q++) s.w[q] = P.seed[q];
+    s.w[8] = (uint32_t)(nonce >> 32); s.w[9] = (uint32_t)nonce;       // big-endian u64
+    s.w[10] = 0x80000000u; s.w[11] = 0; s.w[12] = 0; s.w[13] = 0; s.w[14] = 0; s.w[15] = 320;
+    s.compress();
+    // leading zero bits of the big-endian digest
+    unsigned lz = 0;
+    bool done = false;
+    #pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (!done) {
+            const unsigned z = s.h[q] ? (unsigned)__clz(s.h[q]) : 32u;
+            lz += z;
+            if (z != 32) done = true;
+        }
+    }
+    if (lz >= P.bits) atomicMin(P.found, nonce);
+}
+
 }  // namespace mssha

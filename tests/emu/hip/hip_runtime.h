@@ -96,6 +96,8 @@ static inline unsigned __brev(unsigned x) {
     x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
     return (x >> 16) | (x << 16);
 }
+static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+static inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 static inline unsigned long long __brevll(unsigned long long x) {
     return ((unsigned long long)__brev((unsigned)x) << 32) | __brev((unsigned)(x >> 32));
 }

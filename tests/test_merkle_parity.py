@@ -91,3 +91,29 @@ def test_clone_is_device_side_emu():
     v = GpuVec.from_numpy(pl, a)
     w = v.clone()
     assert w.ptr != v.ptr and np.array_equal(w.to_numpy(), a)
+
+
+def _lz(d):
+    z = 0
+    for b in d:
+        if b == 0:
+            z += 8
+            continue
+        z += 8 - b.bit_length()
+        break
+    return z
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_pow_grind_matches_sequential_search(kind):          # src/random.rs:48-55, 129-132
+    from ministark_amd import grind_proof_of_work
+    pl = backends.planner(kind)
+    bits = 20 if kind == "hip" else 9
+    for s in range(3):
+        seed = hashlib.sha256(bytes([s])).digest()
+        got = grind_proof_of_work(pl, seed, bits, 1 << 32)
+        nonce = 1
+        while _lz(hashlib.sha256(seed + nonce.to_bytes(8, "big")).digest()) < bits:
+            nonce += 1
+        assert got == nonce
+    assert grind_proof_of_work(pl, seed, 0) == 1
