@@ -106,6 +106,40 @@ def test_many_columns_hip():
     _run("hip", GOLDILOCKS_FP, 16, False, 7, ncols=37)   # more than one launch group
 
 
+def _adversarial(n, V, kind):
+    P = cref.GL_P
+    edge = np.array([0, 1, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - (1 << 32), (1 << 63), (1 << 63) - 1,
+                     0xFFFFFFFE00000001, 0xFFFFFFFEFFFFFFFF, 0x00000000FFFFFFFE, 0xFFFFFFFF00000000], dtype=np.uint64)
+    if kind == 0:
+        return np.full(n * V, P - 1, dtype=np.uint64)
+    if kind == 1:
+        a = np.zeros(n * V, dtype=np.uint64); a[::2] = P - 1
+        return a
+    if kind == 2:
+        return edge[np.arange(n * V) % edge.size]
+    rng = np.random.default_rng(9)
+    a = edge[rng.integers(0, edge.size, size=n * V)]
+    return a
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("pattern", [0, 1, 2, 3])
+def test_adversarial_values(kind, pattern):
+    # carries / borrows / p-1 everywhere: the lazy ("weak") arithmetic must still land on canonical results
+    pl = backends.planner(kind)
+    for log_n, V, inverse, offset in ((13, 1, False, 7), (12, 3, True, 7), (16 if kind == "hip" else 12, 1, True, 1), (17 if kind == "hip" else 13, 1, False, 1)):
+        n = 1 << log_n
+        field = GOLDILOCKS_FQ3 if V == 3 else GOLDILOCKS_FP
+        x = _adversarial(n, V, pattern)
+        v = GpuVec.from_numpy(pl, x, field)
+        plan = (GpuIfft if inverse else GpuFft)(Radix2EvaluationDomain(n, offset), field, pl)
+        plan.encode(v); plan.execute()
+        assert np.array_equal(v.to_numpy(), cref.ntt(x, log_n, V, inverse, offset)), (log_n, V, inverse, offset)
+    c = _adversarial(1 << 12, 1, pattern)
+    out = Matrix.from_numpy(pl, [c]).lde(8, 7, True).to_numpy()[0]
+    assert np.array_equal(out, cref.lde(c, 12, 3, 1, 7, True))
+
+
 @pytest.mark.gpu
 def test_four_pass_sizes_hip():
     # 2^25 and beyond take four passes (256 x ...): checked against the oracle at 2^25, round trip at 2^27
@@ -134,6 +168,57 @@ def test_roundtrip_2_24_hip():
     assert not np.array_equal(x, y)
     g = GpuIfft(dom, GOLDILOCKS_FP, pl); g.encode(v); g.execute()
     assert np.array_equal(v.to_numpy(), x)
+
+
+@pytest.mark.gpu
+def test_linearity_and_evaluation_2_24_hip():
+    # size-independent properties at BASELINE's full size: NTT(a + c*b) = NTT(a) + c*NTT(b), and the
+    # transform is polynomial evaluation: y[k] = sum_j a_j (h w^k)^j checked at a few k by Horner on the host
+    from ministark_amd import stages as S
+    pl = backends.planner("hip")
+    log_n, n = 24, 1 << 24
+    a, b = _rand(n, 1), _rand(n, 2)
+    c = _rand(1, 3)
+    dom = Radix2EvaluationDomain(n, 7)
+    A, B = GpuVec.from_numpy(pl, a), GpuVec.from_numpy(pl, b)
+    Cmb = GpuVec(pl, n)
+    S.MulIntoConstStage(pl, n, GOLDILOCKS_FP).encode(Cmb, B, c)
+    S.AddAssignStage(pl, n, GOLDILOCKS_FP).encode(Cmb, A)            # a + c*b
+    f = GpuFft(dom, GOLDILOCKS_FP, pl)
+    for v in (A, B, Cmb):
+        f.encode(v)
+    f.execute()
+    S.MulAssignConstStage(pl, n, GOLDILOCKS_FP).encode(B, c)
+    S.AddAssignStage(pl, n, GOLDILOCKS_FP).encode(B, A)              # NTT(a) + c*NTT(b)
+    assert np.array_equal(B.to_numpy(), Cmb.to_numpy())
+    ya = A.to_numpy()
+    P = cref.GL_P
+    Rinv = pow((1 << 64) % P, -1, P)
+    w = pow(1753635133440165772, 1 << (32 - log_n), P)
+    L = cref.lib()
+    for k in (0, 1, 12345, n - 1):
+        x = (7 * pow(w, k, P)) % P
+        xm = (x * ((1 << 64) % P)) % P
+        acc = 0
+        # Horner in Montgomery form through the C oracle's scalar ops (fast enough for 2^24 terms x 4 points)
+        acc = int(_horner_mont(a, xm))
+        assert acc == int(ya[k]), k
+
+
+def _horner_mont(coeffs, x_mont):
+    """sum_j coeffs[j] * x^j with Montgomery words, vectorised by splitting into 2^12 blocks."""
+    P = cref.GL_P
+    R = (1 << 64) % P
+    Rinv = pow(R, -1, P)
+    x = (int(x_mont) * Rinv) % P
+    blk = 1 << 12
+    xs = np.array([pow(x, j, P) for j in range(blk)], dtype=object)
+    acc, xb, cur = 0, pow(x, blk, P), 1
+    for s in range(0, len(coeffs), blk):
+        part = int(np.dot(coeffs[s:s + blk].astype(object), xs) % P)
+        acc = (acc + part * cur) % P
+        cur = (cur * xb) % P
+    return acc          # coefficients are Montgomery words: sum (c_j R) x^j = (P(x)) R
 
 
 # --- bit reversal ------------------------------------------------------------------------
