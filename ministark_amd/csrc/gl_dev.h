@@ -41,6 +41,15 @@ MS_HD uint32_t subc(uint32_t a, uint32_t b, uint32_t bin, uint32_t* bout) {
 }
 #endif
 
+// Scheduling fence for one 32-bit value: the compiler may not move anything that depends on the result
+// above this point (used to keep table loads of a later phase from being hoisted over an LDS exchange,
+// where they would only pin registers).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+#else
+MS_HD unsigned opaque(unsigned x) { asm volatile("" : "+r"(x)); return x; }
+#endif
+
 // Montgomery product (felt_u64.h.metal:165-177 restated on limbs):
 //   s = xl + (xl << 32); b = s - (s >> 32) - carry; r = xh - b; if borrow r += p
 MS_HD uint64_t mmul(uint64_t a, uint64_t bm) {

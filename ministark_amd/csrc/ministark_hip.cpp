@@ -793,7 +793,11 @@ extern "C" int ms_binary(ms_ctx* ctx, int op, int lf, int rf, size_t n, void* d_
     dim3 g(stream_grid(n)), b(msstage::NT);
     ProfScope ps(ctx, op == MS_ADD ? "stage_add" : "stage_mul", 8.0 * n * (2 * VL + VR));
     using namespace msstage;
-    if (VL == 4) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fp252T, Fp252T, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fp252T, Fp252T, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
+    if (VL == 3 && VR == 3 && op == MS_ADD) {
+        // component-wise: an Fq3 + Fq3 column add is an Fp add over 3n consecutive words (fully coalesced)
+        hipLaunchKernelGGL((k_binary<FpT, FpT, 0>), dim3(stream_grid(3 * n)), b, 0, ctx->stream, dst, l, r, 3 * n, 3 * sh);
+    }
+    else if (VL == 4) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fp252T, Fp252T, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fp252T, Fp252T, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
     else if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
     else if (VR == 3) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fq3T, Fq3T, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fq3T, Fq3T, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
     else { if (op == MS_ADD) hipLaunchKernelGGL((k_binary<Fq3T, FpT, 0>), g, b, 0, ctx->stream, dst, l, r, n, sh); else hipLaunchKernelGGL((k_binary<Fq3T, FpT, 1>), g, b, 0, ctx->stream, dst, l, r, n, sh); }
@@ -814,7 +818,11 @@ extern "C" int ms_binary_const(ms_ctx* ctx, int op, int lf, int rf, size_t n, vo
     dim3 g(stream_grid(n)), b(msstage::NT);
     ProfScope ps(ctx, op == MS_ADD ? "stage_add_const" : "stage_mul_const", 16.0 * n * VL);
     using namespace msstage;
-    if (VL == 4) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fp252T, Fp252T, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fp252T, Fp252T, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
+    if (VL == 3 && VR == 1 && op == MS_MUL) {
+        // scaling an Fq3 column by an Fp constant acts on every word alike
+        hipLaunchKernelGGL((k_binary_const<FpT, FpT, 1>), dim3(stream_grid(3 * n)), b, 0, ctx->stream, dst, l, c, 3 * n);
+    }
+    else if (VL == 4) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fp252T, Fp252T, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fp252T, Fp252T, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
     else if (VL == 1) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<FpT, FpT, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<FpT, FpT, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
     else if (VR == 3) { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fq3T, Fq3T, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fq3T, Fq3T, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
     else { if (op == MS_ADD) hipLaunchKernelGGL((k_binary_const<Fq3T, FpT, 0>), g, b, 0, ctx->stream, dst, l, c, n); else hipLaunchKernelGGL((k_binary_const<Fq3T, FpT, 1>), g, b, 0, ctx->stream, dst, l, c, n); }
@@ -861,7 +869,7 @@ extern "C" int ms_unary(ms_ctx* ctx, int op, int field, size_t n, void* d_dst, c
         else if (op == MS_INV) hipLaunchKernelGGL((k_unary<FpT, 1>), g, b, 0, ctx->stream, dst, src, n, exponent);
         else hipLaunchKernelGGL((k_unary<FpT, 2>), g, b, 0, ctx->stream, dst, src, n, exponent);
     } else {
-        if (op == MS_NEG) hipLaunchKernelGGL((k_unary<Fq3T, 0>), g, b, 0, ctx->stream, dst, src, n, exponent);
+        if (op == MS_NEG) hipLaunchKernelGGL((k_unary<FpT, 0>), dim3(stream_grid(3 * n)), b, 0, ctx->stream, dst, src, 3 * n, exponent);   // component-wise
         else if (op == MS_INV) hipLaunchKernelGGL((k_unary<Fq3T, 1>), g, b, 0, ctx->stream, dst, src, n, exponent);
         else hipLaunchKernelGGL((k_unary<Fq3T, 2>), g, b, 0, ctx->stream, dst, src, n, exponent);
     }

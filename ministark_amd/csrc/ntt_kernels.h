@@ -37,7 +37,10 @@ namespace msntt {
 static constexpr int MAXC = 16;        // columns per launch (grid.y)
 static constexpr int TILE = 4096;      // words per workgroup tile
 static constexpr int NT = 256;         // threads per workgroup
-static constexpr int LDS_PAD_CS = 272; // c-stride (words) of the mid-pass exchange layout
+static constexpr int LDS_PAD_CS = 144; // c-stride (words) of the mid-pass exchange layout (half tile + 16)
+#ifndef MS_NTT_WAVES
+#define MS_NTT_WAVES 8                 // resident waves per SIMD the pass kernels are register-allocated for
+#endif
 
 struct DigitField { unsigned in_shift, out_shift, mask; };
 
@@ -86,10 +89,14 @@ __device__ __forceinline__ unsigned digit_rev(const PassParams& P, unsigned x) {
 // grid = (n*V/256/16, columns).  COSET: input scaled by h^j (offset != 1, forward).
 // NA: 16 = dense input; 1 / 2 / 4 = only rows j1 < 16*NA are non-zero (LDE blow-up 16 / 8 / 4): the
 // zero rows are neither loaded nor multiplied and the first network collapses (gld::dft16_pruned).
+// The LDS exchange runs in two rounds through one 16 KiB buffer (waves 0-1 publish their half of the
+// tile, everybody reads; then waves 2-3): half the footprint of a one-shot exchange, so that 8
+// workgroups (the VGPR limit) are resident per CU to cover the global-load latency.
 template <bool INV, bool COSET, int NA = 16>
-__global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
+__global__ void __launch_bounds__(NT, INV ? MS_NTT_WAVES - 1 : MS_NTT_WAVES) ntt_first_pass(PassParams P) {
     const unsigned V = P.V;
-    __shared__ uint64_t lds[TILE];
+    __shared__ uint64_t lds[TILE / 2];
+    uint64_t y[16];
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
     uint64_t* __restrict__ dst = P.dst[blockIdx.y];
     const unsigned tid = threadIdx.x;
@@ -121,18 +128,38 @@ __global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
         // internal twiddle w_256^(b c) (also canonicalises: wr[0] = 1), then exchange so that
         // thread (c, t) gets all b
         #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const uint64_t y = gld::mmul(x[c], P.wr[(b * c) & 255]);
-            lds[t * 256 + (((b << 4) | c) ^ (t | ((t & 1) << 4)))] = y;
+        for (int c = 0; c < 16; c++) x[c] = gld::mmul(x[c], P.wr[(b * c) & 255]);
+        // word (t, b & 7, c) of the half tile sits at  (t*128 + (b & 7)*16 + c) ^ (t | (t & 1) << 4):
+        // conflict-free for the (t, b)-major 64-bit writes and the (c, t)-major reads.  The write
+        // address is A ^ c (re-derived per round, one v_xor each, instead of 16 pinned registers),
+        // the read address one of two bases plus an immediate.
+        const unsigned c2 = tid & 15, t2 = tid >> 4;
+        const unsigned A = (t * 128 + ((b & 7) << 4)) ^ (t | ((t & 1) << 4));
+        const unsigned Rb = (t2 * 128 + c2) ^ (t2 | ((t2 & 1) << 4));
+        const uint64_t* rd0 = lds + Rb;            // even rows bb
+        const uint64_t* rd1 = lds + (Rb ^ 16);     // odd rows
+        if (b < 8) {                                         // wave-uniform: waves 0-1
+            const unsigned A0 = gld::opaque(A);
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[A0 ^ c] = x[c];
         }
+        __syncthreads();
+        #pragma unroll
+        for (int bb = 0; bb < 8; bb++) y[bb] = (bb & 1) ? rd1[(bb & ~1) << 4] : rd0[bb << 4];
+        __syncthreads();
+        if (b >= 8) {
+            const unsigned A1 = gld::opaque(A);
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[A1 ^ c] = x[c];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int bb = 0; bb < 8; bb++) y[8 + bb] = (bb & 1) ? rd1[(bb & ~1) << 4] : rd0[bb << 4];
     }
-    __syncthreads();
     // phase 2: thread (c, t) owns b = 0..15 -> outputs k1 = c + 16 d
     {
-        const unsigned c = tid & 15, t = tid >> 4;
-        uint64_t y[16];
-        #pragma unroll
-        for (int b = 0; b < 16; b++) y[b] = lds[t * 256 + (((b << 4) | c) ^ (t | ((t & 1) << 4)))];
+        const unsigned tid2 = gld::opaque(tid);              // keep the twiddle loads below the exchange
+        const unsigned c = tid2 & 15, t = tid2 >> 4;
         gld::dft_lazy<16, INV>(y);
         const size_t w = w0 + t;
         const unsigned jp = (unsigned)(w / V), v = (unsigned)(w % V);
@@ -157,12 +184,14 @@ __global__ void __launch_bounds__(NT) ntt_first_pass(PassParams P) {
 // (src/matrix.rs:352-354) fused into the transform: the tile is transposed through LDS so that
 // each wave still writes runs of R consecutive elements.
 template <int RB, bool INV, bool LAST, int SCALE, bool BITREV = false>
-__global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
+__global__ void __launch_bounds__(NT, SCALE == 2 ? 5 : MS_NTT_WAVES) ntt_mid_pass(PassParams P) {   // SCALE 2 carries a table walk per output
     constexpr int R = 16 * RB, T = 256 / RB, G = 16 / RB;
     constexpr int LOGR = (RB == 1) ? 4 : (RB == 2) ? 5 : (RB == 4) ? 6 : (RB == 8) ? 7 : 8;
     static_assert(!BITREV || LAST, "bit-reversed store only exists for the last pass");
     const unsigned V = P.V;
-    __shared__ uint64_t lds[16 * LDS_PAD_CS];
+    // exchange in two rounds of half a tile (see ntt_first_pass); the bit-reversed store transposes a whole tile
+    constexpr int LDS_WORDS = BITREV ? T * (R + 1) : 16 * LDS_PAD_CS;
+    __shared__ uint64_t lds[LDS_WORDS];
     __shared__ uint64_t twl[R];
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
     uint64_t* __restrict__ dst = P.dst[blockIdx.y];
@@ -197,23 +226,39 @@ __global__ void __launch_bounds__(NT) ntt_mid_pass(PassParams P) {
             for (int a = 0; a < 16; a++) x[a] = src[base + (size_t)(a * RB + b) * sw + t];
             gld::dft_lazy<16, INV>(x);
             #pragma unroll
-            for (int c = 0; c < 16; c++)
-                lds[c * LDS_PAD_CS + b * T + t] = gld::mmul(x[c], P.wr[(b * c) & (R - 1)]);
-        }
-        __syncthreads();
-        {
-            const unsigned t = tid % T, cl = tid / T;
+            for (int c = 0; c < 16; c++) x[c] = gld::mmul(x[c], P.wr[(b * c) & (R - 1)]);
+            // rows b < RB/2 live in threads 0..127 (waves 0-1): b * T + t = tid
+            const unsigned t2 = tid % T, cl = tid / T;
+            constexpr int HB = RB / 2;
+            if (tid < 128) {
+                #pragma unroll
+                for (int c = 0; c < 16; c++) lds[c * LDS_PAD_CS + tid] = x[c];
+            }
+            __syncthreads();
             #pragma unroll
             for (int g = 0; g < G; g++) {
                 #pragma unroll
-                for (int b = 0; b < RB; b++) y[g * RB + b] = lds[(cl * G + g) * LDS_PAD_CS + b * T + t];
-                gld::dft_lazy<RB, INV>(y + g * RB);
+                for (int bb = 0; bb < HB; bb++) y[g * RB + bb] = lds[(cl * G + g) * LDS_PAD_CS + bb * T + t2];
+            }
+            __syncthreads();
+            if (tid >= 128) {
+                #pragma unroll
+                for (int c = 0; c < 16; c++) lds[c * LDS_PAD_CS + tid - 128] = x[c];
+            }
+            __syncthreads();
+            #pragma unroll
+            for (int g = 0; g < G; g++) {
+                #pragma unroll
+                for (int bb = 0; bb < HB; bb++) y[g * RB + HB + bb] = lds[(cl * G + g) * LDS_PAD_CS + bb * T + t2];
             }
         }
+        #pragma unroll
+        for (int g = 0; g < G; g++) gld::dft_lazy<RB, INV>(y + g * RB);
     }
     // outputs: thread (t, cl) holds k = c + 16 d, c = cl*G + g, d = 0..RB-1 in y[g*RB + d]
     {
-        const unsigned t = tid % T, cl = tid / T;
+        const unsigned tid3 = gld::opaque(tid);              // keep the store addressing below the exchange
+        const unsigned t = tid3 % T, cl = tid3 / T;
         if constexpr (BITREV) __syncthreads();               // phase 2 has finished reading lds
         #pragma unroll
         for (int g = 0; g < G; g++) {
