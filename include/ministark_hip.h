@@ -162,14 +162,25 @@ int ms_sha256_rows_row_major(ms_ctx* ctx, int field, size_t nrows, unsigned ncol
  *     19 EMBED              Q[dst] = (P[a], 0, 0)
  *     20 STORE_Q            out[i] = Q[a]  (out_field = MS_GOLDILOCKS_FQ3)
  *     21 STORE_P            out[i] = P[a]  (out_field = MS_GOLDILOCKS_FP, i.e. Fq = Fp AIRs)
- *   The program is validated on the host (MS_ERR_INVALID on any out-of-range operand).
- * d_x_lde may be NULL (x generated on the fly from h_domain_offset); d_out has 2^log_n elements
- * of out_field.  Asynchronous. */
+ *   The program is validated on the host (MS_ERR_INVALID on any out-of-range operand; `b` of a STORE
+ *   must be 0).  Before launch the library rewrites it (csrc/eval_opt.h): sub-expressions of short
+ *   period in i (zerofier inverses, x^N) are evaluated once into tables, long x^e chains become
+ *   twiddle-table lookups; on domains of >= 2^16 points the result is compiled (hiprtc, cached per
+ *   context) into a specialised straight-line kernel (csrc/eval_jit.h; MS_EVAL_JIT=0 keeps the
+ *   interpreter).  Results are bit-identical either way.
+ * d_x_lde may be NULL (x generated on the fly from h_domain_offset; a caller-supplied x array
+ * disables the rewrites that rely on x_i = offset * w^i); d_out has 2^log_n elements of out_field.
+ * At most 16 periodic columns.  Asynchronous. */
 int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
                     unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
                     const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
                     const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
                     int out_field, void* d_out);
+
+/* Diagnostics: compile the specialised kernel for a (validated-shape) program without launching it;
+ * needs no device.  *code_bytes receives the size of the gfx950 code object; on failure returns
+ * MS_ERR_UNSUPPORTED with the compiler log in ms_last_error(). */
+int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int out_field, size_t* code_bytes);
 
 /* ---- FRI fold: apply_drp (src/fri.rs:526-567) as called by FriProver::build_layer
  * (src/fri.rs:199-231).  d_evals holds 2^log_n elements in bit-reversed order (the layer that

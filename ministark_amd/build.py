@@ -22,16 +22,35 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x",
 def _deps():
     out = []
     for d, _, files in os.walk(CSRC):
-        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".cpp", ".hip"))]
+        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".cpp", ".hip", ".inc"))]
     out.append(os.path.join(ROOT, "include", "ministark_hip.h"))
     return out
 
 
+JIT_HEADERS = ["gl.h", "gl_dev.h", "fp252.h", "stage_kernels.h", "eval_kernels.h"]
+EMBED = os.path.join(CSRC, "_embedded_headers.inc")
+
+
+def embed_headers():
+    """The device headers the specialised constraint kernels include (csrc/eval_jit.h) travel inside
+    the library as strings: hiprtc has no include path on the box that runs it."""
+    parts = []
+    for name in JIT_HEADERS:
+        text = open(os.path.join(CSRC, name)).read()
+        assert ')MSHDR"' not in text
+        parts.append('{"%s", R"MSHDR(%s)MSHDR"},\n' % (name, text))
+    new = "".join(parts)
+    if not os.path.exists(EMBED) or open(EMBED).read() != new:
+        with open(EMBED, "w") as f:
+            f.write(new)
+
+
 def build(force=False, verbose=True):
+    embed_headers()
     newest = max(os.path.getmtime(p) for p in _deps())
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO]
+    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO, "-lhiprtc"]
     if verbose:
         print("[ministark_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -13,7 +13,9 @@
 // (eval_cpu.rs:115-134), coalesced across the wave; the program is wave-uniform so the
 // interpreter's branches never diverge.  Registers live in the lane's private segment.
 #pragma once
+#if !defined(__HIPCC_RTC__)      // hiprtc pre-includes the runtime declarations
 #include <hip/hip_runtime.h>
+#endif
 #include "gl.h"
 #include "gl_dev.h"
 #include "stage_kernels.h"
@@ -22,12 +24,14 @@ namespace mseval {
 
 static constexpr int NT = 256;
 static constexpr int MAXCOLS = 96;        // base + extension columns
-static constexpr int MAXPERIODIC = 16;
+static constexpr int MAXPERIODIC = 64;    // caller periodic columns + hoisted short-period tables (eval_opt.h)
 
 enum Op : uint32_t {
     OP_X_P = 0, OP_CONST_P, OP_CONST_Q, OP_TRACE_P, OP_TRACE_Q, OP_PERIODIC_P, OP_PERIODIC_Q,
     OP_NEG_P, OP_NEG_Q, OP_ADD_PP, OP_ADD_QQ, OP_ADD_QP, OP_MUL_PP, OP_MUL_QQ, OP_MUL_QP,
-    OP_INV_P, OP_INV_Q, OP_POW_P, OP_POW_Q, OP_EMBED, OP_STORE_Q, OP_STORE_P, OP_COUNT
+    OP_INV_P, OP_INV_Q, OP_POW_P, OP_POW_Q, OP_EMBED, OP_STORE_Q, OP_STORE_P,
+    OP_XPOW_P,      // internal (eval_opt.h): dst = consts[a] * w_n^(b*i mod n)  ==  x^b with consts[a] = h^b
+    OP_COUNT
 };
 struct Instr { uint32_t op, dst, a, b; };
 
@@ -38,7 +42,7 @@ struct EvalParams {
     const uint64_t* ext_cols[MAXCOLS];
     const uint64_t* periodic[MAXPERIODIC];
     uint32_t periodic_len[MAXPERIODIC];
-    uint64_t* out;                // n x Fq3 (or n x Fp when the program ends in STORE_P)
+    uint64_t* out;                // n x Fq3 (or n x Fp when the program ends in STORE_P); STORE with b > 0 writes table b-1 of `periodic`
     const uint64_t* x_lde;        // optional: x values (Fp); nullptr -> generated as h*w^i
     const uint64_t* tw_lo;        // w_n^i two-level tables of the size-n forward plan (Montgomery form)
     const uint64_t* tw_hi;
@@ -48,6 +52,61 @@ struct EvalParams {
     uint32_t xshift;              // the w table belongs to a domain of 2^(log_n + xshift) points
 };
 
+
+// ---- the operations of the program, shared by the interpreter below and by the specialised kernels
+// eval_jit.h generates (one call per instruction, registers as named locals)
+__device__ __forceinline__ size_t ev_row(const EvalParams& P, size_t i, uint32_t off) {     // (i + lde_step*offset) mod n
+    return (i + (size_t)((long long)(int32_t)off * (long long)P.lde_step)) & (P.n - 1);       // n is a power of two
+}
+__device__ __forceinline__ uint64_t ev_wpow(const EvalParams& P, size_t e) {                // w^e from the two-level table
+    uint64_t x = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+    if (e >> P.lo_bits) x = gld::mmul(x, P.tw_hi[e >> P.lo_bits]);
+    return x;
+}
+__device__ __forceinline__ uint64_t ev_x(const EvalParams& P, size_t i) {
+    if (P.x_lde) return P.x_lde[i];
+    return gld::mmul(ev_wpow(P, i << P.xshift), P.h_mont);
+}
+__device__ __forceinline__ uint64_t ev_xpow(const EvalParams& P, size_t i, uint32_t cslot, uint32_t e) {
+    return gld::mmul(ev_wpow(P, (((size_t)e * i) & (P.n - 1)) << P.xshift), P.consts[cslot]);
+}
+__device__ __forceinline__ uint64_t ev_trace_p(const EvalParams& P, size_t i, uint32_t col, uint32_t off) { return P.base_cols[col][ev_row(P, i, off)]; }
+__device__ __forceinline__ gl::Fq3 ev_trace_q(const EvalParams& P, size_t i, uint32_t col, uint32_t off) {
+    const uint64_t* c = P.ext_cols[col] + 3 * ev_row(P, i, off);
+    return {c[0], c[1], c[2]};
+}
+__device__ __forceinline__ uint64_t ev_periodic_p(const EvalParams& P, size_t i, uint32_t id) { return P.periodic[id][i % P.periodic_len[id]]; }
+__device__ __forceinline__ gl::Fq3 ev_periodic_q(const EvalParams& P, size_t i, uint32_t id) {
+    const uint64_t* c = P.periodic[id] + 3 * (i % P.periodic_len[id]);
+    return {c[0], c[1], c[2]};
+}
+__device__ __forceinline__ gl::Fq3 ev_const_q(const EvalParams& P, uint32_t a) { return {P.consts[a], P.consts[a + 1], P.consts[a + 2]}; }
+__device__ __forceinline__ void ev_store_p(const EvalParams& P, size_t i, uint32_t slot, uint64_t v) { (slot ? (uint64_t*)P.periodic[slot - 1] : P.out)[i] = v; }
+__device__ __forceinline__ void ev_store_q(const EvalParams& P, size_t i, uint32_t slot, const gl::Fq3& v) {
+    uint64_t* o = (slot ? (uint64_t*)P.periodic[slot - 1] : P.out) + 3 * i;
+    o[0] = v.c0; o[1] = v.c1; o[2] = v.c2;
+}
+// Fp252 (Fq = Fp): elements are 4 words; h_mont is the word index of the domain offset in consts
+__device__ __forceinline__ f252::E ev252_load(const uint64_t* p, size_t i) { return msstage::Fp252T::load(p, i); }
+__device__ __forceinline__ f252::E ev252_wpow(const EvalParams& P, size_t e) {
+    f252::E x = ev252_load(P.tw_lo, e & ((1u << P.lo_bits) - 1));
+    if (e >> P.lo_bits) x = f252::mul(x, ev252_load(P.tw_hi, e >> P.lo_bits));
+    return x;
+}
+__device__ __forceinline__ f252::E ev252_x(const EvalParams& P, size_t i) {
+    if (P.x_lde) return ev252_load(P.x_lde, i);
+    return f252::mul(ev252_wpow(P, i << P.xshift), ev252_load(P.consts + P.h_mont, 0));
+}
+__device__ __forceinline__ f252::E ev252_xpow(const EvalParams& P, size_t i, uint32_t cslot, uint32_t e) {
+    return f252::mul(ev252_wpow(P, (((size_t)e * i) & (P.n - 1)) << P.xshift), ev252_load(P.consts + cslot, 0));
+}
+__device__ __forceinline__ f252::E ev252_const(const EvalParams& P, uint32_t a) { return f252::E{{P.consts[a], P.consts[a + 1], P.consts[a + 2], P.consts[a + 3]}}; }
+__device__ __forceinline__ f252::E ev252_trace(const EvalParams& P, size_t i, uint32_t col, uint32_t off) { return ev252_load(P.base_cols[col], ev_row(P, i, off)); }
+__device__ __forceinline__ f252::E ev252_periodic(const EvalParams& P, size_t i, uint32_t id) { return ev252_load(P.periodic[id], i % P.periodic_len[id]); }
+__device__ __forceinline__ void ev252_store(const EvalParams& P, size_t i, uint32_t slot, const f252::E& v) {
+    msstage::Fp252T::store(slot ? (uint64_t*)P.periodic[slot - 1] : P.out, i, v);
+}
+
 template <int NP, int NQ>
 __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
     using F3 = msstage::Fq3T;
@@ -56,34 +115,16 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
     if (i >= P.n) return;
     uint64_t rp[NP];
     gl::Fq3 rq[NQ];
-    const size_t nmask = P.n - 1;
     for (uint32_t pc = 0; pc < P.ninstr; pc++) {
         const Instr I = P.prog[pc];
         switch (I.op) {
-        case OP_X_P: {
-            uint64_t x;
-            if (P.x_lde) x = P.x_lde[i];
-            else {
-                const size_t e = i << P.xshift;
-                x = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
-                if (e >> P.lo_bits) x = gld::mmul(x, P.tw_hi[e >> P.lo_bits]);
-                x = gld::mmul(x, P.h_mont);
-            }
-            rp[I.dst] = x;
-        } break;
+        case OP_X_P: rp[I.dst] = ev_x(P, i); break;
         case OP_CONST_P: rp[I.dst] = P.consts[I.a]; break;
-        case OP_CONST_Q: rq[I.dst] = {P.consts[I.a], P.consts[I.a + 1], P.consts[I.a + 2]}; break;
-        case OP_TRACE_P: {
-            const size_t j = (i + (size_t)((long long)(int32_t)I.b * (long long)P.lde_step)) & nmask;   // n is a power of two
-            rp[I.dst] = P.base_cols[I.a][j];
-        } break;
-        case OP_TRACE_Q: {
-            const size_t j = (i + (size_t)((long long)(int32_t)I.b * (long long)P.lde_step)) & nmask;
-            const uint64_t* c = P.ext_cols[I.a] + 3 * j;
-            rq[I.dst] = {c[0], c[1], c[2]};
-        } break;
-        case OP_PERIODIC_P: rp[I.dst] = P.periodic[I.a][i % P.periodic_len[I.a]]; break;
-        case OP_PERIODIC_Q: { const uint64_t* c = P.periodic[I.a] + 3 * (i % P.periodic_len[I.a]); rq[I.dst] = {c[0], c[1], c[2]}; } break;
+        case OP_CONST_Q: rq[I.dst] = ev_const_q(P, I.a); break;
+        case OP_TRACE_P: rp[I.dst] = ev_trace_p(P, i, I.a, I.b); break;
+        case OP_TRACE_Q: rq[I.dst] = ev_trace_q(P, i, I.a, I.b); break;
+        case OP_PERIODIC_P: rp[I.dst] = ev_periodic_p(P, i, I.a); break;
+        case OP_PERIODIC_Q: rq[I.dst] = ev_periodic_q(P, i, I.a); break;
         case OP_NEG_P: rp[I.dst] = gl::neg(rp[I.a]); break;
         case OP_NEG_Q: rq[I.dst] = gl::neg(rq[I.a]); break;
         case OP_ADD_PP: rp[I.dst] = gl::add(rp[I.a], rp[I.b]); break;
@@ -97,8 +138,9 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
         case OP_POW_P: rp[I.dst] = msstage::powu<F1>(rp[I.a], I.b); break;
         case OP_POW_Q: rq[I.dst] = msstage::powu<F3>(rq[I.a], I.b); break;
         case OP_EMBED: rq[I.dst] = {rp[I.a], 0, 0}; break;
-        case OP_STORE_Q: { uint64_t* o = P.out + 3 * i; const gl::Fq3 v = rq[I.a]; o[0] = v.c0; o[1] = v.c1; o[2] = v.c2; } break;
-        case OP_STORE_P: P.out[i] = rp[I.a]; break;
+        case OP_STORE_Q: ev_store_q(P, i, I.b, rq[I.a]); break;
+        case OP_STORE_P: ev_store_p(P, i, I.b, rp[I.a]); break;
+        case OP_XPOW_P: rp[I.dst] = ev_xpow(P, i, I.a, I.b); break;
         default: break;
         }
     }
@@ -112,33 +154,20 @@ __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= P.n) return;
     f252::E rp[NP];
-    const size_t nmask = P.n - 1;
     for (uint32_t pc = 0; pc < P.ninstr; pc++) {
         const Instr I = P.prog[pc];
         switch (I.op) {
-        case OP_X_P: {
-            f252::E x;
-            if (P.x_lde) x = F::load(P.x_lde, i);
-            else {
-                const size_t e = i << P.xshift;
-                x = F::load(P.tw_lo, e & ((1u << P.lo_bits) - 1));
-                if (e >> P.lo_bits) x = f252::mul(x, F::load(P.tw_hi, e >> P.lo_bits));
-                x = f252::mul(x, F::load(P.consts + P.h_mont, 0));      // h_mont = word index of the offset in consts
-            }
-            rp[I.dst] = x;
-        } break;
-        case OP_CONST_P: rp[I.dst] = f252::E{{P.consts[I.a], P.consts[I.a + 1], P.consts[I.a + 2], P.consts[I.a + 3]}}; break;
-        case OP_TRACE_P: {
-            const size_t j = (i + (size_t)((long long)(int32_t)I.b * (long long)P.lde_step)) & nmask;
-            rp[I.dst] = F::load(P.base_cols[I.a], j);
-        } break;
-        case OP_PERIODIC_P: rp[I.dst] = F::load(P.periodic[I.a], i % P.periodic_len[I.a]); break;
+        case OP_X_P: rp[I.dst] = ev252_x(P, i); break;
+        case OP_CONST_P: rp[I.dst] = ev252_const(P, I.a); break;
+        case OP_TRACE_P: rp[I.dst] = ev252_trace(P, i, I.a, I.b); break;
+        case OP_PERIODIC_P: rp[I.dst] = ev252_periodic(P, i, I.a); break;
         case OP_NEG_P: rp[I.dst] = f252::neg(rp[I.a]); break;
         case OP_ADD_PP: rp[I.dst] = f252::add(rp[I.a], rp[I.b]); break;
         case OP_MUL_PP: rp[I.dst] = f252::mul(rp[I.a], rp[I.b]); break;
         case OP_INV_P: rp[I.dst] = f252::inv(rp[I.a]); break;
         case OP_POW_P: rp[I.dst] = msstage::powu<F>(rp[I.a], I.b); break;
-        case OP_STORE_P: F::store(P.out, i, rp[I.a]); break;
+        case OP_STORE_P: ev252_store(P, i, I.b, rp[I.a]); break;
+        case OP_XPOW_P: rp[I.dst] = ev252_xpow(P, i, I.a, I.b); break;
         default: break;
         }
     }

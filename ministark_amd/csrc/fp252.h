@@ -8,7 +8,9 @@
 // This field is compute-bound on any GPU (>= 20 64x64 products per multiplication); no attempt is
 // made here to reach an HBM roofline.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#endif
 #include "gl.h"   // MS_HD
 
 namespace f252 {

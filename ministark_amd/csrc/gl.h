@@ -16,7 +16,15 @@
 // So the code below prefers the single-instruction 64-bit add/compare forms
 // the compiler emits for plain uint64_t arithmetic over carry chains.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#else                            // hiprtc (eval_jit.h) has no system headers
+typedef unsigned char uint8_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+#endif
 
 #if defined(__HIPCC__)
 #define MS_HD __host__ __device__ __forceinline__

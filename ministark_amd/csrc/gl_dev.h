@@ -16,14 +16,16 @@
 // v_add_co/v_addc_co chains (and inserts the gfx950 VALU->VCC wait states itself) and g++
 // compiles the same source for the host-side simulator tests.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
-#include <type_traits>
+#endif
 #include "gl.h"
 
 namespace gld {
 
 typedef unsigned __int128 u128;
 static constexpr uint32_t EPS32 = 0xFFFFFFFFu;
+template <int N> struct int_c { static constexpr int value = N; };     // compile-time index passed by value
 
 MS_HD uint32_t lo32(uint64_t x) { return (uint32_t)x; }
 MS_HD uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
@@ -264,10 +266,10 @@ MS_HD void dft16_pruned(uint64_t* x) {
             bfly<INV, c1 + 4, false>(s1, q);          // X[c1 + 4], X[c1 + 12]
             x[c1] = s0; x[c1 + 8] = p; x[c1 + 4] = s1; x[c1 + 12] = q;
         };
-        quad(std::integral_constant<int, 0>{});
-        quad(std::integral_constant<int, 1>{});
-        quad(std::integral_constant<int, 2>{});
-        quad(std::integral_constant<int, 3>{});
+        quad(int_c<0>{});
+        quad(int_c<1>{});
+        quad(int_c<2>{});
+        quad(int_c<3>{});
     }
 }
 

@@ -20,6 +20,10 @@
 #include "stage_kernels.h"
 #include "fri_kernels.h"
 #include "eval_kernels.h"
+#include "eval_opt.h"
+#ifndef MS_NO_JIT
+#include "eval_jit.h"
+#endif
 #include "fp252_kernels.h"
 #include "rpo_kernels.h"
 #include "deep_kernels.h"
@@ -31,7 +35,7 @@ using msntt::MAXC;
 // ---------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 static int fail(int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[4096];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
@@ -88,6 +92,10 @@ struct ms_ctx {
     std::map<void*, size_t> live;            // size of every block handed out by ms_alloc
     void* prog_buf = nullptr;                // device copy of the current constraint program + constants
     size_t prog_bytes = 0;
+    // constraint programs compiled to specialised kernels (eval_jit.h), by hash of the generated source;
+    // nullptr = compilation failed once, use the interpreter
+    std::map<uint64_t, hipFunction_t> jit_cache;
+    std::vector<hipModule_t> jit_modules;
     // optional per-launch timing (ms_profile_*): hipEvent pairs around every kernel launch
     bool profiling = false;
     struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes; };
@@ -148,6 +156,7 @@ extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);
+    for (auto m : ctx->jit_modules) (void)hipModuleUnload(m);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MS_OK;
@@ -188,10 +197,9 @@ extern "C" int ms_profile_read(ms_ctx* ctx, char* buf, size_t cap) {
     return MS_OK;
 }
 
-extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {
-    if (!ctx || !d_ptr) return fail(MS_ERR_INVALID, "ms_alloc: null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+// pooled blocks; the caller holds ctx->mu.  A freed block may be handed out again at once: every
+// kernel runs on ctx->stream, so the next user queues behind the last one.
+static int pool_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {
     bytes = (bytes + 255) & ~(size_t)255;
     auto it = ctx->pool.find(bytes);
     if (it != ctx->pool.end()) {
@@ -211,10 +219,8 @@ extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {
     ctx->live[*d_ptr] = bytes;
     return MS_OK;
 }
-extern "C" int ms_free(ms_ctx* ctx, void* d_ptr) {
-    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+static int pool_free(ms_ctx* ctx, void* d_ptr) {
     if (!d_ptr) return MS_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->live.find(d_ptr);
     if (it == ctx->live.end()) return fail(MS_ERR_INVALID, "ms_free: pointer was not returned by ms_alloc on this context");
     const size_t bytes = it->second;
@@ -223,6 +229,17 @@ extern "C" int ms_free(ms_ctx* ctx, void* d_ptr) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(d_ptr));
     return MS_OK;
+}
+extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return fail(MS_ERR_INVALID, "ms_alloc: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return pool_alloc(ctx, bytes, d_ptr);
+}
+extern "C" int ms_free(ms_ctx* ctx, void* d_ptr) {
+    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return pool_free(ctx, d_ptr);
 }
 extern "C" int ms_copy(ms_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
     if (!ctx || (bytes && (!d_dst || !d_src))) return fail(MS_ERR_INVALID, "ms_copy: null argument");
@@ -988,7 +1005,7 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
     using namespace mseval;
     if (!ctx || !h_prog || !d_out || (nconst_words && !h_consts)) return fail(MS_ERR_INVALID, "ms_eval_program: null argument");
     if (nbase > (unsigned)MAXCOLS || next > (unsigned)MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d base and %d extension columns", MAXCOLS, MAXCOLS);
-    if (nperiodic > (unsigned)MAXPERIODIC) return fail(MS_ERR_UNSUPPORTED, "at most %d periodic columns", MAXPERIODIC);
+    if (nperiodic > 16u) return fail(MS_ERR_UNSUPPORTED, "at most 16 periodic columns");      // the other slots hold hoisted tables
     if ((nbase && !d_base_cols) || (next && !d_ext_cols) || (nperiodic && (!d_periodic || !periodic_len))) return fail(MS_ERR_INVALID, "ms_eval_program: null column table");
     if (log_n > 32) return fail(MS_ERR_INVALID, "log_n too large");
     if (lde_step == 0) return fail(MS_ERR_INVALID, "lde_step must be positive");
@@ -1019,8 +1036,8 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
         case OP_ADD_QQ: case OP_MUL_QQ: ok = Q_ok(I.a) && Q_ok(I.b); dq = true; break;
         case OP_ADD_QP: case OP_MUL_QP: ok = Q_ok(I.a) && P_ok(I.b); dq = true; break;
         case OP_EMBED: ok = P_ok(I.a); dq = true; break;
-        case OP_STORE_Q: ok = Q_ok(I.a) && out_field == MS_GOLDILOCKS_FQ3; stored = true; break;
-        case OP_STORE_P: ok = P_ok(I.a) && (out_field == MS_GOLDILOCKS_FP || is252); stored = true; break;
+        case OP_STORE_Q: ok = Q_ok(I.a) && I.b == 0 && out_field == MS_GOLDILOCKS_FQ3; stored = true; break;
+        case OP_STORE_P: ok = P_ok(I.a) && I.b == 0 && (out_field == MS_GOLDILOCKS_FP || is252); stored = true; break;
         default: ok = false;
         }
         if (is252 && (dq || I.op == OP_STORE_Q)) ok = false;
@@ -1032,69 +1049,164 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
     const size_t n = (size_t)1 << log_n;
     uint64_t h = 1;
     if (h_domain_offset && !is252) { uint64_t h_m; memcpy(&h_m, h_domain_offset, 8); h = gl::from_mont(h_m); }
+    f252::E h252 = f252::one();
+    if (h_domain_offset && is252) memcpy(h252.l, h_domain_offset, 32);
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    // program + constants (+ the Fp252 domain offset as one more constant) -> device
-    std::vector<uint64_t> consts_ext;
-    if (is252) {
-        consts_ext.resize((size_t)nconst_words + 4);
-        if (nconst_words) memcpy(consts_ext.data(), h_consts, (size_t)nconst_words * 8);
-        f252::E ho = f252::one();
-        if (h_domain_offset) memcpy(ho.l, h_domain_offset, 32);
-        memcpy(consts_ext.data() + nconst_words, ho.l, 32);
-        h_consts = consts_ext.data();
-        nconst_words += 4;
+    // ---- rewrite: short-period sub-expressions -> tables, long x^e chains -> twiddle lookups (eval_opt.h)
+    static const bool no_opt = getenv("MS_EVAL_NO_HOIST") != nullptr;
+    SplitProgram split;
+    if (!no_opt) {
+        split = split_periodic(prog, ninstr, log_n, d_x_lde == nullptr, periodic_len, nperiodic, (unsigned)MAXPERIODIC - nperiodic, PW);
+        size_t words = 0;
+        for (unsigned w : split.table_words) words += (size_t)w << split.log_period;
+        if (words * 8 > ((size_t)64 << 20))                   // keep the tables cache-sized: fall back to short periods only
+            split = split_periodic(prog, ninstr, log_n, d_x_lde == nullptr, periodic_len, nperiodic, (unsigned)MAXPERIODIC - nperiodic, PW, 12);
     }
-    const size_t pbytes = (size_t)ninstr * sizeof(Instr), cbytes = (size_t)nconst_words * 8, total = pbytes + cbytes + 64;
+    std::vector<uint64_t> consts((const uint64_t*)h_consts, (const uint64_t*)h_consts + nconst_words);
+    for (auto& xp : split.xpows) {
+        split.main[xp.instr].a = (uint32_t)consts.size();
+        if (is252) { const f252::E v = f252::pow_u64(h252, xp.e); consts.insert(consts.end(), v.l, v.l + 4); }
+        else consts.push_back(gl::to_mont(gl::pow(h, xp.e)));
+    }
+    if (getenv("MS_EVAL_DEBUG")) {
+        fprintf(stderr, "split active=%d log_period=%u tables=%zu\n", (int)split.active, split.log_period, split.table_words.size());
+        for (unsigned k = 0; k < ninstr; k++) fprintf(stderr, "  orig %3u: op %2u dst %u a %u b %u\n", k, prog[k].op, prog[k].dst, prog[k].a, prog[k].b);
+        for (auto& I : split.prologue) fprintf(stderr, "  pro : op %2u dst %u a %u b %u\n", I.op, I.dst, I.a, I.b);
+        for (auto& I : split.main) fprintf(stderr, "  main: op %2u dst %u a %u b %u\n", I.op, I.dst, I.a, I.b);
+    }
+    const unsigned h252_slot = (unsigned)consts.size();       // the Fp252 domain offset travels as one more constant
+    if (is252) consts.insert(consts.end(), h252.l, h252.l + 4);
+    const Instr* main_prog = split.active ? split.main.data() : prog;
+    const unsigned main_n = split.active ? (unsigned)split.main.size() : ninstr;
+    const unsigned pro_n = (unsigned)split.prologue.size();
+    // ---- program(s) + constants -> device
+    const size_t mbytes = (size_t)main_n * sizeof(Instr), pbytes = (size_t)pro_n * sizeof(Instr), cbytes = consts.size() * 8;
+    const size_t poff = (mbytes + 15) & ~(size_t)15, coff = (poff + pbytes + 15) & ~(size_t)15, total = coff + cbytes + 64;
+    HIPCHK(hipStreamSynchronize(ctx->stream));               // a previous evaluation may still read the buffer
     if (ctx->prog_bytes < total) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->prog_buf) HIPCHK(hipFree(ctx->prog_buf));
         ctx->prog_buf = nullptr; ctx->prog_bytes = 0;
         if (hipMalloc(&ctx->prog_buf, total) != hipSuccess) return fail(MS_ERR_NOMEM, "program buffer");
         ctx->prog_bytes = total;
-    } else {
-        HIPCHK(hipStreamSynchronize(ctx->stream));           // a previous evaluation may still read the buffer
     }
-    const size_t coff = (pbytes + 15) & ~(size_t)15;
-    HIPCHK(hipMemcpy(ctx->prog_buf, h_prog, pbytes, hipMemcpyHostToDevice));
-    if (cbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + coff, h_consts, cbytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->prog_buf, main_prog, mbytes, hipMemcpyHostToDevice));
+    if (pbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + poff, split.prologue.data(), pbytes, hipMemcpyHostToDevice));
+    if (cbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + coff, consts.data(), cbytes, hipMemcpyHostToDevice));
     EvalParams E;
     memset(&E, 0, sizeof E);
-    E.prog = (const Instr*)ctx->prog_buf;
     E.consts = (const uint64_t*)((char*)ctx->prog_buf + coff);
     for (unsigned c = 0; c < nbase; c++) E.base_cols[c] = (const uint64_t*)d_base_cols[c];
     for (unsigned c = 0; c < next; c++) E.ext_cols[c] = (const uint64_t*)d_ext_cols[c];
     for (unsigned c = 0; c < nperiodic; c++) { E.periodic[c] = (const uint64_t*)d_periodic[c]; E.periodic_len[c] = periodic_len[c]; }
     E.out = (uint64_t*)d_out; E.x_lde = (const uint64_t*)d_x_lde;
-    E.h_mont = gl::to_mont(h); E.n = n; E.ninstr = ninstr; E.lde_step = lde_step; E.log_n = log_n;
-    dim3 g((unsigned)((n + NT - 1) / NT));
-    if (is252) {
-        if (!d_x_lde) {
-            ms_ntt_plan* plan = nullptr;
-            for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_n && !kv.first.inverse && kv.first.h == 1) plan = kv.second;
-            if (!plan) { MSCHK(plan_build252(ctx, log_n, false, nullptr, nullptr, &plan)); ctx->plan_cache.push_back({PlanKey{4, log_n, false, 1}, plan}); }
-            E.tw_lo = plan->d252_tw_lo; E.tw_hi = plan->d252_tw_hi; E.lo_bits = plan->lo_bits; E.xshift = 0;
-        }
-        E.h_mont = nconst_words - 4;           // word index of the offset inside consts
-        ProfScope ps(ctx, "eval_program252", 32.0 * n * (nbase + 1));
-        if (maxp <= 16) hipLaunchKernelGGL((eval_program252<16>), g, dim3(NT), 0, ctx->stream, E);
-        else if (maxp <= 64) hipLaunchKernelGGL((eval_program252<64>), g, dim3(NT), 0, ctx->stream, E);
-        else hipLaunchKernelGGL((eval_program252<256>), g, dim3(NT), 0, ctx->stream, E);
-        HIPCHK(hipGetLastError());
-        return MS_OK;
-    }
+    E.h_mont = is252 ? h252_slot : gl::to_mont(h); E.lde_step = lde_step;
+    unsigned table_log = log_n;                               // domain the w table was built for
     if (!d_x_lde) {
         ms_ntt_plan* plan = nullptr;
-        const unsigned tl = std::max(log_n, 12u);
-        MSCHK(ctx_plan(ctx, 1, tl, false, 1, &plan));
-        E.tw_lo = plan->d_tw_lo; E.tw_hi = plan->d_tw_hi; E.lo_bits = plan->lo_bits; E.xshift = tl - log_n;
+        if (is252) {
+            for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_n && !kv.first.inverse && kv.first.h == 1) plan = kv.second;
+            if (!plan) { MSCHK(plan_build252(ctx, log_n, false, nullptr, nullptr, &plan)); ctx->plan_cache.push_back({PlanKey{4, log_n, false, 1}, plan}); }
+            E.tw_lo = plan->d252_tw_lo; E.tw_hi = plan->d252_tw_hi; E.lo_bits = plan->lo_bits;
+        } else {
+            table_log = std::max(log_n, 12u);
+            MSCHK(ctx_plan(ctx, 1, table_log, false, 1, &plan));
+            E.tw_lo = plan->d_tw_lo; E.tw_hi = plan->d_tw_hi; E.lo_bits = plan->lo_bits;
+        }
     }
-    ProfScope ps(ctx, "eval_program", 8.0 * n * (nbase + 3.0 * next + (out_field == MS_GOLDILOCKS_FQ3 ? 3 : 1)));
-    if (maxp <= 16 && maxq <= 8) hipLaunchKernelGGL((eval_program<16, 8>), g, dim3(NT), 0, ctx->stream, E);
-    else if (maxp <= 64 && maxq <= 32) hipLaunchKernelGGL((eval_program<64, 32>), g, dim3(NT), 0, ctx->stream, E);
-    else hipLaunchKernelGGL((eval_program<256, 128>), g, dim3(NT), 0, ctx->stream, E);
+    // specialised kernel for a program (compiled on first use), or nullptr -> interpreter
+    auto specialised = [&](const Instr* pr, unsigned cnt) -> hipFunction_t {
+#ifndef MS_NO_JIT
+        static const bool off = getenv("MS_EVAL_JIT") && !strcmp(getenv("MS_EVAL_JIT"), "0");
+        if (off) return nullptr;
+        const std::string src = jit_source(pr, cnt, is252, maxp, maxq);
+        const uint64_t key = jit_hash(src);
+        auto it = ctx->jit_cache.find(key);
+        if (it != ctx->jit_cache.end()) return it->second;
+        hipFunction_t fn = nullptr;
+        std::vector<char> code;
+        std::string log;
+        if (jit_compile(src, code, log)) {
+            hipModule_t mod = nullptr;
+            if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, "ms_eval_jit") == hipSuccess) ctx->jit_modules.push_back(mod);
+            else { fn = nullptr; (void)hipGetLastError(); }
+        } else if (getenv("MS_EVAL_DEBUG")) fprintf(stderr, "[ministark_hip] constraint kernel compilation failed, using the interpreter:\n%s\n", log.c_str());
+        ctx->jit_cache[key] = fn;
+        return fn;
+#else
+        (void)pr; (void)cnt;
+        return nullptr;
+#endif
+    };
+    auto launch = [&](const EvalParams& Q, hipFunction_t fn) {
+        dim3 g((unsigned)((Q.n + NT - 1) / NT));
+        if (fn) {
+            EvalParams A = Q;
+            void* args[] = {&A};
+            (void)hipModuleLaunchKernel(fn, g.x, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+            return;
+        }
+        if (is252) {
+            if (maxp <= 16) hipLaunchKernelGGL((eval_program252<16>), g, dim3(NT), 0, ctx->stream, Q);
+            else if (maxp <= 64) hipLaunchKernelGGL((eval_program252<64>), g, dim3(NT), 0, ctx->stream, Q);
+            else hipLaunchKernelGGL((eval_program252<256>), g, dim3(NT), 0, ctx->stream, Q);
+        } else {
+            if (maxp <= 16 && maxq <= 8) hipLaunchKernelGGL((eval_program<16, 8>), g, dim3(NT), 0, ctx->stream, Q);
+            else if (maxp <= 64 && maxq <= 32) hipLaunchKernelGGL((eval_program<64, 32>), g, dim3(NT), 0, ctx->stream, Q);
+            else hipLaunchKernelGGL((eval_program<256, 128>), g, dim3(NT), 0, ctx->stream, Q);
+        }
+    };
+    // ---- prologue: the short-period values on the first 2^log_period points -> tables
+    void* tables = nullptr;
+    if (pro_n) {
+        const size_t period = (size_t)1 << split.log_period;
+        size_t words = 0;
+        for (unsigned w : split.table_words) words += w * period;
+        MSCHK(pool_alloc(ctx, words * 8, &tables));
+        uint64_t* tp = (uint64_t*)tables;
+        for (size_t t = 0; t < split.table_words.size(); t++) {
+            E.periodic[nperiodic + t] = tp; E.periodic_len[nperiodic + t] = (uint32_t)period;
+            tp += split.table_words[t] * period;
+        }
+        EvalParams Q = E;
+        Q.prog = (const Instr*)((char*)ctx->prog_buf + poff); Q.ninstr = pro_n;
+        Q.n = period; Q.log_n = split.log_period; Q.xshift = table_log - log_n;      // the first points of the same domain
+        ProfScope ps(ctx, "eval_prologue", 0.0);
+        launch(Q, nullptr);                                   // runs on a few points: not worth a compilation
+    }
+    E.prog = (const Instr*)ctx->prog_buf; E.ninstr = main_n; E.n = n; E.log_n = log_n; E.xshift = table_log - log_n;
+    {
+        hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(main_prog, main_n) : nullptr;   // small domains: the interpreter is quicker than a compilation
+        ProfScope ps(ctx, fn ? (is252 ? "eval_program252_jit" : "eval_program_jit") : (is252 ? "eval_program252" : "eval_program"),
+                     is252 ? 32.0 * n * (nbase + 1) : 8.0 * n * (nbase + 3.0 * next + (out_field == MS_GOLDILOCKS_FQ3 ? 3 : 1)));
+        launch(E, fn);
+    }
+    if (tables) pool_free(ctx, tables);                      // stream-ordered: the next user of the block queues behind this kernel
     HIPCHK(hipGetLastError());
     return MS_OK;
+}
+
+extern "C" int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int out_field, size_t* code_bytes) {
+#ifndef MS_NO_JIT
+    using namespace mseval;
+    if (!h_prog || !code_bytes) return fail(MS_ERR_INVALID, "ms_eval_jit_check: null argument");
+    const bool is252 = out_field == MS_STARK252_FP;
+    const Instr* prog = (const Instr*)h_prog;
+    unsigned maxp = 0, maxq = 0;
+    for (unsigned k = 0; k < ninstr; k++) {
+        if (prog[k].op >= OP_COUNT || prog[k].dst >= 256) return fail(MS_ERR_INVALID, "invalid instruction %u", k);
+        if (op_is_store(prog[k].op)) continue;
+        if (op_is_q_dst(prog[k].op)) maxq = std::max(maxq, prog[k].dst + 1); else maxp = std::max(maxp, prog[k].dst + 1);
+    }
+    std::vector<char> code;
+    std::string log;
+    if (!jit_compile(jit_source(prog, ninstr, is252, maxp, maxq), code, log)) return fail(MS_ERR_UNSUPPORTED, "hiprtc: %s", log.c_str());
+    *code_bytes = code.size();
+    return MS_OK;
+#else
+    (void)h_prog; (void)ninstr; (void)out_field; (void)code_bytes;
+    return fail(MS_ERR_UNSUPPORTED, "built without hiprtc");
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

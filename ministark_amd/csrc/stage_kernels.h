@@ -12,7 +12,9 @@
 // (evaluation_shaders.h.metal:393,401; src/eval_gpu.rs:338) is provided.
 // Pure streaming kernels: HBM-bound for add/neg/convert/fill, ALU-bound for inverse/exp.
 #pragma once
+#if !defined(__HIPCC_RTC__)      // hiprtc pre-includes the runtime declarations
 #include <hip/hip_runtime.h>
+#endif
 #include "gl.h"
 #include "gl_dev.h"
 #include "fp252.h"

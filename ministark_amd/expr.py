@@ -183,7 +183,9 @@ def compile_expr(expr, num_base_columns, fq_is_ext=True, base_field=GOLDILOCKS_F
             a, b = kids
             if kd == "div":
                 tb = nodes[b][4]
-                b = memo.setdefault(("inv", b), emit(OP_INV_P if tb == FP else OP_INV_Q, tb, b))
+                if ("inv", b) not in memo:
+                    memo[("inv", b)] = emit(OP_INV_P if tb == FP else OP_INV_Q, tb, b)
+                b = memo[("inv", b)]
             ta, tb = nodes[a][4], nodes[b][4]
             base = OP_ADD_PP if kd == "add" else OP_MUL_PP
             if ta == FP and tb == FP:

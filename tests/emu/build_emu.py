@@ -21,7 +21,7 @@ def build(force=False):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
-           "-Wno-unknown-pragmas"] + srcs + ["-o", SO]
+           "-Wno-unknown-pragmas", "-DMS_NO_JIT"] + srcs + ["-o", SO]
     subprocess.check_call(cmd)
     return SO
 

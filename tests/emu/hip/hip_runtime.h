@@ -46,6 +46,11 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+// code-object API: the simulator build has no runtime compiler (MS_NO_JIT), these only have to exist
+typedef void* hipModule_t;
+typedef void* hipFunction_t;
+static inline hipError_t hipModuleUnload(hipModule_t) { return hipSuccess; }
+static inline hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t, void**, void**) { return hipErrorInvalidValue; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }

@@ -96,6 +96,24 @@ def test_periodic_column_and_const_fq(kind):
     _check(kind, expr, 12, 2, 1, 1)
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_zerofier_tables_and_x_power_lookup(kind):
+    # the library hoists short-period sub-expressions (zerofier inverses, periodic columns times x^N) into
+    # tables and turns long x^e chains into twiddle lookups (csrc/eval_opt.h): results must not change
+    x = E.X()
+    per = E.Periodic([2, 7, 1, 8], 4)
+    zer_inv = 1 / ((x ** 256 - 1) * (x ** 512 - E.Constant(5)))
+    expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) * zer_inv * (E.Challenge(0) * x ** 1000003 + E.Challenge(1)) \
+        + per * x ** 1024 * E.Trace(2) + (x ** 4096) ** 3 * E.Trace(1, -2) + x ** 12 + E.Challenge(1) * E.Challenge(0) * E.Challenge(1) * E.Trace(3)
+    pl = backends.planner(kind)
+    pl.profile(True)
+    _check(kind, expr, 14, 4, 2, 2, nch=2)
+    _check(kind, expr, 14, 4, 4, 0, nch=2, fq_is_ext=False, offset=3)
+    prof = pl.profile_read()
+    pl.profile(False)
+    assert "eval_prologue" in prof and "eval_program" in prof
+
+
 def test_many_registers_emu():
     # a wide sum of products keeps many values alive -> larger register files
     terms = [E.Trace(k) * E.Trace(k + 1, 1) for k in range(0, 40, 2)]
@@ -130,23 +148,76 @@ def test_eval_2_20_vs_sampled_oracle_hip():
     _check("hip", expr, 20, 8, 2, 2, nch=1, npoints=24)
 
 
-@pytest.mark.parametrize("kind", KINDS)
-def test_fp252_program(kind):                      # src/eval_gpu.rs:1054-1082: constants / columns on Fp252
+def test_specialised_kernel_compiles_for_gfx950():
+    # hiprtc needs no device: the straight-line kernel generated for a program (csrc/eval_jit.h) must
+    # compile for gfx950 from the headers embedded in the library
+    import ctypes
+    from ministark_amd import STARK252_FP
+    from ministark_amd._lib import Lib
+    L = Lib()
+    x = E.X()
+    expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1) + E.Trace(2) * E.Trace(3, -1)) / (x ** 64 - 1) + E.Challenge(0) * x ** 3 + E.Trace(2) ** 7
+    for prog, field in ((E.compile_expr(expr, 2, True), FQ3), (E.compile_expr(expr, 4, False), FP), (E.compile_expr(expr, 4, False, STARK252_FP), STARK252_FP)):
+        code = np.array(prog.instrs, dtype=np.uint32).reshape(-1, 4)
+        size = ctypes.c_size_t(0)
+        rc = L.ms_eval_jit_check(code.ctypes.data, len(code), field, ctypes.byref(size))
+        assert rc == 0, L.ms_last_error().decode()[:2000]
+        assert size.value > 1000
+
+
+@pytest.mark.gpu
+def test_specialised_kernels_2_16_hip():
+    # domains of >= 2^16 points run the hiprtc-compiled straight-line kernel (csrc/eval_jit.h)
+    pl = backends.planner("hip")
+    x = E.X()
+    b0, b1, b2 = (lambda o=0, c=c: E.Trace(c, o) for c in range(3))
+    e0, e1 = (lambda o=0, c=c: E.Trace(3 + c, o) for c in range(2))
+    mixed = (b0(1) - b0() * b1() + e0(1) * e1() - e0() * b2(-1)) * (x - 1) / (x ** 8 - 1) \
+        + E.Challenge(0) * e1(2) + E.Hint(1) * b1(1) + e0() ** 3 + (b2() + E.Challenge(1)) / (e1() - E.Hint(0))
+    per = E.Periodic([3, 1, 4, 1, 5, 9, 2, 6], 8)
+    periodic = per * E.Trace(0) + E.Constant((5, 6, 7)) * x - per ** 2 + E.Trace(1, 3) + x ** 1000003 * E.Trace(0, -1) / (x ** 4096 - 1)
+    pl.profile(True)
+    _check("hip", mixed, 16, 4, 3, 2, nch=2, nh=2, npoints=24)
+    _check("hip", periodic, 16, 2, 1, 1, npoints=24)
+    _check("hip", (b0(1) - b0() * b1()) / (x ** 1024 - 1) + b2() ** 5 * E.Challenge(0), 16, 8, 3, 0, nch=1, fq_is_ext=False, npoints=24)
+    prof = pl.profile_read()
+    pl.profile(False)
+    assert prof.get("eval_program_jit", {}).get("calls", 0) >= 3, prof.keys()
+
+
+def _check252(kind, log_n):
     from oracle.pyref.fields import F252
     from ministark_amd import STARK252_FP, f252_from_mont_limbs, f252_to_mont_limbs
     pl = backends.planner(kind)
-    log_n, lde_step, ncols = 10, 2, 3
+    lde_step, ncols = 2, 3
     n = 1 << log_n
     rng = np.random.default_rng(3)
-    cols = [[int.from_bytes(rng.bytes(32), "little") % F252.p for _ in range(n)] for _ in range(ncols)]
+    raw = rng.integers(0, 1 << 62, size=(ncols, n, 4), dtype=np.uint64)       # any 4-limb pattern < 2^254 is reduced below
+    cols = [[(int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | (int(r[3]) & ((1 << 58) - 1)) << 192) % F252.p for r in raw[c]] for c in range(ncols)]
     ch = [int.from_bytes(rng.bytes(32), "little") % F252.p for _ in range(2)]
     x = E.X()
-    expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) / (x ** 4 - 1) + E.Trace(2, -1) ** 3 * E.Challenge(1) + E.Constant(12345678901234567890123) / x + E.Challenge(0)
+    expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) / (x ** 4 - 1) + E.Trace(2, -1) ** 3 * E.Challenge(1) + E.Constant(12345678901234567890123) / x + E.Challenge(0) \
+        + E.Trace(1) / ((x ** 128 - 1) * (x ** 64 - 7)) + x ** 77777 * E.Trace(0)       # hoisted table + x^e lookup (csrc/eval_opt.h)
     prog = E.compile_expr(expr, ncols, fq_is_ext=False, base_field=STARK252_FP)
     dev = [GpuVec.from_numpy(pl, np.concatenate([f252_to_mont_limbs(v) for v in c]), STARK252_FP) for c in cols]
     chm = np.stack([f252_to_mont_limbs(v) for v in ch])
+    pl.profile(True)
     out = E.eval(prog, pl, chm, chm[:1], lde_step, 3, n, dev).to_numpy().reshape(n, 4)
+    prof = pl.profile_read()
+    pl.profile(False)
     pts = [0, 1, 5, n // 2, n - 1, 777]
     want = evalexpr.eval_points(expr, pts, n, lde_step, 3, cols, [], ch, ch[:1], False, F252)
     for i, w in zip(pts, want):
         assert f252_from_mont_limbs(out[i]) == w, f"point {i}"
+    return prof
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fp252_program(kind):                      # src/eval_gpu.rs:1054-1082: constants / columns on Fp252
+    prof = _check252(kind, 10)
+    assert "eval_prologue" in prof and "eval_program252" in prof
+
+
+@pytest.mark.gpu
+def test_fp252_specialised_kernel_2_16_hip():
+    assert "eval_program252_jit" in _check252("hip", 16)
