@@ -182,6 +182,23 @@ int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const 
  * MS_ERR_UNSUPPORTED with the compiler log in ms_last_error(). */
 int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int out_field, size_t* code_bytes);
 
+/* ---- extension columns and queries.
+ * ms_scan_affine     the sequential host loops that build running-product / running-evaluation
+ *                    extension columns (examples/brainfuck/trace.rs:108-289):
+ *                        state = init;  for i in 0..n:  out[i] = state;  state = a[i]*state + b[i]
+ *                    (inclusive != 0: out[i] = the state AFTER row i).  d_a NULL = all ones (running sum),
+ *                    d_b NULL = all zeros (running product); masked rows are a = 1, b = 0.  a, b, init, out
+ *                    are elements of `field` (Goldilocks Fp or Fq3); out may alias a or b.  Any n >= 0.
+ * ms_gather_rows     out[p][c] = cols[c][positions[p]], row-major: Matrix::get_row over the query
+ *                    positions (src/trace.rs:139-152, src/matrix.rs get_row)
+ * ms_gather_digests  out[k] = digests[indices[k]] (32-byte records): the leaves / sibling leaves / nodes
+ *                    a batched Merkle opening lists (MerkleTreeImpl::prove, src/merkle.rs:149-206)
+ * Positions / indices are host arrays of u64 (they come from the channel); outputs are device buffers. */
+int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a, const void* d_b, const void* h_init, int inclusive, void* d_out);
+int ms_gather_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols,
+                   const uint64_t* h_positions, size_t npos, void* d_out);
+int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_digests, const uint64_t* h_indices, size_t count, void* d_out);
+
 /* ---- FRI fold: apply_drp (src/fri.rs:526-567) as called by FriProver::build_layer
  * (src/fri.rs:199-231).  d_evals holds 2^log_n elements in bit-reversed order (the layer that
  * was just committed); d_out receives 2^log_n / folding_factor elements, bit-reversed, the next

@@ -63,6 +63,9 @@ class Lib:
             "ms_sum_columns": (i, [vp, i, sz, c_void_pp, u, vp]),
             "ms_eval_program": (i, [vp, vp, u, vp, u, u, u, vp, vp, c_void_pp, u, c_void_pp, u, c_void_pp, vp, u, i, vp]),
             "ms_eval_jit_check": (i, [vp, u, i, vp]),
+            "ms_scan_affine": (i, [vp, i, sz, vp, vp, vp, i, vp]),
+            "ms_gather_rows": (i, [vp, i, sz, c_void_pp, u, vp, sz, vp]),
+            "ms_gather_digests": (i, [vp, sz, vp, vp, sz, vp]),
             "ms_fri_fold": (i, [vp, i, u, u, vp, vp, vp, vp]),
             "ms_sha256_rows": (i, [vp, i, sz, c_void_pp, u, vp]),
             "ms_sha256_merkle": (i, [vp, sz, vp, vp]),

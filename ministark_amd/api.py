@@ -9,6 +9,7 @@ ministark_amd/csrc/host/ministark.hpp stand where the `cfg(feature = "hip")`
 shim of INTEGRATION.md would.)
 """
 import ctypes
+from collections import deque
 
 import numpy as np
 
@@ -180,6 +181,18 @@ class DeviceBytes:
             pass
 
 
+def _gather_digests(planner, digests, ndigests, ids):
+    """32-byte records `ids` of a device digest array -> list of bytes (one device gather + one copy)."""
+    if not ids:
+        return []
+    idx = np.asarray(ids, dtype=np.uint64)
+    out = DeviceBytes(planner, 32 * len(ids))
+    L = planner.lib
+    L.check(L.ms_gather_digests(planner.handle, ndigests, digests.ptr, idx.ctypes.data, len(ids), out.ptr))
+    raw = out.to_numpy().tobytes()
+    return [raw[32 * k:32 * k + 32] for k in range(len(ids))]
+
+
 class MerkleTree:
     """`MatrixMerkleTreeImpl<Sha256HashFn>` (src/merkle.rs:296-361): `from_matrix` hashes the
     rows and builds the node array on device; `root` is nodes[1] (src/merkle.rs:145-147)."""
@@ -204,6 +217,42 @@ class MerkleTree:
         leaves = DeviceBytes(pl, nrows * 32)
         pl.lib.check(pl.lib.ms_sha256_rows_row_major(pl.handle, evaluations.field, nrows, folding_factor, evaluations.ptr, leaves.ptr))
         return cls(pl, leaves, nrows)
+
+    def prove(self, indices):
+        """`MerkleTreeImpl::prove` (src/merkle.rs:149-206): the batched opening of `indices` as the
+        reference's MerkleView -> dict(nodes, initial_leaves, sibling_leaves, height), digests as
+        bytes.  The walk over indices is bookkeeping; the digests are gathered on the device and
+        come back in one copy."""
+        n = self.nleaves
+        for i in indices:
+            if i >= n:
+                raise IndexError(f"leaf index {i} out of bounds ({n})")         # Error::LeafIndexOutOfBounds
+        leaf_ids, initial, sibling = [], [], []
+        node_queue = deque()
+        leaf_queue = deque(sorted(set(int(i) for i in indices)))
+        while leaf_queue:
+            index = leaf_queue.popleft()
+            initial.append(len(leaf_ids)); leaf_ids.append(index)
+            node_queue.append((n + index) >> 1)
+            if leaf_queue and (index ^ 1) == leaf_queue[0]:
+                initial.append(len(leaf_ids)); leaf_ids.append(leaf_queue.popleft())
+                continue
+            sibling.append(len(leaf_ids)); leaf_ids.append(index ^ 1)
+        node_ids = []
+        while node_queue:
+            index = node_queue.popleft()
+            if index > 2:
+                node_queue.append(index >> 1)
+            if node_queue and (index ^ 1) == node_queue[0]:
+                node_queue.popleft()
+                continue
+            node_ids.append(index ^ 1)
+        leaves = _gather_digests(self.planner, self.leaves, n, leaf_ids)
+        nodes = _gather_digests(self.planner, self.nodes, n, node_ids)
+        return {"nodes": [nodes[k] for k in range(len(node_ids))],
+                "initial_leaves": [leaves[k] for k in initial],
+                "sibling_leaves": [leaves[k] for k in sibling],
+                "height": n.bit_length() - 1}
 
     def root(self):
         out = np.empty(32, dtype=np.uint8)
@@ -406,6 +455,16 @@ class Matrix:
     def bit_reversed_evaluate(self, domain):           # src/matrix.rs:245-251
         return self.clone().into_bit_reversed_evaluations(domain)
 
+    def get_rows(self, positions):
+        """`Matrix::get_row` for every queried position (src/trace.rs:139-152): numpy u64 array
+        [len(positions), num_cols * words], Montgomery words, gathered on the device."""
+        pl, L = self.planner, self.planner.lib
+        pos = np.asarray(positions, dtype=np.uint64)
+        words = self.num_cols() * FIELD_WORDS[self.field]
+        out = DeviceBytes(pl, max(1, len(pos) * words * 8))
+        L.check(L.ms_gather_rows(pl.handle, self.field, self.num_rows(), _ptr_array(self.columns), self.num_cols(), pos.ctypes.data, len(pos), out.ptr))
+        return out.to_numpy().view(np.uint64)[: len(pos) * words].reshape(len(pos), words)
+
     def hash_rows(self):
         """`hash_rows::<F, Sha256HashFn>` (src/merkle.rs:412-436, src/matrix.rs:254-280):
         one SHA-256 digest per row -> DeviceBytes of num_rows x 32."""
@@ -427,6 +486,39 @@ class Matrix:
                          _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
         self.planner.sync()
         return Matrix(outs)
+
+
+def scan_affine(a, b, init, inclusive=False):
+    """The sequential loops that build extension columns (examples/brainfuck/trace.rs:108-289):
+    state = init; for every row: out[row] = state; state = a[row] * state + b[row].  `a` or `b` may
+    be None (all ones / all zeros: a running sum / a running product).  a, b: GpuVec of one field
+    (Goldilocks Fp or Fq3); init: numpy u64 Montgomery words of one element."""
+    ref = a if a is not None else b
+    pl, L = ref.planner, ref.planner.lib
+    out = GpuVec(pl, len(ref), ref.field)
+    init = np.ascontiguousarray(init, dtype=np.uint64)
+    L.check(L.ms_scan_affine(pl.handle, ref.field, len(ref), a.ptr if a is not None else None, b.ptr if b is not None else None,
+                             init.ctypes.data, int(bool(inclusive)), out.ptr))
+    return out
+
+
+def running_product(factors, init):
+    """ext[row] = init * prod(factors[:row])  (the permutation columns, trace.rs:131-145)."""
+    return scan_affine(factors, None, init)
+
+
+class Queries:
+    """`Queries::new` (src/trace.rs:113-157): the rows of the base / extension / composition LDEs at the
+    query positions and the batched Merkle openings of the three trees, all gathered on the device."""
+
+    def __init__(self, base_trace_lde, extension_trace_lde, composition_trace_lde, base_tree, extension_tree, composition_tree, positions):
+        positions = [int(p) for p in positions]
+        self.base_trace_proof = base_tree.prove(positions)
+        self.extension_trace_proof = extension_tree.prove(positions) if extension_tree is not None else None
+        self.composition_trace_proof = composition_tree.prove(positions)
+        self.base_trace_values = base_trace_lde.get_rows(positions)
+        self.extension_trace_values = extension_trace_lde.get_rows(positions) if extension_trace_lde is not None else None
+        self.composition_trace_values = composition_trace_lde.get_rows(positions)
 
 
 def apply_drp(evals, alpha, folding_factor, domain_offset=1):

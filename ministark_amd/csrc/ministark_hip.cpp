@@ -20,6 +20,7 @@
 #include "stage_kernels.h"
 #include "fri_kernels.h"
 #include "eval_kernels.h"
+#include "scan_kernels.h"
 #include "eval_opt.h"
 #ifndef MS_NO_JIT
 #include "eval_jit.h"
@@ -1207,6 +1208,89 @@ extern "C" int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int ou
     (void)h_prog; (void)ninstr; (void)out_field; (void)code_bytes;
     return fail(MS_ERR_UNSUPPORTED, "built without hiprtc");
 #endif
+}
+
+// ---------------------------------------------------------------------------------------
+// running products / evaluations, query gathers
+// ---------------------------------------------------------------------------------------
+template <class F, bool HAS_A, bool HAS_B>
+static void scan_launch(ms_ctx* ctx, const msscan::ScanParams& P) {
+    using namespace msscan;
+    { ProfScope ps(ctx, "scan_reduce", 8.0 * P.n * F::V * ((HAS_A ? 1 : 0) + (HAS_B ? 1 : 0)));
+      hipLaunchKernelGGL((scan_reduce<F, HAS_A, HAS_B>), dim3(P.nblocks), dim3(NT), 0, ctx->stream, P); }
+    { ProfScope ps(ctx, "scan_blocks", 0.0);
+      hipLaunchKernelGGL((scan_blocks<F, HAS_A, HAS_B>), dim3(1), dim3(NT), 0, ctx->stream, P); }
+    { ProfScope ps(ctx, "scan_apply", 8.0 * P.n * F::V * (1 + (HAS_A ? 1 : 0) + (HAS_B ? 1 : 0)));
+      hipLaunchKernelGGL((scan_apply<F, HAS_A, HAS_B>), dim3(P.nblocks), dim3(NT), 0, ctx->stream, P); }
+}
+extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a, const void* d_b, const void* h_init, int inclusive, void* d_out) {
+    if (!ctx || !d_out || !h_init) return fail(MS_ERR_INVALID, "ms_scan_affine: null argument");
+    if (!d_a && !d_b) return fail(MS_ERR_INVALID, "ms_scan_affine: neither multipliers nor addends given");
+    if (field != MS_GOLDILOCKS_FP && field != MS_GOLDILOCKS_FQ3) return fail(MS_ERR_UNSUPPORTED, "ms_scan_affine: Goldilocks Fp / Fq3 only");
+    if (n == 0) return MS_OK;
+    const unsigned V = field == MS_GOLDILOCKS_FQ3 ? 3 : 1;
+    if ((n + msscan::TILE - 1) / msscan::TILE > 0xFFFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "column too long");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    msscan::ScanParams P;
+    memset(&P, 0, sizeof P);
+    P.a = (const uint64_t*)d_a; P.b = (const uint64_t*)d_b; P.out = (uint64_t*)d_out;
+    memcpy(P.init, h_init, V * 8);
+    P.n = n; P.nblocks = (unsigned)((n + msscan::TILE - 1) / msscan::TILE); P.inclusive = inclusive != 0;
+    void* tmp = nullptr;
+    MSCHK(pool_alloc(ctx, (size_t)P.nblocks * 3 * V * 8, &tmp));
+    P.agg = (uint64_t*)tmp; P.block_state = (uint64_t*)tmp + (size_t)P.nblocks * 2 * V;
+    using msstage::FpT; using msstage::Fq3T;
+    if (V == 1) {
+        if (d_a && d_b) scan_launch<FpT, true, true>(ctx, P); else if (d_a) scan_launch<FpT, true, false>(ctx, P); else scan_launch<FpT, false, true>(ctx, P);
+    } else {
+        if (d_a && d_b) scan_launch<Fq3T, true, true>(ctx, P); else if (d_a) scan_launch<Fq3T, true, false>(ctx, P); else scan_launch<Fq3T, false, true>(ctx, P);
+    }
+    pool_free(ctx, tmp);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_gather_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols,
+                              const uint64_t* h_positions, size_t npos, void* d_out) {
+    if (!ctx || !d_cols || !d_out || (npos && !h_positions)) return fail(MS_ERR_INVALID, "ms_gather_rows: null argument");
+    const size_t fb = ms_field_bytes(field);
+    if (!fb) return fail(MS_ERR_UNSUPPORTED, "unknown field %d", field);
+    if (ncols == 0 || ncols > (unsigned)msstage::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "1..%d columns", msstage::MAXCOLS);
+    for (size_t p = 0; p < npos; p++) if (h_positions[p] >= nrows) return fail(MS_ERR_INVALID, "row %llu out of range", (unsigned long long)h_positions[p]);
+    if (npos == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    void* d_pos = nullptr;
+    MSCHK(pool_alloc(ctx, npos * 8, &d_pos));
+    HIPCHK(hipMemcpyAsync(d_pos, h_positions, npos * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));               // h_positions is pageable caller memory
+    msscan::GatherRowsParams P;
+    memset(&P, 0, sizeof P);
+    for (unsigned c = 0; c < ncols; c++) { if (!d_cols[c]) { pool_free(ctx, d_pos); return fail(MS_ERR_INVALID, "null column %u", c); } P.cols[c] = (const uint64_t*)d_cols[c]; }
+    P.pos = (const uint64_t*)d_pos; P.out = (uint64_t*)d_out; P.npos = npos; P.ncols = ncols; P.V = (unsigned)(fb / 8);
+    const size_t total = npos * ncols * P.V;
+    { ProfScope ps(ctx, "gather_rows", 16.0 * total);
+      hipLaunchKernelGGL(msscan::gather_rows, dim3(stream_grid(total)), dim3(msscan::NT), 0, ctx->stream, P); }
+    pool_free(ctx, d_pos);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+extern "C" int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_digests, const uint64_t* h_indices, size_t count, void* d_out) {
+    if (!ctx || !d_digests || !d_out || (count && !h_indices)) return fail(MS_ERR_INVALID, "ms_gather_digests: null argument");
+    for (size_t k = 0; k < count; k++) if (h_indices[k] >= ndigests) return fail(MS_ERR_INVALID, "digest %llu out of range", (unsigned long long)h_indices[k]);
+    if (count == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    void* d_idx = nullptr;
+    MSCHK(pool_alloc(ctx, count * 8, &d_idx));
+    HIPCHK(hipMemcpyAsync(d_idx, h_indices, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { ProfScope ps(ctx, "gather_digests", 64.0 * count);
+      hipLaunchKernelGGL(msscan::gather_records, dim3(stream_grid(count * 4)), dim3(msscan::NT), 0, ctx->stream,
+                         (const uint64_t*)d_digests, (const uint64_t*)d_idx, (uint64_t*)d_out, count, 4u); }
+    pool_free(ctx, d_idx);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
 }
 
 // ---------------------------------------------------------------------------------------

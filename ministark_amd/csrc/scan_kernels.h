@@ -1,0 +1,171 @@
+// Running products / running evaluations along a column, and row / digest gathers
+// (SURVEY.md 8(f) rank 4): the reference builds its extension columns with sequential host loops
+//     state = init;  for row: ext[row] = state;  state = a_row * state + b_row
+// (examples/brainfuck/trace.rs:108-289: permutation running products are the b = 0 case, the
+// input / output running evaluations state*gamma + value the general one, masked rows are the
+// identity map a = 1, b = 0) and reads query rows / authentication nodes back one by one
+// (src/trace.rs:115-157, src/merkle.rs:149-206).
+//
+// scan: the maps x -> a*x + b compose associatively, so the column is scanned in three launches:
+//   scan_reduce  one workgroup per 4096 rows: each lane composes its 16 consecutive maps, the
+//                workgroup composes the 256 lane maps in order -> one aggregate map per block
+//   scan_blocks  one workgroup walks the block aggregates -> the state at the start of every block
+//   scan_apply   per block: lane maps again, an in-order prefix over the 256 lanes gives every
+//                lane its incoming state, then the 16 rows are written
+// All arithmetic is exact field arithmetic: results equal the sequential loop bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.h"
+#include "gl_dev.h"
+#include "stage_kernels.h"
+
+namespace msscan {
+
+static constexpr int NT = 256;
+static constexpr int PER = 16;
+static constexpr int TILE = NT * PER;
+
+struct ScanParams {
+    const uint64_t* a;       // multipliers (nullptr: all one)
+    const uint64_t* b;       // addends     (nullptr: all zero)
+    uint64_t* out;
+    uint64_t* agg;           // [nblocks][2] elements: aggregate map of every block
+    uint64_t* block_state;   // [nblocks] elements: state at the start of every block
+    uint64_t init[3];
+    size_t n;
+    unsigned nblocks;
+    int inclusive;
+};
+
+template <class F> struct Map { typename F::T a, b; };
+
+template <class F> __device__ __forceinline__ typename F::T f_zero();
+template <> __device__ __forceinline__ uint64_t f_zero<msstage::FpT>() { return 0; }
+template <> __device__ __forceinline__ gl::Fq3 f_zero<msstage::Fq3T>() { return {0, 0, 0}; }
+
+// `l` first, then `r`:  x -> r.a*(l.a*x + l.b) + r.b
+template <class F, bool HAS_A, bool HAS_B>
+__device__ __forceinline__ Map<F> compose(const Map<F>& l, const Map<F>& r) {
+    Map<F> m;
+    m.a = HAS_A ? F::mul(r.a, l.a) : l.a;
+    if constexpr (HAS_B) m.b = HAS_A ? F::add(F::mul(r.a, l.b), r.b) : F::add(l.b, r.b);
+    else m.b = l.b;
+    return m;
+}
+template <class F, bool HAS_A, bool HAS_B>
+__device__ __forceinline__ typename F::T apply(const Map<F>& m, const typename F::T& x) {
+    typename F::T y = HAS_A ? F::mul(m.a, x) : x;
+    if constexpr (HAS_B) y = F::add(y, m.b);
+    return y;
+}
+template <class F> __device__ __forceinline__ Map<F> identity() { return {F::one(), f_zero<F>()}; }
+
+template <class F, bool HAS_A, bool HAS_B>
+__device__ __forceinline__ Map<F> load_map(const ScanParams& P, size_t i) {
+    Map<F> m = identity<F>();
+    if (i < P.n) {
+        if constexpr (HAS_A) m.a = F::load(P.a, i);
+        if constexpr (HAS_B) m.b = F::load(P.b, i);
+    }
+    return m;
+}
+
+// in-order inclusive scan of one map per lane across the workgroup (Hillis-Steele through LDS);
+// returns the inclusive result of this lane, *excl = composition of all lanes before it
+template <class F, bool HAS_A, bool HAS_B>
+__device__ __forceinline__ Map<F> wg_scan(Map<F> m, Map<F>* sh, Map<F>* excl) {
+    const unsigned t = threadIdx.x;
+    for (unsigned off = 1; off < (unsigned)NT; off <<= 1) {
+        sh[t] = m;
+        __syncthreads();
+        if (t >= off) m = compose<F, HAS_A, HAS_B>(sh[t - off], m);
+        __syncthreads();
+    }
+    sh[t] = m;
+    __syncthreads();
+    *excl = t ? sh[t - 1] : identity<F>();
+    __syncthreads();
+    return m;
+}
+
+template <class F, bool HAS_A, bool HAS_B>
+__global__ void __launch_bounds__(NT) scan_reduce(ScanParams P) {
+    __shared__ Map<F> sh[NT];
+    const size_t i0 = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * PER;
+    Map<F> m = load_map<F, HAS_A, HAS_B>(P, i0);
+    for (int j = 1; j < PER; j++) m = compose<F, HAS_A, HAS_B>(m, load_map<F, HAS_A, HAS_B>(P, i0 + j));
+    Map<F> excl;
+    m = wg_scan<F, HAS_A, HAS_B>(m, sh, &excl);
+    if (threadIdx.x == NT - 1) {
+        F::store(P.agg, 2 * (size_t)blockIdx.x, m.a);
+        F::store(P.agg, 2 * (size_t)blockIdx.x + 1, m.b);
+    }
+}
+
+// one workgroup: lane t walks blocks [t*chunk, (t+1)*chunk)
+template <class F, bool HAS_A, bool HAS_B>
+__global__ void __launch_bounds__(NT) scan_blocks(ScanParams P) {
+    __shared__ Map<F> sh[NT];
+    const unsigned chunk = (P.nblocks + NT - 1) / NT;
+    const unsigned b0 = threadIdx.x * chunk;
+    Map<F> m = identity<F>();
+    for (unsigned k = 0; k < chunk; k++) {
+        const unsigned blk = b0 + k;
+        if (blk < P.nblocks) m = compose<F, HAS_A, HAS_B>(m, Map<F>{F::load(P.agg, 2 * (size_t)blk), F::load(P.agg, 2 * (size_t)blk + 1)});
+    }
+    Map<F> excl;
+    wg_scan<F, HAS_A, HAS_B>(m, sh, &excl);
+    typename F::T s = apply<F, HAS_A, HAS_B>(excl, F::load(P.init, 0));
+    for (unsigned k = 0; k < chunk; k++) {
+        const unsigned blk = b0 + k;
+        if (blk >= P.nblocks) break;
+        F::store(P.block_state, blk, s);
+        s = apply<F, HAS_A, HAS_B>(Map<F>{F::load(P.agg, 2 * (size_t)blk), F::load(P.agg, 2 * (size_t)blk + 1)}, s);
+    }
+}
+
+template <class F, bool HAS_A, bool HAS_B>
+__global__ void __launch_bounds__(NT) scan_apply(ScanParams P) {
+    __shared__ Map<F> sh[NT];
+    const size_t i0 = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * PER;
+    Map<F> m = load_map<F, HAS_A, HAS_B>(P, i0);
+    for (int j = 1; j < PER; j++) m = compose<F, HAS_A, HAS_B>(m, load_map<F, HAS_A, HAS_B>(P, i0 + j));
+    Map<F> excl;
+    wg_scan<F, HAS_A, HAS_B>(m, sh, &excl);
+    typename F::T s = apply<F, HAS_A, HAS_B>(excl, F::load(P.block_state, blockIdx.x));
+    for (int j = 0; j < PER; j++) {
+        const size_t i = i0 + j;
+        if (i >= P.n) break;
+        const Map<F> mj = load_map<F, HAS_A, HAS_B>(P, i);      // second read (cache-resident); element i is read before it is written: in place is fine
+        if (!P.inclusive) F::store(P.out, i, s);
+        s = apply<F, HAS_A, HAS_B>(mj, s);
+        if (P.inclusive) F::store(P.out, i, s);
+    }
+}
+
+// ---- gathers ---------------------------------------------------------------------------------
+// out[p][c] = cols[c][pos[p]]  (row-major rows of the queried positions: Matrix::get_row, src/matrix.rs)
+struct GatherRowsParams {
+    const uint64_t* cols[msstage::MAXCOLS];
+    const uint64_t* pos;     // device
+    uint64_t* out;
+    size_t npos;
+    unsigned ncols, V;
+};
+__global__ void __launch_bounds__(NT) gather_rows(GatherRowsParams P) {
+    const size_t words_per_row = (size_t)P.ncols * P.V;
+    const size_t total = P.npos * words_per_row;
+    for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+        const size_t p = idx / words_per_row, w = idx % words_per_row;
+        const unsigned c = (unsigned)(w / P.V), v = (unsigned)(w % P.V);
+        P.out[idx] = P.cols[c][(size_t)P.pos[p] * P.V + v];
+    }
+}
+// out[k] = src[idx[k]] for records of `words` u64 words (Merkle digests: 4 words)
+__global__ void __launch_bounds__(NT) gather_records(const uint64_t* __restrict__ src, const uint64_t* __restrict__ idx, uint64_t* __restrict__ out, size_t count, unsigned words) {
+    const size_t total = count * words;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT)
+        out[i] = src[(size_t)idx[i / words] * words + i % words];
+}
+
+}  // namespace msscan

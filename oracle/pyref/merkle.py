@@ -38,3 +38,74 @@ def build_merkle_nodes(leaves):
 
 def merkle_root(leaves):
     return build_merkle_nodes(leaves)[1]
+
+
+def prove(leaves, nodes, indices):
+    """MerkleTreeImpl::prove (src/merkle.rs:149-206): the batched opening ("MerkleView") of the
+    sorted, de-duplicated `indices` -> dict(nodes, initial_leaves, sibling_leaves, height)."""
+    from collections import deque
+    num_leaves = len(leaves)
+    for i in indices:
+        if i >= num_leaves:
+            raise IndexError(f"leaf index {i} out of bounds ({num_leaves})")          # Error::LeafIndexOutOfBounds
+    idx = sorted(set(indices))
+    initial_leaves, sibling_leaves = [], []
+    node_queue = deque()
+    leaf_queue = deque(idx)
+    while leaf_queue:                                                               # merkle.rs:166-182
+        index = leaf_queue.popleft()
+        initial_leaves.append(leaves[index])
+        node_queue.append((num_leaves + index) >> 1)
+        if leaf_queue and (index ^ 1) == leaf_queue[0]:
+            initial_leaves.append(leaves[leaf_queue.popleft()])
+            continue
+        sibling_leaves.append(leaves[index ^ 1])
+    out_nodes = []
+    while node_queue:                                                               # merkle.rs:185-198
+        index = node_queue.popleft()
+        if index > 2:
+            node_queue.append(index >> 1)
+        if node_queue and (index ^ 1) == node_queue[0]:
+            node_queue.popleft()
+            continue
+        out_nodes.append(nodes[index ^ 1])
+    return {"nodes": out_nodes, "initial_leaves": initial_leaves, "sibling_leaves": sibling_leaves,
+            "height": num_leaves.bit_length() - 1}
+
+
+def verify(root, proof, indices):
+    """MerkleTreeImpl::verify (src/merkle.rs:208-287) with HashedLeafConfig (hash_leaves = hash_nodes =
+    SHA-256(l || r), src/merkle.rs:397-405).  Returns True iff the opening is consistent with `root`."""
+    from collections import deque
+    merge = lambda l, r: hashlib.sha256(l + r).digest()
+    height = proof["height"]
+    num_leaves = 1 << height
+    if any(i >= num_leaves for i in indices):
+        raise IndexError("leaf index out of bounds")
+    idx = sorted(set(indices))
+    node_queue = deque()
+    siblings = deque(proof["sibling_leaves"])
+    leaf_queue = deque(zip(idx, proof["initial_leaves"]))
+    while leaf_queue:
+        index, leaf = leaf_queue.popleft()
+        node_index = (num_leaves + index) >> 1
+        if leaf_queue and (index ^ 1) == leaf_queue[0][0]:
+            _, nxt = leaf_queue.popleft()
+            node_queue.append((node_index, merge(leaf, nxt)))
+            continue
+        sib = siblings.popleft()
+        node_queue.append((node_index, merge(leaf, sib) if index % 2 == 0 else merge(sib, leaf)))
+    assert not siblings
+    nodes = deque(proof["nodes"])
+    while node_queue:
+        index, h = node_queue.popleft()
+        if index.bit_length() - 1 == 0:
+            assert not node_queue
+            return h == root
+        if node_queue and (index ^ 1) == node_queue[0][0]:
+            _, nh = node_queue.popleft()
+            node_queue.append((index >> 1, merge(h, nh)))
+            continue
+        sib = nodes.popleft()
+        node_queue.append((index >> 1, merge(h, sib) if index % 2 == 0 else merge(sib, h)))
+    return True

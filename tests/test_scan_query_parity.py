@@ -1,0 +1,154 @@
+"""Extension-column scans, query-row gathers and batched Merkle openings
+against the oracle's sequential restatements, bit-exact.  Shapes follow the reference: running
+products with masked (padding) rows and running evaluations state*gamma + value
+(examples/brainfuck/trace.rs:108-289); Queries::new (src/trace.rs:113-157); MerkleTreeImpl::prove /
+verify and their tests (src/merkle.rs:149-287, 519-580: all leaves, single leaf, sibling pairs)."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle.pyref import merkle as omerkle
+from oracle.pyref import scan as oscan
+from oracle.pyref.fields import GL, FQ3
+from tests import backends
+from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3F, GpuVec, Matrix, MerkleTree, Queries, scan_affine, running_product
+
+KINDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _canon(arr, ext):
+    a = [GL.from_mont(int(x)) for x in arr]
+    return [tuple(a[3 * i:3 * i + 3]) for i in range(len(a) // 3)] if ext else a
+
+
+def _mont(vals, ext):
+    flat = [c for v in vals for c in v] if ext else vals
+    return np.array([GL.to_mont(c) for c in flat], dtype=np.uint64)
+
+
+def _scan_case(kind, n, ext, has_a, has_b, inclusive, seed, mask_every=3):
+    pl = backends.planner(kind)
+    V = 3 if ext else 1
+    a = cref.random_elements(n * V, seed) if has_a else None
+    b = cref.random_elements(n * V, seed + 1) if has_b else None
+    one = _mont([FQ3.one()] if ext else [1], ext)
+    # padding / non-matching rows leave the state unchanged: a = 1, b = 0 (trace.rs:134, :150-158)
+    for i in range(0, n, mask_every):
+        if a is not None:
+            a[V * i:V * i + V] = one
+        if b is not None:
+            b[V * i:V * i + V] = 0
+    init = cref.random_elements(V, seed + 2)
+    da = GpuVec.from_numpy(pl, a, FQ3F if ext else FP) if has_a else None
+    db = GpuVec.from_numpy(pl, b, FQ3F if ext else FP) if has_b else None
+    got = _canon(scan_affine(da, db, init, inclusive).to_numpy(), ext)
+    want = oscan.scan_affine(_canon(a, ext) if has_a else None, _canon(b, ext) if has_b else None,
+                             _canon(init, ext)[0], n, ext, inclusive)
+    assert got == want
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("n", [1, 5, 4096, 4097, 3 * 4096 + 17])
+@pytest.mark.parametrize("ext", [False, True])
+def test_running_product_masked(kind, n, ext):        # permutation columns, trace.rs:131-145
+    _scan_case(kind, n, ext, True, False, False, seed=n)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("ext", [False, True])
+@pytest.mark.parametrize("inclusive", [False, True])
+def test_running_evaluation(kind, ext, inclusive):     # input / output evaluation columns, trace.rs:147-159
+    _scan_case(kind, 9000, ext, True, True, inclusive, seed=7)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_running_sum_and_in_place(kind):
+    _scan_case(kind, 5000, True, False, True, True, seed=11)
+    pl = backends.planner(kind)
+    n = 6000
+    a = cref.random_elements(n, 3)
+    da = GpuVec.from_numpy(pl, a, FP)
+    init = cref.random_elements(1, 4)
+    L = pl.lib
+    L.check(L.ms_scan_affine(pl.handle, FP, n, da.ptr, None, init.ctypes.data, 0, da.ptr))      # out aliases a
+    assert _canon(da.to_numpy(), False) == oscan.scan_affine(_canon(a, False), None, _canon(init, False)[0], n)
+
+
+def test_scan_rejects_bad_arguments_emu():
+    pl = backends.planner("emu")
+    L = pl.lib
+    v = GpuVec(pl, 8, FP)
+    init = np.zeros(1, dtype=np.uint64)
+    assert L.ms_scan_affine(pl.handle, FP, 8, None, None, init.ctypes.data, 0, v.ptr) == -1
+    assert L.ms_scan_affine(pl.handle, 2, 8, v.ptr, None, init.ctypes.data, 0, v.ptr) == -2      # Fp252 not supported
+    assert L.ms_scan_affine(pl.handle, FP, 0, v.ptr, None, init.ctypes.data, 0, v.ptr) == 0
+
+
+@pytest.mark.gpu
+def test_running_product_2_22_hip():
+    pl = backends.planner("hip")
+    n = 1 << 22
+    a = cref.random_elements(3 * n, 21)
+    init = cref.random_elements(3, 22)
+    out = running_product(GpuVec.from_numpy(pl, a, FQ3F), init).to_numpy()
+    # the sequential loop on the last 70 000 rows, seeded with the device's own state there, plus the
+    # total product through a pairwise (different-order) reduction of the whole column
+    ca = _canon(a, True)
+    start = n - 70000
+    want = oscan.scan_affine(ca[start:], None, _canon(out[3 * start:3 * start + 3], True)[0], 70000, True)
+    assert _canon(out[3 * start:], True) == want
+    prod = ca[:]
+    while len(prod) > 1:
+        prod = [FQ3.mul(prod[2 * i], prod[2 * i + 1]) for i in range(len(prod) // 2)]
+    total = FQ3.mul(_canon(init, True)[0], prod[0])
+    last = FQ3.mul(_canon(out[3 * (n - 1):], True)[0], ca[n - 1])
+    assert last == total
+
+
+# ---- queries -------------------------------------------------------------------------------------
+def _tree(kind, log_n, ncols, ext=False, seed=5):
+    pl = backends.planner(kind)
+    n = 1 << log_n
+    V = 3 if ext else 1
+    cols = [cref.random_elements(n * V, seed + c) for c in range(ncols)]
+    m = Matrix.from_numpy(pl, cols, FQ3F if ext else FP)
+    tree = MerkleTree.from_matrix(m)
+    field = FQ3 if ext else GL
+    canon = [_canon(c, ext) for c in cols]
+    leaves = omerkle.hash_rows(field, canon)
+    nodes = omerkle.build_merkle_nodes(leaves)
+    return m, tree, cols, leaves, nodes
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("indices", [[0, 1, 2, 3, 4, 5, 6, 7], [3], [0, 7], [2, 3], [5, 4, 5, 1], [6, 1, 0]])
+def test_merkle_openings_small(kind, indices):          # src/merkle.rs:519-580
+    m, tree, cols, leaves, nodes = _tree(kind, 3, 2)
+    got = tree.prove(indices)
+    want = omerkle.prove(leaves, nodes, indices)
+    assert got == want
+    assert omerkle.verify(nodes[1], got, indices)
+    assert tree.root() == nodes[1]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_queries_rows_and_openings(kind):               # src/trace.rs:113-157
+    rng = np.random.default_rng(9)
+    mb, tb, cb, lb, nb = _tree(kind, 10, 5, False, seed=30)
+    me, te, ce, le, ne = _tree(kind, 10, 3, True, seed=40)
+    mc, tc, cc, lc, nc = _tree(kind, 10, 2, True, seed=50)
+    positions = [int(p) for p in rng.integers(0, 1 << 10, size=40)] + [0, 1023, 1022]
+    q = Queries(mb, me, mc, tb, te, tc, positions)
+    for rows, cols, V in ((q.base_trace_values, cb, 1), (q.extension_trace_values, ce, 3), (q.composition_trace_values, cc, 3)):
+        assert rows.shape == (len(positions), len(cols) * V)
+        for k, p in enumerate(positions):
+            assert list(rows[k]) == [int(x) for c in cols for x in c[V * p:V * p + V]]
+    for proof, leaves, nodes in ((q.base_trace_proof, lb, nb), (q.extension_trace_proof, le, ne), (q.composition_trace_proof, lc, nc)):
+        assert proof == omerkle.prove(leaves, nodes, positions)
+        assert omerkle.verify(nodes[1], proof, positions)
+    # a tampered opening must not verify
+    bad = dict(q.base_trace_proof)
+    bad["nodes"] = [bytes(32)] + bad["nodes"][1:]
+    assert not omerkle.verify(nb[1], bad, positions)
+    with pytest.raises(IndexError):
+        tb.prove([1 << 10])
