@@ -481,11 +481,18 @@ class Matrix:
         n = self.num_rows()
         log_n, log_b = n.bit_length() - 1, blowup.bit_length() - 1
         outs = [GpuVec(self.planner, n * blowup, self.field) for _ in self.columns]
-        off = ctypes.c_uint64(gl_to_mont(offset))
-        L.check(L.ms_lde(self.planner.handle, self.field, log_n, log_b, ctypes.byref(off),
+        off = _offset_words(self.field, offset)
+        L.check(L.ms_lde(self.planner.handle, self.field, log_n, log_b, off.ctypes.data,
                          _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
         self.planner.sync()
         return Matrix(outs)
+
+
+def _offset_words(field, offset):
+    """A domain offset (canonical int of the FFT field) as the Montgomery words the C ABI takes."""
+    if field == STARK252_FP:
+        return np.ascontiguousarray(f252_to_mont_limbs(offset % F252_P), dtype=np.uint64)
+    return np.array([gl_to_mont(offset % GL_P)], dtype=np.uint64)
 
 
 def scan_affine(a, b, init, inclusive=False):
@@ -530,9 +537,9 @@ def apply_drp(evals, alpha, folding_factor, domain_offset=1):
     out = GpuVec(pl, n // folding_factor, evals.field)
     al = np.ascontiguousarray(alpha, dtype=np.uint64).ravel()
     assert al.size == FIELD_WORDS[evals.field]
-    off = ctypes.c_uint64(gl_to_mont(domain_offset))
+    off = _offset_words(evals.field, domain_offset)
     pl.lib.check(pl.lib.ms_fri_fold(pl.handle, evals.field, n.bit_length() - 1, folding_factor, al.ctypes.data,
-                                    ctypes.byref(off), evals.ptr, out.ptr))
+                                    off.ctypes.data, evals.ptr, out.ptr))
     return out
 
 

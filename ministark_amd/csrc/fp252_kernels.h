@@ -82,4 +82,49 @@ __global__ void __launch_bounds__(NT) ntt252_stage(Params P) {
     st(P.col, hi, b);
 }
 
+// FRI degree-respecting projection over Fp252: apply_drp (src/fri.rs:526-567) collapsed exactly as in
+// fri_kernels.h -- out[c] = sum_k (alpha / x_i)^k * A_k with A = the size-ff inverse DFT of the ff
+// contiguous (bit-reversed) evaluations of chunk c, i = bitrev(c).  The field has no power-of-two
+// roots, so the small DFT is a plain radix-2 DIT with the ff/2 twiddles handed over by the host.
+struct Fold252Params {
+    const uint64_t* src;
+    uint64_t* dst;
+    const uint64_t* tw_lo;      // w_n^(-i) two-level table of the size-n inverse plan
+    const uint64_t* tw_hi;
+    unsigned lo_bits, log_m;    // log_m = log2(number of chunks)
+    uint64_t hinv[4];           // h^-1
+    uint64_t alpha[4];
+    uint64_t zinv[8][4];        // (w_n^(-n/ff))^k, k < ff/2
+};
+template <int FF>
+__global__ void __launch_bounds__(NT) fri_fold252(Fold252Params P) {
+    constexpr int LOGF = FF == 2 ? 1 : FF == 4 ? 2 : FF == 8 ? 3 : 4;
+    const size_t c = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (c >> P.log_m) return;
+    const size_t i = P.log_m ? (size_t)(__brevll((unsigned long long)c) >> (64 - P.log_m)) : 0;
+    const f252::E xinv = f252::mul(pow2l(P.tw_lo, P.tw_hi, P.lo_bits, i), f252::E{{P.hinv[0], P.hinv[1], P.hinv[2], P.hinv[3]}});
+    f252::E A[FF];
+    #pragma unroll
+    for (int q = 0; q < FF; q++) A[q] = ld(P.src, c * FF + q);
+    #pragma unroll
+    for (int s = 1; s <= LOGF; s++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int half = 1 << (s - 1);
+        #pragma unroll
+        for (int q = 0; q < FF / 2; q++) {
+            const int k = q & (half - 1), lo = ((q >> (s - 1)) << s) + k, hi = lo + half;
+            const int e = k << (LOGF - s);
+            const f252::E t = e ? f252::mul(A[hi], f252::E{{P.zinv[e][0], P.zinv[e][1], P.zinv[e][2], P.zinv[e][3]}}) : A[hi];
+            const f252::E u = A[lo];
+            A[lo] = f252::add(u, t);
+            A[hi] = f252::sub(u, t);
+        }
+    }
+    const f252::E beta = f252::mul(f252::E{{P.alpha[0], P.alpha[1], P.alpha[2], P.alpha[3]}}, xinv);
+    f252::E acc = A[FF - 1];
+    #pragma unroll
+    for (int k = FF - 2; k >= 0; k--) acc = f252::add(f252::mul(acc, beta), A[k]);
+    st(P.dst, c, acc);
+}
+
 }  // namespace ms252

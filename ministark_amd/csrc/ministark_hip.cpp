@@ -690,8 +690,32 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
     if (!ctx || !d_in || !d_out) return fail(MS_ERR_INVALID, "ms_lde: null argument");
     unsigned V = 0;
     MSCHK(field_words(field, &V));
-    if (V == 4) return fail(MS_ERR_UNSUPPORTED, "fused LDE is not implemented for Fp252 (use two plans + ms_bit_reverse)");
     const unsigned log_N = log_n + log_blowup;
+    if (V == 4) {
+        // compute-bound field: iNTT into the head of the output column, explicit zero padding, coset NTT,
+        // bit reversal -- the plain sequence (the fused / pruned passes are Goldilocks kernels)
+        if (log_N > 40) return fail(MS_ERR_INVALID, "LDE domain 2^%u too large", log_N);
+        f252::E h252 = f252::one();
+        if (h_offset) memcpy(h252.l, h_offset, 32);
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ms_ntt_plan *inv = nullptr, *fwd = nullptr;
+        uint64_t hkey = 1469598103934665603ull;                  // cache key of the forward plan: a hash of the offset
+        for (int w = 0; w < 4; w++) { hkey ^= h252.l[w]; hkey *= 1099511628211ull; }
+        hkey |= (uint64_t)1 << 63;
+        for (auto& kv : ctx->plan_cache) {
+            if (kv.first.V == 4 && kv.first.log_n == log_n && kv.first.inverse && kv.first.h == 1) inv = kv.second;
+            if (kv.first.V == 4 && kv.first.log_n == log_N && !kv.first.inverse && kv.first.h == hkey) fwd = kv.second;
+        }
+        if (!inv) { MSCHK(plan_build252(ctx, log_n, true, nullptr, nullptr, &inv)); ctx->plan_cache.push_back({PlanKey{4, log_n, true, 1}, inv}); }
+        if (!fwd) { MSCHK(plan_build252(ctx, log_N, false, h252.l, nullptr, &fwd)); ctx->plan_cache.push_back({PlanKey{4, log_N, false, hkey}, fwd}); }
+        MSCHK(plan_run252(inv, d_in, d_out, ncols));
+        const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
+        if (N > n)
+            for (unsigned c = 0; c < ncols; c++) HIPCHK(hipMemsetAsync((char*)d_out[c] + n * 32, 0, (N - n) * 32, ctx->stream));
+        MSCHK(plan_run252(fwd, (const void* const*)d_out, d_out, ncols));
+        if (bit_reversed) MSCHK(bit_reverse_run(ctx, 4, log_N, (const void* const*)d_out, d_out, ncols));
+        return MS_OK;
+    }
     if (log_N > 32) return fail(MS_ERR_INVALID, "LDE domain 2^%u exceeds the two-adicity", log_N);
     uint64_t h = 1;
     if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
@@ -962,12 +986,42 @@ extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned fold
     if (!ctx || !h_alpha || !d_evals || !d_out) return fail(MS_ERR_INVALID, "ms_fri_fold: null argument");
     unsigned V = 0;
     MSCHK(field_words(field, &V));
-    if (V == 4) return fail(MS_ERR_UNSUPPORTED, "FRI fold is not implemented for Fp252");
     if (folding_factor != 2 && folding_factor != 4 && folding_factor != 8 && folding_factor != 16)
         return fail(MS_ERR_UNSUPPORTED, "folding factor %u not supported (2, 4, 8, 16)", folding_factor);   // src/fri.rs:186-192
     unsigned log_ff = 0;
     while ((1u << log_ff) < folding_factor) log_ff++;
     if (log_n < log_ff || log_n > 32) return fail(MS_ERR_INVALID, "bad layer size 2^%u for folding factor %u", log_n, folding_factor);
+    if (V == 4) {
+        f252::E h252 = f252::one();
+        if (h_offset) memcpy(h252.l, h_offset, 32);
+        if (f252::is_zero(h252) || f252::geq_p(h252)) return fail(MS_ERR_INVALID, "domain offset must be a non-zero canonical element");
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIPCHK(hipSetDevice(ctx->device));
+        ms_ntt_plan* plan = nullptr;
+        for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_n && kv.first.inverse && kv.first.h == 1) plan = kv.second;
+        if (!plan) { MSCHK(plan_build252(ctx, log_n, true, nullptr, nullptr, &plan)); ctx->plan_cache.push_back({PlanKey{4, log_n, true, 1}, plan}); }
+        ms252::Fold252Params P;
+        memset(&P, 0, sizeof P);
+        P.src = (const uint64_t*)d_evals; P.dst = (uint64_t*)d_out;
+        P.tw_lo = plan->d252_tw_lo; P.tw_hi = plan->d252_tw_hi; P.lo_bits = plan->lo_bits; P.log_m = log_n - log_ff;
+        const f252::E hinv = f252::inv(h252);
+        memcpy(P.hinv, hinv.l, 32);
+        memcpy(P.alpha, h_alpha, 32);
+        const f252::E zinv = f252::pow_u64(f252::inv(f252::root_of_unity(log_n)), (uint64_t)1 << (log_n - log_ff));
+        f252::E zp = f252::one();
+        for (unsigned k = 0; k < folding_factor / 2; k++) { memcpy(P.zinv[k], zp.l, 32); zp = f252::mul(zp, zinv); }
+        const size_t m = (size_t)1 << (log_n - log_ff);
+        dim3 g((unsigned)((m + ms252::NT - 1) / ms252::NT));
+        ProfScope ps(ctx, "fri_fold252", 32.0 * (((size_t)1 << log_n) + m));
+        switch (folding_factor) {
+        case 2: hipLaunchKernelGGL(ms252::fri_fold252<2>, g, dim3(ms252::NT), 0, ctx->stream, P); break;
+        case 4: hipLaunchKernelGGL(ms252::fri_fold252<4>, g, dim3(ms252::NT), 0, ctx->stream, P); break;
+        case 8: hipLaunchKernelGGL(ms252::fri_fold252<8>, g, dim3(ms252::NT), 0, ctx->stream, P); break;
+        default: hipLaunchKernelGGL(ms252::fri_fold252<16>, g, dim3(ms252::NT), 0, ctx->stream, P); break;
+        }
+        HIPCHK(hipGetLastError());
+        return MS_OK;
+    }
     uint64_t h = 1;
     if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
     if (h == 0) return fail(MS_ERR_INVALID, "domain offset must be non-zero");

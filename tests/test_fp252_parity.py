@@ -111,3 +111,31 @@ def test_roundtrip_2_16_252_hip():
     assert not np.array_equal(v.to_numpy(), x)
     g = GpuIfft(dom, STARK252_FP, pl); g.encode(v); g.execute()
     assert np.array_equal(v.to_numpy(), x)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("log_n,blowup", [(4, 2), (6, 8), (11, 4)])
+def test_lde_252(kind, log_n, blowup):                  # interpolate + bit_reversed_evaluate, src/prover.rs:50-51
+    pl = backends.planner(kind)
+    n = 1 << log_n
+    cols = [_rand_canon(n, 10 + c) for c in range(2)]
+    m = Matrix([_to_dev(pl, c) for c in cols])
+    out = m.lde(blowup, 3, True)
+    for c in range(2):
+        assert _from_dev(out.columns[c]) == pyntt.lde_bit_reversed(F.F252, cols[c], blowup, 3)
+    nat = m.lde(blowup, 5, False)
+    assert _from_dev(nat.columns[0]) == F.bit_reverse(pyntt.lde_bit_reversed(F.F252, cols[0], blowup, 5))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("ff", [2, 4, 8, 16])
+@pytest.mark.parametrize("offset", [1, 3])
+def test_fri_fold_252(kind, ff, offset):                # apply_drp, src/fri.rs:526-567
+    from oracle.pyref import fri as ofri
+    from ministark_amd import apply_drp
+    pl = backends.planner(kind)
+    n = 256
+    evals = _rand_canon(n, 20 + ff)
+    alpha = _rand_canon(1, 99)[0]
+    got = _from_dev(apply_drp(_to_dev(pl, evals), f252_to_mont_limbs(alpha), ff, offset))
+    assert got == ofri.apply_drp(F.F252, None, evals, offset, alpha, ff)
