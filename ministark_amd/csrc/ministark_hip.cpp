@@ -797,6 +797,11 @@ extern "C" int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leave
     const uint8_t* src = (const uint8_t*)d_leaves;
     for (size_t count = nleaves / 2; count >= 1; count >>= 1) {
         uint8_t* dst = nodes + count * 32;
+        if (count <= (size_t)mssha::NT) {                        // the remaining levels in one launch
+            ProfScope ps(ctx, "sha256_merkle_top", 96.0 * (2 * count - 1));
+            hipLaunchKernelGGL(mssha::sha256_merkle_top, dim3(1), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
+            break;
+        }
         ProfScope ps(ctx, "sha256_merkle_level", 96.0 * count);
         hipLaunchKernelGGL(mssha::sha256_merge_level, dim3((unsigned)((count + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, src, dst, count);
         src = dst;

@@ -168,6 +168,47 @@ __global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* __restri
     out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
 }
 
+// The top of the tree in ONE launch: levels of <= 256 parents are latency-bound as separate launches
+// (nine launches for the last 511 nodes).  One workgroup keeps the current level in LDS, every
+// level is also written to its slot of nodes[].  `src` holds 2*count digests, count <= 256.
+__global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __restrict__ src, uint8_t* __restrict__ nodes, unsigned count) {
+    __shared__ uint32_t lvl[2][NT * 8];
+    const unsigned t = threadIdx.x;
+    Sha s;
+    if (t < count) {
+        s.init();
+        const uint4* in = (const uint4*)(src + (size_t)t * 64);
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = in[q];
+            s.w[4 * q] = bswap32(v.x); s.w[4 * q + 1] = bswap32(v.y); s.w[4 * q + 2] = bswap32(v.z); s.w[4 * q + 3] = bswap32(v.w);
+        }
+        s.compress();
+        s.compress_pad64();
+    }
+    int cur = 0;
+    for (;;) {
+        if (t < count) {
+            uint4* out = (uint4*)(nodes + ((size_t)count + t) * 32);
+            out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
+            out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
+            #pragma unroll
+            for (int q = 0; q < 8; q++) lvl[cur][t * 8 + q] = s.h[q];         // big-endian words, ready for the next schedule
+        }
+        if (count == 1) break;
+        __syncthreads();
+        count >>= 1;
+        if (t < count) {
+            #pragma unroll
+            for (int q = 0; q < 16; q++) s.w[q] = lvl[cur][t * 16 + q];
+            s.init();
+            s.compress();
+            s.compress_pad64();
+        }
+        cur ^= 1;
+    }
+}
+
 // Proof-of-work grinding: PublicCoin::grind_proof_of_work (src/random.rs:48-55)
 // = the smallest nonce >= 1 with leading_zeros(SHA-256(seed || nonce.to_be_bytes())) >= bits
 // (verify_proof_of_work src/random.rs:129-132, merge_with_int src/hash.rs:84-89, leading_zeros :181-192).
