@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
     newest = max(os.path.getmtime(p) for p in _deps())
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO, "-lhiprtc"]
+    cmd = [HIPCC] + FLAGS + os.environ.get("MS_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO, "-lhiprtc"]
     if verbose:
         print("[ministark_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

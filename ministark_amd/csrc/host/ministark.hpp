@@ -8,10 +8,14 @@
 //   Radix2EvaluationDomain           ark-poly, as consumed at gpu/src/plan.rs:386-423
 //   GpuFft<F> / GpuIfft<F>           gpu/src/plan.rs:236-325
 //   Matrix<F>                        src/matrix.rs:26-394
-//   MerkleTree                       src/merkle.rs:296-361 (MatrixMerkleTreeImpl<Sha256HashFn>)
+//   MerkleTree                       src/merkle.rs:296-361 (MatrixMerkleTreeImpl<Sha256HashFn>), prove :149-206
+// stages.hpp: the 17 element-wise stages; expr.hpp: constraint DAG -> program -> eval; prover.hpp: FRI fold,
+// DEEP composer, extension-column scans, queries, proof-of-work, RPO front-ends.
 // Header-only; needs no HIP headers, link with -lministark_hip.
 #pragma once
+#include <algorithm>
 #include <array>
+#include <deque>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -67,7 +71,7 @@ public:
         check(ms_download(pl_->ctx(), h.data(), ptr_, h.size() * 8));
         return h;
     }
-    GpuVec clone() const { GpuVec c(*pl_, n_); c.upload(to_host()); return c; }
+    GpuVec clone() const { GpuVec c(*pl_, n_); check(ms_copy(pl_->ctx(), c.ptr_, ptr_, n_ * F::words * 8)); return c; }   // device copy
 private:
     Planner* pl_; size_t n_; void* ptr_ = nullptr;
 };
@@ -157,6 +161,20 @@ public:
         planner().sync();
         return dst;
     }
+    // Matrix::get_row for every queried position (src/trace.rs:139-152): row-major [positions][num_cols * words]
+    std::vector<uint64_t> get_rows(const std::vector<uint64_t>& positions) const {
+        const size_t words = num_cols() * F::words;
+        std::vector<uint64_t> out(positions.size() * words);
+        if (out.empty()) return out;
+        void* d = nullptr;
+        check(ms_alloc(planner().ctx(), out.size() * 8, &d));
+        std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
+        int rc = ms_gather_rows(planner().ctx(), F::id, num_rows(), in.data(), (unsigned)in.size(), positions.data(), positions.size(), d);
+        if (rc == MS_OK) rc = ms_download(planner().ctx(), out.data(), d, out.size() * 8);
+        ms_free(planner().ctx(), d);
+        check(rc);
+        return out;
+    }
     std::vector<void*> ptrs() const { std::vector<void*> p; for (auto& c : columns) p.push_back(c.ptr()); return p; }
 };
 
@@ -170,6 +188,48 @@ public:
         check(ms_sha256_merkle(t.pl_->ctx(), t.n_, t.leaves_, t.nodes_));
         return t;
     }
+    // Matrix::from_arrays(evaluations.as_chunks::<N>()) + from_matrix (src/fri.rs:213-216): commit to a bit-reversed
+    // FRI layer whose rows are the cosets of `folding_factor` consecutive evaluations
+    template <class F>
+    static MerkleTree from_fri_layer(const GpuVec<F>& evaluations, unsigned folding_factor) {
+        MerkleTree t(evaluations.planner(), evaluations.len() / folding_factor);
+        check(ms_sha256_rows_row_major(t.pl_->ctx(), F::id, t.n_, folding_factor, evaluations.ptr(), t.leaves_));
+        check(ms_sha256_merkle(t.pl_->ctx(), t.n_, t.leaves_, t.nodes_));
+        return t;
+    }
+    using Digest = std::array<uint8_t, 32>;
+    struct MerkleView { std::vector<Digest> nodes, initial_leaves, sibling_leaves; unsigned height = 0; };   // src/merkle.rs:72-84
+    // MerkleTreeImpl::prove (src/merkle.rs:149-206): the walk over indices is bookkeeping, the digests it lists
+    // are gathered on the device and come back in one copy per array
+    MerkleView prove(std::vector<size_t> indices) const {
+        for (size_t i : indices) if (i >= n_) throw std::out_of_range("leaf index out of bounds");          // Error::LeafIndexOutOfBounds
+        std::sort(indices.begin(), indices.end());
+        indices.erase(std::unique(indices.begin(), indices.end()), indices.end());
+        std::vector<uint64_t> leaf_ids, node_ids;
+        std::vector<size_t> initial, sibling;
+        std::deque<size_t> node_queue, leaf_queue(indices.begin(), indices.end());
+        while (!leaf_queue.empty()) {
+            const size_t index = leaf_queue.front(); leaf_queue.pop_front();
+            initial.push_back(leaf_ids.size()); leaf_ids.push_back(index);
+            node_queue.push_back((n_ + index) >> 1);
+            if (!leaf_queue.empty() && (index ^ 1) == leaf_queue.front()) { initial.push_back(leaf_ids.size()); leaf_ids.push_back(leaf_queue.front()); leaf_queue.pop_front(); continue; }
+            sibling.push_back(leaf_ids.size()); leaf_ids.push_back(index ^ 1);
+        }
+        while (!node_queue.empty()) {
+            const size_t index = node_queue.front(); node_queue.pop_front();
+            if (index > 2) node_queue.push_back(index >> 1);
+            if (!node_queue.empty() && (index ^ 1) == node_queue.front()) { node_queue.pop_front(); continue; }
+            node_ids.push_back(index ^ 1);
+        }
+        const std::vector<Digest> leaves = gather(leaves_, leaf_ids), nodes = gather(nodes_, node_ids);
+        MerkleView v;
+        v.nodes = nodes;
+        for (size_t k : initial) v.initial_leaves.push_back(leaves[k]);
+        for (size_t k : sibling) v.sibling_leaves.push_back(leaves[k]);
+        while (((size_t)1 << v.height) < n_) v.height++;
+        return v;
+    }
+    size_t num_leaves() const { return n_; }
     std::array<uint8_t, 32> root() const {                              // nodes[1], src/merkle.rs:145-147
         std::array<uint8_t, 32> r{};
         check(ms_download(pl_->ctx(), r.data(), (const char*)nodes_ + 32, 32));
@@ -179,6 +239,17 @@ public:
     MerkleTree(MerkleTree&& o) noexcept : pl_(o.pl_), n_(o.n_), leaves_(o.leaves_), nodes_(o.nodes_) { o.leaves_ = o.nodes_ = nullptr; }
 private:
     MerkleTree(Planner& pl, size_t n) : pl_(&pl), n_(n) { check(ms_alloc(pl.ctx(), n * 32, &leaves_)); check(ms_alloc(pl.ctx(), n * 32, &nodes_)); }
+    std::vector<Digest> gather(const void* digests, const std::vector<uint64_t>& ids) const {
+        std::vector<Digest> out(ids.size());
+        if (ids.empty()) return out;
+        void* d = nullptr;
+        check(ms_alloc(pl_->ctx(), ids.size() * 32, &d));
+        int rc = ms_gather_digests(pl_->ctx(), n_, digests, ids.data(), ids.size(), d);
+        if (rc == MS_OK) rc = ms_download(pl_->ctx(), out.data(), d, ids.size() * 32);
+        ms_free(pl_->ctx(), d);
+        check(rc);
+        return out;
+    }
     Planner* pl_; size_t n_; void* leaves_ = nullptr; void* nodes_ = nullptr;
 };
 

@@ -1,0 +1,181 @@
+// prover.hpp -- the remaining data-parallel pieces of default_prove (src/prover.rs:25-174) over the C ABI:
+//   apply_drp                         src/fri.rs:526-567
+//   DeepPolyComposer                  src/composer.rs:17-188
+//   scan_affine / running_product     examples/brainfuck/trace.rs:108-289 (extension-column loops)
+//   Queries                           src/trace.rs:113-157
+//   grind_proof_of_work               src/random.rs:48-55
+//   GpuRpo256ColumnMajor / RowMajor / gen_rpo_merkle_tree   gpu/src/plan.rs:32-174
+// Host values of Fq are canonical integers: FqVal{c0,c1,c2} (c1 = c2 = 0 when Fq = Fp).
+#pragma once
+#include "ministark.hpp"
+
+namespace ms {
+
+struct FqVal {
+    uint64_t c[3] = {0, 0, 0};
+    bool operator==(const FqVal& o) const { return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2]; }
+    bool operator<(const FqVal& o) const { return std::lexicographical_compare(c, c + 3, o.c, o.c + 3); }
+};
+namespace fq {          // Fq3 = Fp[x]/(x^3 - 2) on canonical values: bookkeeping of evaluation points only
+inline uint64_t addp(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % gl::P); }
+inline FqVal mul(const FqVal& a, const FqVal& b) {
+    auto m = gl::mul;
+    return {{addp(m(a.c[0], b.c[0]), m(2, addp(m(a.c[1], b.c[2]), m(a.c[2], b.c[1])))),
+             addp(addp(m(a.c[0], b.c[1]), m(a.c[1], b.c[0])), m(2, m(a.c[2], b.c[2]))),
+             addp(addp(m(a.c[0], b.c[2]), m(a.c[1], b.c[1])), m(a.c[2], b.c[0]))}};
+}
+inline FqVal mul_base(const FqVal& a, uint64_t s) { return {{gl::mul(a.c[0], s), gl::mul(a.c[1], s), gl::mul(a.c[2], s)}}; }
+inline FqVal pow(FqVal a, uint64_t e) { FqVal r{{1, 0, 0}}; while (e) { if (e & 1) r = mul(r, a); a = mul(a, a); e >>= 1; } return r; }
+template <class F> inline void push_words(std::vector<uint64_t>& out, const FqVal& v) { for (unsigned w = 0; w < F::words; w++) out.push_back(gl::to_mont(v.c[w])); }
+inline uint64_t from_mont(uint64_t m) { return gl::mul(m, gl::pow(0xFFFFFFFFull, gl::P - 2)); }
+template <class F> inline FqVal from_words(const uint64_t* w) { FqVal v; for (unsigned k = 0; k < F::words; k++) v.c[k] = from_mont(w[k]); return v; }
+}  // namespace fq
+
+// apply_drp(evals, domain_offset, alpha, folding_factor): `evals` in bit-reversed order; returns the next layer
+// (bit-reversed).  alpha: Montgomery words of one element of F.
+template <class F>
+inline GpuVec<F> apply_drp(const GpuVec<F>& evals, const std::vector<uint64_t>& alpha, unsigned folding_factor, uint64_t domain_offset = 1) {
+    if (alpha.size() != F::words) throw std::invalid_argument("alpha has the wrong number of limbs");
+    GpuVec<F> out(evals.planner(), evals.len() / folding_factor);
+    unsigned log_n = 0; while (((size_t)1 << log_n) < evals.len()) log_n++;
+    const uint64_t off = gl::to_mont(domain_offset);
+    check(ms_fri_fold(evals.planner().ctx(), F::id, log_n, folding_factor, alpha.data(), &off, evals.ptr(), out.ptr()));
+    return out;
+}
+
+// state = init; for every row: out[row] = state; state = a[row]*state + b[row]   (a or b may be null)
+template <class F>
+inline GpuVec<F> scan_affine(const GpuVec<F>* a, const GpuVec<F>* b, const std::vector<uint64_t>& init, bool inclusive = false) {
+    const GpuVec<F>* ref = a ? a : b;
+    if (!ref) throw std::invalid_argument("scan_affine: neither multipliers nor addends given");
+    if (init.size() != F::words) throw std::invalid_argument("init has the wrong number of limbs");
+    GpuVec<F> out(ref->planner(), ref->len());
+    check(ms_scan_affine(ref->planner().ctx(), F::id, ref->len(), a ? a->ptr() : nullptr, b ? b->ptr() : nullptr, init.data(), inclusive ? 1 : 0, out.ptr()));
+    return out;
+}
+template <class F> inline GpuVec<F> running_product(const GpuVec<F>& factors, const std::vector<uint64_t>& init) { return scan_affine<F>(&factors, nullptr, init); }
+
+// Queries::new: rows of the three LDE matrices at the query positions + batched openings of the three trees
+template <class FqT>
+struct Queries {
+    std::vector<uint64_t> base_trace_values, extension_trace_values, composition_trace_values;
+    MerkleTree::MerkleView base_trace_proof, extension_trace_proof, composition_trace_proof;
+    Queries(const Matrix<Fp>& base_lde, const Matrix<FqT>* extension_lde, const Matrix<FqT>& composition_lde,
+            const MerkleTree& base_tree, const MerkleTree* extension_tree, const MerkleTree& composition_tree, const std::vector<size_t>& positions) {
+        std::vector<uint64_t> pos(positions.begin(), positions.end());
+        base_trace_proof = base_tree.prove(positions);
+        if (extension_tree) extension_trace_proof = extension_tree->prove(positions);
+        composition_trace_proof = composition_tree.prove(positions);
+        base_trace_values = base_lde.get_rows(pos);
+        if (extension_lde) extension_trace_values = extension_lde->get_rows(pos);
+        composition_trace_values = composition_lde.get_rows(pos);
+    }
+};
+
+// PublicCoin::grind_proof_of_work(bits): the smallest nonce >= 1 with `bits` leading zero bits of SHA-256(seed || nonce_be)
+inline uint64_t grind_proof_of_work(Planner& pl, const std::array<uint8_t, 32>& seed, unsigned proof_of_work_bits, uint64_t max_nonce = (uint64_t)1 << 40) {
+    uint64_t nonce = 0;
+    check(ms_sha256_pow_grind(pl.ctx(), seed.data(), proof_of_work_bits, max_nonce, &nonce));
+    return nonce;
+}
+
+// DeepPolyComposer::new(air, z, base_trace_polys, extension_trace_polys, composition_trace_polys)
+// trace_arguments: the AIR's (column, offset) pairs (air.trace_arguments()).  Polynomials are coefficient-form
+// matrices on the device (what interpolate / into_polynomials return).  FqT = Fq3 or Fp (Fq = Fp AIRs).
+struct DeepCompositionCoeffs { std::vector<FqVal> execution_trace, composition_trace; FqVal degree[2]; };   // src/composer.rs:191-198
+template <class FqT>
+class DeepPolyComposer {
+public:
+    DeepPolyComposer(std::vector<std::pair<unsigned, int>> trace_arguments, size_t trace_len, FqVal z, const Matrix<Fp>& base_polys,
+                     const Matrix<FqT>* extension_polys, const Matrix<FqT>& composition_polys)
+        : args_(std::move(trace_arguments)), n_(trace_len), z_(z), base_(base_polys), ext_(extension_polys), comp_(composition_polys) {
+        Radix2EvaluationDomain d(trace_len);
+        g_ = d.group_gen; g_inv_ = gl::pow(g_, gl::P - 2);
+        nbase_ = (unsigned)base_.num_cols();
+    }
+    // -> (execution trace values in trace_arguments order, composition trace values)   src/composer.rs:43-86
+    std::pair<std::vector<FqVal>, std::vector<FqVal>> get_ood_evals() {
+        std::vector<unsigned> bq_col, eq_col; std::vector<FqVal> bq_pt, eq_pt;
+        for (auto& a : args_) { if (a.first < nbase_) { bq_col.push_back(a.first); bq_pt.push_back(point(a.second)); } else { eq_col.push_back(a.first - nbase_); eq_pt.push_back(point(a.second)); } }
+        const auto bv = horner(base_, bq_col, bq_pt);
+        const auto ev = ext_ ? horner(*ext_, eq_col, eq_pt) : std::vector<FqVal>{};
+        size_t bi = 0, ei = 0;
+        std::vector<FqVal> execution;
+        for (auto& a : args_) execution.push_back(a.first < nbase_ ? bv[bi++] : ev[ei++]);
+        const FqVal z_n = fq::pow(z_, comp_.num_cols());
+        std::vector<unsigned> cc; std::vector<FqVal> cp;
+        for (unsigned c = 0; c < comp_.num_cols(); c++) { cc.push_back(c); cp.push_back(z_n); }
+        ood_exec_ = execution; ood_comp_ = horner(comp_, cc, cp); have_ood_ = true;
+        return {ood_exec_, ood_comp_};
+    }
+    GpuVec<FqT> into_deep_poly(const DeepCompositionCoeffs& coeffs) {           // src/composer.rs:89-188
+        if (!have_ood_) get_ood_evals();
+        Planner& pl = base_.planner();
+        std::vector<FqVal> points;
+        auto pid = [&](const FqVal& p) { for (size_t k = 0; k < points.size(); k++) if (points[k] == p) return (unsigned)k; points.push_back(p); return (unsigned)points.size() - 1; };
+        const FqVal z_n = fq::pow(z_, comp_.num_cols());
+        const unsigned next = ext_ ? (unsigned)ext_->num_cols() : 0;
+        std::vector<unsigned> tcol, tpoint; std::vector<FqVal> talpha, tood;
+        for (unsigned c = 0; c < comp_.num_cols(); c++) { tcol.push_back(nbase_ + next + c); tpoint.push_back(pid(z_n)); talpha.push_back(coeffs.composition_trace.at(c)); tood.push_back(ood_comp_[c]); }
+        for (size_t k = 0; k < args_.size(); k++) { tcol.push_back(args_[k].first); tpoint.push_back(pid(point(args_[k].second))); talpha.push_back(coeffs.execution_trace.at(k)); tood.push_back(ood_exec_[k]); }
+        std::vector<const void*> bp, ep;
+        for (auto& c : base_.columns) bp.push_back(c.ptr());
+        auto& second = FqT::words == 1 ? bp : ep;                    // Fq = Fp: everything is a base column
+        if (ext_) for (auto& c : ext_->columns) second.push_back(c.ptr());
+        for (auto& c : comp_.columns) second.push_back(c.ptr());
+        auto flat = [](const std::vector<FqVal>& v) { std::vector<uint64_t> o; for (auto& q : v) fq::push_words<FqT>(o, q); return o; };
+        const auto pts = flat(points), al = flat(talpha), od = flat(tood), da = flat({coeffs.degree[0]}), db = flat({coeffs.degree[1]});
+        GpuVec<FqT> out(pl, n_);
+        unsigned log_n = 0; while (((size_t)1 << log_n) < n_) log_n++;
+        check(ms_deep_compose(pl.ctx(), FqT::id, log_n, nullptr, bp.empty() ? nullptr : bp.data(), (unsigned)bp.size(), ep.empty() ? nullptr : ep.data(), (unsigned)ep.size(),
+                              pts.data(), (unsigned)points.size(), tcol.data(), tpoint.data(), al.data(), od.data(), (unsigned)tcol.size(), da.data(), db.data(), out.ptr()));
+        pl.sync();
+        return out;
+    }
+private:
+    FqVal point(int offset) const { return fq::mul_base(z_, gl::pow(offset >= 0 ? g_ : g_inv_, (uint64_t)(offset >= 0 ? offset : -offset))); }
+    template <class CF>
+    std::vector<FqVal> horner(const Matrix<CF>& m, const std::vector<unsigned>& qcol, const std::vector<FqVal>& qpt) {
+        std::vector<FqVal> res;
+        if (qcol.empty()) return res;
+        std::vector<uint64_t> pts, out(qcol.size() * FqT::words);
+        for (auto& p : qpt) fq::push_words<FqT>(pts, p);
+        std::vector<const void*> in; for (auto& c : m.columns) in.push_back(c.ptr());
+        check(ms_horner_eval(m.planner().ctx(), CF::id, FqT::id, m.num_rows(), in.data(), (unsigned)in.size(), qcol.data(), pts.data(), (unsigned)qcol.size(), out.data()));
+        for (size_t k = 0; k < qcol.size(); k++) res.push_back(fq::from_words<FqT>(&out[k * FqT::words]));
+        return res;
+    }
+    std::vector<std::pair<unsigned, int>> args_;
+    size_t n_; FqVal z_; const Matrix<Fp>& base_; const Matrix<FqT>* ext_; const Matrix<FqT>& comp_;
+    uint64_t g_ = 1, g_inv_ = 1; unsigned nbase_ = 0;
+    std::vector<FqVal> ood_exec_, ood_comp_; bool have_ood_ = false;
+};
+
+// ---- RPO-256 front-ends (gpu/src/plan.rs:32-174); digests are 4 Fp elements, Montgomery form
+class GpuRpo256ColumnMajor {                      // ::new(n, requires_padding); update(col) per column; finish()
+public:
+    GpuRpo256ColumnMajor(Planner& pl, size_t n) : pl_(&pl), n_(n) {}
+    void update(const GpuVec<Fp>& col) { if (col.len() != n_) throw std::invalid_argument("column length differs from n"); cols_.push_back(col.ptr()); }
+    GpuVec<Fp> finish() {
+        GpuVec<Fp> digests(*pl_, n_ * 4);
+        check(ms_rpo256_rows(pl_->ctx(), n_, cols_.data(), (unsigned)cols_.size(), digests.ptr()));
+        pl_->sync();
+        return digests;
+    }
+private:
+    Planner* pl_; size_t n_; std::vector<const void*> cols_;
+};
+inline GpuVec<Fp> rpo256_rows_row_major(const GpuVec<Fp>& rows, unsigned ncols = 8) {      // GpuRpo256RowMajor: update(rows) + finish()
+    GpuVec<Fp> digests(rows.planner(), rows.len() / ncols * 4);
+    check(ms_rpo256_rows_row_major(rows.planner().ctx(), rows.len() / ncols, ncols, rows.ptr(), digests.ptr()));
+    rows.planner().sync();
+    return digests;
+}
+inline GpuVec<Fp> gen_rpo_merkle_tree(const GpuVec<Fp>& leaves) {                          // nodes, [n][4] Fp
+    GpuVec<Fp> nodes(leaves.planner(), leaves.len());
+    check(ms_rpo256_merkle(leaves.planner().ctx(), leaves.len() / 4, leaves.ptr(), nodes.ptr()));
+    leaves.planner().sync();
+    return nodes;
+}
+
+}  // namespace ms
