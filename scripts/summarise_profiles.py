@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""gpurun_out/profiles_raw/ (scripts/collect_profiles.sh) -> profiles/rNN_* summaries.
+    python scripts/summarise_profiles.py [round_tag]
+FETCH_SIZE is doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 tallies a coalesced stream at
+64 B); counter units are KB = 1024 B; values are averaged per launch (one launch = one 2^24 column)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+PROF = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(RAW, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def counters(path):
+    """-> {kernel: {counter: [values per dispatch]}}"""
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+stats = one("stats/**/*kernel_stats.csv")
+if stats:
+    rows = [r for r in csv.DictReader(open(stats)) if "msntt" in r["Name"]]
+    with open(os.path.join(PROF, f"{tag}_ntt_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+        w.writeheader()
+        w.writerows(rows)
+traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --cols 2 --no-cpu-baseline",
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream's bytes); WRITE_SIZE as reported. "
+                   "Units: KB = 1024 B. Per launch = one column (2^24 x 8 B).", "kernels": {}}
+fetch, write = one("pmc_fetch/**/*counter_collection.csv"), one("pmc_write/**/*counter_collection.csv")
+if fetch and write:
+    fc, wc = counters(fetch), counters(write)
+    total = 0.0
+    for k in fc:
+        if "msntt" not in k:
+            continue
+        fb = 2 * 1024 * sum(fc[k]["FETCH_SIZE"]) / len(fc[k]["FETCH_SIZE"])      # one 2^24 column per launch (128 MiB columns exceed the 32 MiB launch group)
+        wb = 1024 * sum(wc[k]["WRITE_SIZE"]) / len(wc[k]["WRITE_SIZE"])
+        traffic["kernels"][k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb}
+        total += fb + wb
+        shutil.copy(fetch, os.path.join(PROF, f"{tag}_ntt_pmc_fetch_size.csv"))
+        shutil.copy(write, os.path.join(PROF, f"{tag}_ntt_pmc_write_size.csv"))
+    traffic["hbm_bytes_per_transform"] = total
+    traffic["algorithmic_bytes_per_transform"] = 2.0 * 8 * (1 << 24)
+    json.dump(traffic, open(os.path.join(PROF, f"{tag}_ntt_traffic.json"), "w"), indent=1)
+for name, dst in (("pmc_sq", "ntt_sq_counters"), ("pmc_sha", "sha256_sq_counters")):
+    p = one(f"{name}/**/*counter_collection.csv")
+    if not p:
+        continue
+    c = counters(p)
+    with open(os.path.join(PROF, f"{tag}_{dst}.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches", "counter", "mean_per_dispatch"])
+        for k in sorted(c):
+            if "msntt" in k or "mssha" in k:
+                for cn, vals in sorted(c[k].items()):
+                    w.writerow([k, len(vals), cn, sum(vals) / len(vals)])
+for src, dst in (("bench.json", f"{tag}_bench_ntt_2_24.json"), ("bench_configs.jsonl", f"{tag}_bench_configs.jsonl"), ("bench_commit.json", f"{tag}_bench_commit.json")):
+    p = os.path.join(RAW, src)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(PROF, dst))
+print(json.dumps(traffic, indent=1)[:1200])
