@@ -107,6 +107,17 @@ int ms_bit_reverse(ms_ctx* ctx, int field, unsigned log_n, void* const* d_column
 int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowup, const void* h_offset,
            const void* const* d_in, void* const* d_out, unsigned ncols, int bit_reversed);
 
+/* ---- evaluation of coefficient columns shorter than the domain: Matrix::into_evaluations /
+ * bit_reversed_evaluate with their "resize the column to the domain size" (src/matrix.rs:193-251), e.g. the
+ * composition-trace and DEEP polynomials (src/prover.rs:122-124, 156).  d_in[c] holds 2^log_n coefficients
+ * (untouched unless d_out[c] aliases it), d_out[c] receives 2^log_domain evaluations on coset(2^log_domain,
+ * h_offset), optionally in bit-reversed order.  Blow-ups 4..16 never materialise the zero padding.
+ * ms_deinterleave: `composition_poly.chunks(k)` spread over k columns (src/prover.rs:113-121):
+ * d_out[c][j] = d_in[j*k + c], j < n_out. */
+int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_domain, const void* h_offset,
+                const void* const* d_in, void* const* d_out, unsigned ncols, int bit_reversed);
+int ms_deinterleave(ms_ctx* ctx, int field, size_t n_out, unsigned k, const void* d_in, void* const* d_out);
+
 /* ---- element-wise stages (gpu/src/stage.rs:115-1155; kernels evaluation_shaders.h.metal:11-168).
  * lf / rf are the fields of lhs(=dst) and rhs: (Fp,Fp), (Fq3,Fq3) or (Fq3,Fp) -- the GpuMul / GpuAdd
  * impls of gpu/src/fields.rs:55-216.  `shift` rotates the rhs index: rhs[(i + shift) mod n], any sign

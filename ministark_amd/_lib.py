@@ -54,6 +54,8 @@ class Lib:
             "ms_ntt_enqueue": (i, [vp, c_void_pp, u]),
             "ms_bit_reverse": (i, [vp, i, u, c_void_pp, u]),
             "ms_lde": (i, [vp, i, u, u, vp, c_void_pp, c_void_pp, u, i]),
+            "ms_evaluate": (i, [vp, i, u, u, vp, c_void_pp, c_void_pp, u, i]),
+            "ms_deinterleave": (i, [vp, i, sz, u, vp, c_void_pp]),
             "ms_binary": (i, [vp, i, i, i, sz, vp, vp, vp, ctypes.c_long]),
             "ms_binary_const": (i, [vp, i, i, i, sz, vp, vp, vp]),
             "ms_mul_pow": (i, [vp, i, i, sz, vp, vp, vp, u, ctypes.c_long]),

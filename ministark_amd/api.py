@@ -420,22 +420,27 @@ class Matrix:
         return self.clone().into_polynomials(domain)
 
     # src/matrix.rs:193-208 (into_evaluations_gpu): column.resize(domain.size(), 0) then fft
-    def into_evaluations(self, domain):
-        cols = []
-        for c in self.columns:
-            if len(c) > domain.size:
-                raise ValueError("column longer than the evaluation domain")
-            if len(c) < domain.size:
-                a = np.zeros(domain.size * FIELD_WORDS[c.field], dtype=np.uint64)
-                a[:c.words] = c.to_numpy()
-                c = GpuVec.from_numpy(self.planner, a, c.field)
-            cols.append(c)
-        self.columns = cols
-        fft = GpuFft(domain, self.field, self.planner)
-        for c in self.columns:
-            fft.encode(c)
-        fft.execute()
-        fft.close()
+    def into_evaluations(self, domain, bit_reversed=False):
+        """`Matrix::into_evaluations(domain)` (src/matrix.rs:193-208): columns shorter than the domain are
+        coefficient vectors to be zero-extended (`column.resize(domain.size(), F::zero())`, :201) -- done on
+        the device, for blow-ups 4..16 without materialising the padding."""
+        n = self.num_rows()
+        if n > domain.size:
+            raise ValueError("column longer than the evaluation domain")
+        if n == domain.size and not bit_reversed:
+            fft = GpuFft(domain, self.field, self.planner)
+            for c in self.columns:
+                fft.encode(c)
+            fft.execute()
+            fft.close()
+            return self
+        L = self.planner.lib
+        outs = self.columns if n == domain.size else [GpuVec(self.planner, domain.size, self.field) for _ in self.columns]
+        off = _offset_words(self.field, domain.offset)
+        L.check(L.ms_evaluate(self.planner.handle, self.field, n.bit_length() - 1, domain.log_size, off.ctypes.data,
+                              _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
+        self.planner.sync()
+        self.columns = outs
         return self
 
     def evaluate(self, domain):           # src/matrix.rs:237-243
@@ -449,8 +454,18 @@ class Matrix:
         self.planner.sync()
         return self
 
-    def into_bit_reversed_evaluations(self, domain):   # src/matrix.rs:225-234
-        return self.into_evaluations(domain).bit_reverse_rows()
+    def into_bit_reversed_evaluations(self, domain):   # src/matrix.rs:225-234 (the bit reversal is fused into the last pass)
+        return self.into_evaluations(domain, bit_reversed=True)
+
+    @classmethod
+    def from_chunks(cls, poly, k):
+        """`composition_poly.chunks(k)` spread over k columns (src/prover.rs:113-121): column c holds
+        coefficients c, c + k, c + 2k, ... of `poly` (a GpuVec)."""
+        pl = poly.planner
+        n_out = len(poly) // k
+        outs = [GpuVec(pl, n_out, poly.field) for _ in range(k)]
+        pl.lib.check(pl.lib.ms_deinterleave(pl.handle, poly.field, n_out, k, poly.ptr, _ptr_array(outs)))
+        return cls(outs)
 
     def bit_reversed_evaluate(self, domain):           # src/matrix.rs:245-251
         return self.clone().into_bit_reversed_evaluations(domain)

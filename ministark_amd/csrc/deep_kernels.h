@@ -3,8 +3,8 @@
 // (horner_evaluate src/utils.rs:124-133, divide_out_point(s)_into src/utils.rs:151-175).
 //
 //  * horner_blocks: out-of-domain evaluations P_c(x) for (column, point) queries.  One workgroup per
-//    4096 coefficients and query: each lane runs Horner over 16 consecutive coefficients, the
-//    workgroup combines with powers of x^16 in LDS; the <= n/4096 block values are combined on the host.
+//    4096 coefficients and query: lane t runs Horner in x^256 over coefficients t, t+256, ... (coalesced
+//    loads), the workgroup folds sum_t A_t x^t in LDS; the <= n/4096 block values are combined on the host.
 //  * deep_points: the reference builds  Q(X) = sum_t alpha_t (P_ct(X) - P_ct(z_t)) / (X - z_t)  by synthetic
 //    division in coefficient space.  Q has degree <= n-2, so it is determined by its values on any n
 //    points: this kernel evaluates the sum at the n points of the coset offset*<w_n> from coset
@@ -62,33 +62,38 @@ struct HornerParams {
     unsigned nblocks;
 };
 // CW: words per coefficient (1 Fp, 3 Fq3); PW: words of the point field (PW >= CW)
+// Lane t of block b takes coefficients b*4096 + t + 256*k, k < 16 (a wave reads 64 consecutive
+// coefficients per load): Horner in y = x^256 gives A_t = sum_k c[t + 256k] y^k, and the block value
+// sum_t A_t x^t is folded pairwise through LDS with x^(2^l) at level l.
 template <int CW, int PW>
 __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
     __shared__ uint64_t sh[NT * 3];
     const unsigned q = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
     const uint64_t* col = P.cols[P.qcol[q]];
     const Q x = {{P.qpoint[3 * q], P.qpoint[3 * q + 1], P.qpoint[3 * q + 2]}};
-    const size_t start = (size_t)b * 4096 + (size_t)t * 16;
+    Q xp[9];                                   // x^(2^l), l = 0..8 (wave-uniform)
+    xp[0] = x;
+    #pragma unroll
+    for (int l = 1; l <= 8; l++) xp[l] = q_mul<PW>(xp[l - 1], xp[l - 1]);
+    const size_t start = (size_t)b * 4096 + t;
     Q acc = q_zero<PW>();
     #pragma unroll 4
-    for (int j = 15; j >= 0; j--) {
-        const size_t i = start + j;
+    for (int k = 15; k >= 0; k--) {
+        const size_t i = start + (size_t)k * NT;
         Q c = q_zero<PW>();
         if (i < P.n) c = q_load<CW>(col, i);
-        acc = q_add<PW>(q_mul<PW>(acc, x), c);
+        acc = q_add<PW>(q_mul<PW>(acc, xp[8]), c);
     }
-    // combine: value_t * (x^16)^t, pairwise with pw = x^(16 * 2^l)
-    Q pw = x;
-    for (int s = 0; s < 4; s++) pw = q_mul<PW>(pw, pw);
+    // combine: sum_t A_t x^t, pairwise: A_t += A_(t+step) * x^step
+    #pragma unroll
     for (unsigned l = 0; l < 8; l++) {
         sh[3 * t] = acc.w[0]; sh[3 * t + 1] = acc.w[1]; sh[3 * t + 2] = acc.w[2];
         __syncthreads();
         const unsigned step = 1u << l;
         if ((t & (2 * step - 1)) == 0) {
             const Q other = {{sh[3 * (t + step)], sh[3 * (t + step) + 1], sh[3 * (t + step) + 2]}};
-            acc = q_add<PW>(acc, q_mul<PW>(other, pw));
+            acc = q_add<PW>(acc, q_mul<PW>(other, xp[l]));
         }
-        pw = q_mul<PW>(pw, pw);
         __syncthreads();
     }
     if (t == 0) {

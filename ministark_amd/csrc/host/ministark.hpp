@@ -134,7 +134,29 @@ public:
         fft.execute();
         return *this;
     }
-    Matrix evaluate(const Radix2EvaluationDomain& d) const { Matrix m = clone(); m.into_evaluations(d); return m; }
+    // evaluate / bit_reversed_evaluate (src/matrix.rs:237-251): columns shorter than the domain are coefficient
+    // vectors, zero-extended on the device ("resize", :201); the input is preserved
+    Matrix evaluate(const Radix2EvaluationDomain& d, bool bit_reversed = false) const {
+        if (num_rows() == d.size && !bit_reversed) { Matrix m = clone(); m.into_evaluations(d); return m; }
+        Matrix out;
+        for (size_t c = 0; c < columns.size(); c++) out.columns.emplace_back(planner(), d.size);
+        std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
+        auto o = out.ptrs();
+        unsigned lg = 0; while (((size_t)1 << lg) < num_rows()) lg++;
+        const uint64_t off = gl::to_mont(d.offset);
+        check(ms_evaluate(planner().ctx(), F::id, lg, d.log_size, &off, in.data(), o.data(), (unsigned)in.size(), bit_reversed ? 1 : 0));
+        planner().sync();
+        return out;
+    }
+    Matrix bit_reversed_evaluate(const Radix2EvaluationDomain& d) const { return evaluate(d, true); }
+    // composition_poly.chunks(k) spread over k columns (src/prover.rs:113-121)
+    static Matrix from_chunks(const GpuVec<F>& poly, unsigned k) {
+        Matrix out;
+        for (unsigned c = 0; c < k; c++) out.columns.emplace_back(poly.planner(), poly.len() / k);
+        auto o = out.ptrs();
+        check(ms_deinterleave(poly.planner().ctx(), F::id, poly.len() / k, k, poly.ptr(), o.data()));
+        return out;
+    }
     Matrix& bit_reverse_rows() {                                       // src/matrix.rs:352-354
         auto p = ptrs();
         unsigned lg = 0; while (((size_t)1 << lg) < num_rows()) lg++;

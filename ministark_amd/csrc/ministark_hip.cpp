@@ -499,6 +499,7 @@ static void launch_mid(bool inv, bool last, int scale, bool bitrev, dim3 grid, h
 }
 
 static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* const* src, void* const* dst, unsigned ncols);
+static unsigned stream_grid(size_t n);
 
 static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols) {
     ms_ctx* ctx = p->ctx;
@@ -746,6 +747,69 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
     return rc;
 }
 
+// Matrix::into_evaluations / bit_reversed_evaluate on columns shorter than the domain (src/matrix.rs:193-251:
+// "resize the column to the domain size", i.e. zero-extend the coefficient vector): the second half of ms_lde.
+extern "C" int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_domain, const void* h_offset,
+                           const void* const* d_in, void* const* d_out, unsigned ncols, int bit_reversed) {
+    if (!ctx || !d_in || !d_out) return fail(MS_ERR_INVALID, "ms_evaluate: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (log_n > log_domain) return fail(MS_ERR_INVALID, "more coefficients (2^%u) than domain points (2^%u)", log_n, log_domain);
+    const unsigned log_blowup = log_domain - log_n;
+    const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_domain;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    ms_ntt_plan* fwd = nullptr;
+    if (V == 4) {
+        if (log_domain > 40) return fail(MS_ERR_INVALID, "domain 2^%u too large", log_domain);
+        f252::E h252 = f252::one();
+        if (h_offset) memcpy(h252.l, h_offset, 32);
+        uint64_t hkey = 1469598103934665603ull;
+        for (int w = 0; w < 4; w++) { hkey ^= h252.l[w]; hkey *= 1099511628211ull; }
+        hkey |= (uint64_t)1 << 63;
+        for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_domain && !kv.first.inverse && kv.first.h == hkey) fwd = kv.second;
+        if (!fwd) { MSCHK(plan_build252(ctx, log_domain, false, h252.l, nullptr, &fwd)); ctx->plan_cache.push_back({PlanKey{4, log_domain, false, hkey}, fwd}); }
+    } else {
+        if (log_domain > 32) return fail(MS_ERR_INVALID, "domain 2^%u exceeds the two-adicity", log_domain);
+        uint64_t h = 1;
+        if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
+        if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
+        MSCHK(ctx_plan(ctx, V, log_domain, false, h, &fwd));
+    }
+    if (V != 4 && !fwd->small && log_blowup >= 2 && log_blowup <= 4) {
+        // pass 1 reads only the rows that hold coefficients (straight from d_in), zero padding is implicit,
+        // the bit reversal is fused into the last pass
+        return plan_run(fwd, d_in, d_out, ncols, 256u >> log_blowup, bit_reversed != 0);
+    }
+    for (unsigned c = 0; c < ncols; c++) {
+        if (d_in[c] != d_out[c]) HIPCHK(hipMemcpyAsync(d_out[c], d_in[c], n * V * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (N > n) HIPCHK(hipMemsetAsync((char*)d_out[c] + n * V * 8, 0, (N - n) * V * 8, ctx->stream));
+    }
+    MSCHK(plan_run(fwd, (const void* const*)d_out, d_out, ncols, 256));
+    if (bit_reversed) MSCHK(bit_reverse_run(ctx, V, log_domain, (const void* const*)d_out, d_out, ncols));
+    return MS_OK;
+}
+
+// composition_poly.chunks(k) -> k columns (src/prover.rs:113-121): out[c][j] = in[j*k + c]
+extern "C" int ms_deinterleave(ms_ctx* ctx, int field, size_t n_out, unsigned k, const void* d_in, void* const* d_out) {
+    if (!ctx || !d_in || !d_out) return fail(MS_ERR_INVALID, "ms_deinterleave: null argument");
+    const size_t fb = ms_field_bytes(field);
+    if (!fb) return fail(MS_ERR_UNSUPPORTED, "unknown field %d", field);
+    if (k == 0 || k > (unsigned)msstage::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "1..%d columns", msstage::MAXCOLS);
+    if (n_out == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    msscan::DeinterleaveParams P;
+    memset(&P, 0, sizeof P);
+    for (unsigned c = 0; c < k; c++) { if (!d_out[c]) return fail(MS_ERR_INVALID, "null column %u", c); P.out[c] = (uint64_t*)d_out[c]; }
+    P.in = (const uint64_t*)d_in; P.n_out = n_out; P.k = k; P.V = (unsigned)(fb / 8);
+    const size_t total = n_out * k * P.V;
+    ProfScope ps(ctx, "deinterleave", 16.0 * total);
+    hipLaunchKernelGGL(msscan::deinterleave, dim3(stream_grid(total)), dim3(msscan::NT), 0, ctx->stream, P);
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // SHA-256 commitments
 // ---------------------------------------------------------------------------------------
@@ -761,6 +825,7 @@ extern "C" int ms_sha256_rows(ms_ctx* ctx, int field, size_t nrows, const void* 
     memset(&P, 0, sizeof P);
     for (unsigned c = 0; c < ncols; c++) P.cols[c] = (const uint64_t*)d_cols[c];
     P.leaves = (uint8_t*)d_leaves; P.nrows = nrows; P.ncols = ncols; P.V = V; P.row_stride = V;
+    if (ncols && (ncols * V) % 8 == 0) { P.fold_last = 1; mssha::sha256_fold_pad_block((uint64_t)ncols * V * 64, P.kw_last); }
     {
         ProfScope ps(ctx, "sha256_rows", (double)nrows * ncols * V * 8 + 32.0 * nrows);
         hipLaunchKernelGGL(mssha::sha256_rows, dim3((unsigned)((nrows + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, P);
@@ -780,6 +845,7 @@ extern "C" int ms_sha256_rows_row_major(ms_ctx* ctx, int field, size_t nrows, un
     memset(&P, 0, sizeof P);
     for (unsigned c = 0; c < ncols; c++) P.cols[c] = (const uint64_t*)d_matrix + (size_t)c * V;
     P.leaves = (uint8_t*)d_leaves; P.nrows = nrows; P.ncols = ncols; P.V = V; P.row_stride = ncols * V;
+    if ((ncols * V) % 8 == 0) { P.fold_last = 1; mssha::sha256_fold_pad_block((uint64_t)ncols * V * 64, P.kw_last); }
     {
         ProfScope ps(ctx, "sha256_rows", (double)nrows * ncols * V * 8 + 32.0 * nrows);
         hipLaunchKernelGGL(mssha::sha256_rows, dim3((unsigned)((nrows + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, P);

@@ -168,4 +168,21 @@ __global__ void __launch_bounds__(NT) gather_records(const uint64_t* __restrict_
         out[i] = src[(size_t)idx[i / words] * words + i % words];
 }
 
+// composition_poly.chunks(k) into k columns (src/prover.rs:113-121): out[c][j] = in[j*k + c].  Lanes run along
+// the interleaved input (coalesced reads; the k output streams are each contiguous per lane group).
+struct DeinterleaveParams {
+    uint64_t* out[msstage::MAXCOLS];
+    const uint64_t* in;
+    size_t n_out;
+    unsigned k, V;
+};
+__global__ void __launch_bounds__(NT) deinterleave(DeinterleaveParams P) {
+    const size_t total = P.n_out * P.k * P.V;
+    for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+        const size_t e = idx / P.V;                    // input element
+        const unsigned v = (unsigned)(idx % P.V);
+        P.out[e % P.k][(e / P.k) * P.V + v] = P.in[idx];
+    }
+}
+
 }  // namespace msscan

@@ -78,6 +78,21 @@ struct Sha {
         }
         h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
     }
+    // compression of a block whose 16 words are constants: kw[i] = K256[i] + W[i] precomputed (wave-uniform table)
+    __device__ __forceinline__ void compress_kw(const uint32_t* __restrict__ kw) {
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        #pragma unroll
+        for (int i = 0; i < 64; i++) {
+            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+            const uint32_t ch = (e & f) ^ (~e & g);
+            const uint32_t t1 = hh + S1 + ch + kw[i];
+            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+            const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
     // compression of the constant padding block that follows a 64-byte message
     __device__ __forceinline__ void compress_pad64() {
         uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
@@ -102,7 +117,29 @@ struct RowsParams {
     unsigned ncols;
     unsigned V;               // u64 words per element
     unsigned row_stride;      // words between consecutive rows of one column (V when columns are dense)
+    unsigned fold_last;       // the last block holds only padding + length (row length a multiple of 64 bytes):
+    uint32_t kw_last[64];     //   its message schedule is constant and comes folded into the round constants
 };
+// host: K256[i] + W[i] of the block {0x80000000, 0, ..., 0, bits_hi, bits_lo}
+static inline void sha256_fold_pad_block(uint64_t bits, uint32_t kw[64]) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64] = {0};
+    w[0] = 0x80000000u; w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits;
+    auto rr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = rr(w[i - 15], 7) ^ rr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rr(w[i - 2], 17) ^ rr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    for (int i = 0; i < 64; i++) kw[i] = K[i] + w[i];
+}
 
 // One row per lane.  The message is a stream of 8-byte slots: slot i < nslots is limb (i % V) of the
 // element of column i / V, as its canonical value x, contributing the big-endian words
@@ -119,7 +156,8 @@ __global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
     const unsigned nblocks = (nslots + 2 + 7) / 8;
     const uint64_t bits = (uint64_t)nslots * 64;
     f252::E big = f252::zero();
-    for (unsigned blk = 0; blk < nblocks; blk++) {
+    const unsigned data_blocks = P.fold_last ? nblocks - 1 : nblocks;
+    for (unsigned blk = 0; blk < data_blocks; blk++) {
         #pragma unroll
         for (int j = 0; j < 8; j++) {
             const unsigned i = blk * 8 + j;
@@ -144,6 +182,7 @@ __global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
         }
         s.compress();
     }
+    if (P.fold_last) s.compress_kw(P.kw_last);
     uint4* out = (uint4*)(P.leaves + r * 32);
     out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
     out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));

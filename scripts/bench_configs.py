@@ -133,42 +133,58 @@ def fri():
 wall, k = timed(fri, reps=3)
 emit("FRI folds 2^23 -> 2^8 by 8 (Fq3), 5 layers", wall, k, first_layer_GBps=round((24 * (1 << 23) * 9 / 8) / (k.get("fri_fold", 1) * 1e-6) / 1e9, 1))
 
-# ---- C5-shaped pipeline on ONE GPU: the data-parallel phases of default_prove (src/prover.rs:25-174)
-# on a 2^22-row x 8-column fib-shaped trace, ProofOptions::new(32, 4, 8, 8, 64) (examples/fib/main.rs:225):
-# blow-up 4, FRI folding 8.  DEEP composition (src/composer.rs, host-side in the reference) is replaced by
-# taking the composition LDE as the FRI input; no channel / queries.  Timings only.
+# ---- C5-shaped pipeline on ONE GPU: every data-parallel phase of default_prove (src/prover.rs:25-174), device-resident,
+# on a 2^22-row x 8-column fib-shaped trace, ProofOptions::new(32, 4, 8, 8, 64) (examples/fib/main.rs:225): 32 queries,
+# blow-up 4, grinding 8 bits, FRI folding 8, remainder <= 64.  The channel (Fiat-Shamir hashing of a few digests) is
+# replaced by fixed pseudo-random challenges: timings only; every phase's parity is asserted in tests/.
+from ministark_amd import Queries, grind_proof_of_work   # noqa: E402
+from ministark_amd.composer import DeepCompositionCoeffs, DeepPolyComposer   # noqa: E402
+
 del lde, state
 log_t, blow = 22, 4
-trace = Matrix.from_numpy(pl, [rand(1 << log_t) for _ in range(8)], FP)
+n_t, n_lde = 1 << log_t, 1 << (log_t + 2)
+trace = Matrix.from_numpy(pl, [rand(n_t) for _ in range(8)], FP)
 prog_c5 = E.compile_expr(comp, 8, False)
+trace_args = [(c, o) for c in range(8) for o in (0, 1)]          # every column at the current and the next row
+coeffs = DeepCompositionCoeffs([int(v) for v in rand(len(trace_args))], [int(v) for v in rand(blow)], (int(rand(1)[0]), int(rand(1)[0])))
+positions = [int(p) for p in rng.integers(0, n_lde, size=32)]
 phase = {}
 
 
 def c5():
     t = time.perf_counter()
-    lde_t = trace.lde(blow, 7, True)                                   # prover.rs:50-51
+    trace_dom, lde_dom = Radix2EvaluationDomain(n_t), Radix2EvaluationDomain(n_lde, 7)
+    base_polys = trace.interpolate(trace_dom)                          # prover.rs:50
+    lde_t = base_polys.bit_reversed_evaluate(lde_dom)                  # prover.rs:51
     tree_t = MerkleTree.from_matrix(lde_t); tree_t.root()              # prover.rs:52-55
-    phase["lde+commit base trace"] = time.perf_counter() - t; t = time.perf_counter()
+    phase["base trace: interpolate + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
     nat = lde_t.clone().bit_reverse_rows()                             # prover.rs:88-91 (ce domain = lde domain here)
-    comp_evals = E.eval(prog_c5, pl, ch, ch[:1], blow, 7, 1 << (log_t + 2), nat.columns)   # prover.rs:98-107
+    comp_evals = E.eval(prog_c5, pl, ch, ch[:1], blow, 7, n_lde, nat.columns)   # prover.rs:98-107
+    del nat
     phase["constraint evaluation"] = time.perf_counter() - t; t = time.perf_counter()
-    ifft = GpuIfft(Radix2EvaluationDomain(1 << (log_t + 2), 7), FP, pl)    # prover.rs:111-112
-    ifft.encode(comp_evals); ifft.execute(); ifft.close()
-    fft = GpuFft(Radix2EvaluationDomain(1 << (log_t + 2), 7), FP, pl)      # prover.rs:122-124 (one column of the split)
-    fft.encode(comp_evals); fft.execute(); fft.close()
-    cm = Matrix([comp_evals]).bit_reverse_rows()
-    MerkleTree.from_matrix(cm).root()
-    phase["composition iNTT + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
-    cur, n = cm.columns[0], 1 << (log_t + 2)                            # fri.rs:179-231
+    comp_poly = Matrix([comp_evals]).into_polynomials(lde_dom).columns[0]   # prover.rs:111-112
+    comp_polys = Matrix.from_chunks(comp_poly, blow)                   # prover.rs:113-121
+    comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)               # prover.rs:122
+    tree_c = MerkleTree.from_matrix(comp_lde); tree_c.root()           # prover.rs:123-124
+    phase["composition trace: iNTT + split + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
+    composer = DeepPolyComposer(trace_args, n_t, 0x1234567890abcdef % P, base_polys, None, comp_polys)   # prover.rs:137-144
+    composer.get_ood_evals()                                           # prover.rs:145-146
+    deep = Matrix([composer.into_deep_poly(coeffs)]).into_bit_reversed_evaluations(lde_dom)   # prover.rs:149-152
+    phase["DEEP: OOD evaluations + composition + LDE"] = time.perf_counter() - t; t = time.perf_counter()
+    cur, n = deep.columns[0], n_lde                                    # fri.rs:179-231
     alpha1 = rand(1)
+    last_root = None
     while n > 64 * blow:
-        MerkleTree.from_fri_layer(cur, 8).root()
+        last_root = MerkleTree.from_fri_layer(cur, 8).root()
         cur = apply_drp(cur, alpha1, 8, 1)
         n //= 8
     pl.sync()
-    phase["FRI layers (commit + fold)"] = time.perf_counter() - t
+    phase["FRI layers (commit + fold)"] = time.perf_counter() - t; t = time.perf_counter()
+    grind_proof_of_work(pl, last_root, 8)                              # prover.rs:160 (grinding factor 8)
+    Queries(lde_t, None, comp_lde, tree_t, None, tree_c, positions)    # prover.rs:163-173
+    phase["proof of work + queries"] = time.perf_counter() - t
 
 
 wall, k = timed(c5, reps=2)
-emit("C5-shaped single-GPU pipeline: 2^22 rows x 8 cols, blow-up 4, FRI fold 8 (no DEEP/channel)", wall, k,
+emit("C5-shaped single-GPU pipeline: 2^22 rows x 8 cols, blow-up 4, FRI fold 8, 32 queries, 8 grinding bits (fixed challenges instead of the channel)", wall, k,
      phases_ms={kk: round(v * 1e3, 2) for kk, v in phase.items()})

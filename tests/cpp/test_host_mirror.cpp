@@ -73,6 +73,12 @@ int main() {
         oracle_sha256_merkle(leaves.data(), N, nodes.data());
         auto root = ms::MerkleTree::from_matrix(lde).root();
         REQUIRE(memcmp(root.data(), nodes.data() + 32, 32) == 0);
+        // bit_reversed_evaluate of the interpolated polynomials = the fused LDE; chunks() of a column
+        ms::Matrix<ms::Fp> polys = m.interpolate(td);
+        ms::Matrix<ms::Fp> lde2 = polys.bit_reversed_evaluate(ms::Radix2EvaluationDomain(N, 7));
+        for (unsigned c = 0; c < ncols; c++) REQUIRE(lde2.columns[c].to_host() == want[c]);
+        ms::Matrix<ms::Fp> parts = ms::Matrix<ms::Fp>::from_chunks(m.columns[0], 4);
+        for (unsigned c = 0; c < 4; c++) { auto pc = parts.columns[c].to_host(); for (size_t j = 0; j < pc.size(); j++) REQUIRE(pc[j] == cols[0][j * 4 + c]); }
         // sum_columns
         auto sum = m.sum_columns().to_host();
         for (size_t i = 0; i < sum.size(); i++) {

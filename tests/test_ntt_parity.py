@@ -288,3 +288,56 @@ def test_lde_hip(log_n, log_b):
 @pytest.mark.gpu
 def test_lde_fq3_hip():
     _lde("hip", GOLDILOCKS_FQ3, 14, 3)
+
+
+# --- evaluation of short coefficient columns (Matrix::into_evaluations with its resize, src/matrix.rs:193-251)
+def _evaluate(kind, field, log_n, log_b, offset=7, ncols=2):
+    from ministark_amd import Radix2EvaluationDomain
+    pl = backends.planner(kind)
+    V = 3 if field == GOLDILOCKS_FQ3 else 1
+    n, N = 1 << log_n, 1 << (log_n + log_b)
+    cols = [_rand(n * V, 70 + c) for c in range(ncols)]
+    want = []
+    for c in cols:
+        padded = np.zeros(N * V, dtype=np.uint64)
+        padded[: n * V] = c
+        want.append(cref.ntt(padded, log_n + log_b, V, False, offset))
+    dom = Radix2EvaluationDomain(N, offset)
+    m = Matrix.from_numpy(pl, cols, field)
+    nat = m.evaluate(dom)
+    for c, keep, got, w in zip(cols, m.to_numpy(), nat.to_numpy(), want):
+        assert np.array_equal(keep, c), "evaluate() must not touch its input"
+        assert np.array_equal(got, w)
+    br = m.bit_reversed_evaluate(dom)
+    for got, w in zip(br.to_numpy(), want):
+        assert np.array_equal(got, cref.bit_reverse(w, log_n + log_b, V))
+
+
+@pytest.mark.parametrize("log_n,log_b", [(3, 1), (8, 2), (10, 2), (10, 3), (9, 4), (8, 5), (12, 0), (11, 1)])
+def test_evaluate_short_columns_emu(log_n, log_b):
+    _evaluate("emu", GOLDILOCKS_FP, log_n, log_b)
+
+
+def test_evaluate_short_columns_fq3_and_subgroup_emu():
+    _evaluate("emu", GOLDILOCKS_FQ3, 10, 2)
+    _evaluate("emu", GOLDILOCKS_FP, 10, 3, offset=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,log_b", [(18, 2), (16, 3), (14, 4), (15, 1), (13, 6)])
+def test_evaluate_short_columns_hip(log_n, log_b):
+    _evaluate("hip", GOLDILOCKS_FP, log_n, log_b, ncols=3)
+    if log_b == 2:
+        _evaluate("hip", GOLDILOCKS_FQ3, 14, 2)
+
+
+@pytest.mark.parametrize("kind", [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)])
+def test_composition_poly_chunks(kind):                 # src/prover.rs:113-121
+    pl = backends.planner(kind)
+    for field, V in ((GOLDILOCKS_FP, 1), (GOLDILOCKS_FQ3, 3)):
+        n, k = 1 << 12, 4
+        poly = _rand(n * V, 5)
+        cols = Matrix.from_chunks(GpuVec.from_numpy(pl, poly, field), k).to_numpy()
+        elems = poly.reshape(n, V)
+        for c in range(k):
+            assert np.array_equal(cols[c].reshape(-1, V), elems[c::k])
