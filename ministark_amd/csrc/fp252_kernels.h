@@ -2,8 +2,9 @@
 // gpu/src/metal/fft_shaders.h.metal:108-119 and gpu/tests/shaders.rs:69-91).
 // The field is compute-bound (one Montgomery product = 20 64x64 multiplies), so the structure
 // is deliberately plain: bit-reverse, then radix-2 DIT stages -- the first nine inside LDS on
-// 512-element chunks, the rest one launch per stage in global memory -- with the coset /
-// normalisation scale fused into the first / last kernel.  Twiddles come from a two-level table.
+// 512-element chunks, the rest two stages per launch in registers (ntt252_stages) -- with the coset /
+// normalisation scale fused into the first / last kernel.  Twiddles come from a one-level table up to
+// 2^21 points (a two-level lookup costs a second ~440-instruction product per butterfly).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fp252.h"
@@ -63,23 +64,43 @@ __global__ void __launch_bounds__(NT) ntt252_local(Params P) {
         st(P.col, base + q, x);
     }
 }
-// one global radix-2 DIT stage s (> CHUNK_LOG); the last stage applies the output scale
-__global__ void __launch_bounds__(NT) ntt252_stage(Params P) {
-    const size_t q = (size_t)blockIdx.x * NT + threadIdx.x;
+// R consecutive global DIT stages (stage+1 .. stage+R) in one pass: lane = one group of 2^R elements
+// spaced 2^stage apart (consecutive lanes take consecutive low indices: 32-byte loads, coalesced).
+// A single global stage moves 64 bytes per butterfly and is HBM-bound (measured 3.9 TB/s); two stages per
+// pass halve the traffic.  More than two were measured slower: 2^R elements of 8 dwords plus the
+// product's temporaries leave 2-3 waves per SIMD, too few to keep the loads in flight.
+static constexpr unsigned MAX_FUSED_STAGES = 2;
+template <int R>
+__global__ void __launch_bounds__(NT) ntt252_stages(Params P) {
+    constexpr int G = 1 << R;
+    const size_t gid = (size_t)blockIdx.x * NT + threadIdx.x;
     const size_t n = (size_t)1 << P.log_n;
-    if (q >= n / 2) return;
-    const unsigned s = P.stage;
-    const size_t half = (size_t)1 << (s - 1);
-    const size_t i = q & (half - 1), lo = ((q >> (s - 1)) << s) + i, hi = lo + half;
-    const f252::E u = ld(P.col, lo);
-    const f252::E t = f252::mul(ld(P.col, hi), pow2l(P.tw_lo, P.tw_hi, P.lo_bits, i << (P.log_n - s)));
-    f252::E a = f252::add(u, t), b = f252::sub(u, t);
-    if (s == P.log_n && P.scale_out) {
-        a = f252::mul(a, pow2l(P.sc_lo, P.sc_hi, P.lo_bits, lo));
-        b = f252::mul(b, pow2l(P.sc_lo, P.sc_hi, P.lo_bits, hi));
+    if (gid >= (n >> R)) return;
+    const unsigned s0 = P.stage;                               // stages s0+1 .. s0+R
+    const size_t i0 = gid & (((size_t)1 << s0) - 1), base = ((gid >> s0) << (s0 + R)) + i0;
+    f252::E x[G];
+    #pragma clang loop unroll(full)
+    for (int j = 0; j < G; j++) x[j] = ld(P.col, base + ((size_t)j << s0));
+    #pragma clang loop unroll(full)
+    for (int r = 1; r <= R; r++) {
+        const int half = 1 << (r - 1);
+        #pragma clang loop unroll(full)
+        for (int q = 0; q < G / 2; q++) {
+            const int k = q & (half - 1), lo = ((q >> (r - 1)) << r) + k, hi = lo + half;
+            const size_t i = i0 + ((size_t)k << s0);           // index inside the half-block of stage s0+r
+            const f252::E t = f252::mul(x[hi], pow2l(P.tw_lo, P.tw_hi, P.lo_bits, i << (P.log_n - s0 - r)));
+            const f252::E u = x[lo];
+            x[lo] = f252::add(u, t);
+            x[hi] = f252::sub(u, t);
+        }
     }
-    st(P.col, lo, a);
-    st(P.col, hi, b);
+    const bool last = s0 + R == P.log_n;
+    #pragma clang loop unroll(full)
+    for (int j = 0; j < G; j++) {
+        const size_t e = base + ((size_t)j << s0);
+        if (last && P.scale_out) x[j] = f252::mul(x[j], pow2l(P.sc_lo, P.sc_hi, P.lo_bits, e));
+        st(P.col, e, x[j]);
+    }
 }
 
 // FRI degree-respecting projection over Fp252: apply_drp (src/fri.rs:526-567) collapsed exactly as in
@@ -97,20 +118,20 @@ struct Fold252Params {
     uint64_t zinv[8][4];        // (w_n^(-n/ff))^k, k < ff/2
 };
 template <int FF>
-__global__ void __launch_bounds__(NT) fri_fold252(Fold252Params P) {
+__global__ void __launch_bounds__(NT, 2) fri_fold252(Fold252Params P) {      // FF elements of 8 dwords live in registers
     constexpr int LOGF = FF == 2 ? 1 : FF == 4 ? 2 : FF == 8 ? 3 : 4;
     const size_t c = (size_t)blockIdx.x * NT + threadIdx.x;
     if (c >> P.log_m) return;
     const size_t i = P.log_m ? (size_t)(__brevll((unsigned long long)c) >> (64 - P.log_m)) : 0;
     const f252::E xinv = f252::mul(pow2l(P.tw_lo, P.tw_hi, P.lo_bits, i), f252::E{{P.hinv[0], P.hinv[1], P.hinv[2], P.hinv[3]}});
     f252::E A[FF];
-    #pragma unroll
+    #pragma clang loop unroll(full)
     for (int q = 0; q < FF; q++) A[q] = ld(P.src, c * FF + q);
-    #pragma unroll
+    #pragma clang loop unroll(full)
     for (int s = 1; s <= LOGF; s++) {
         constexpr int dummy = 0; (void)dummy;
         const int half = 1 << (s - 1);
-        #pragma unroll
+        #pragma clang loop unroll(full)
         for (int q = 0; q < FF / 2; q++) {
             const int k = q & (half - 1), lo = ((q >> (s - 1)) << s) + k, hi = lo + half;
             const int e = k << (LOGF - s);
@@ -122,7 +143,7 @@ __global__ void __launch_bounds__(NT) fri_fold252(Fold252Params P) {
     }
     const f252::E beta = f252::mul(f252::E{{P.alpha[0], P.alpha[1], P.alpha[2], P.alpha[3]}}, xinv);
     f252::E acc = A[FF - 1];
-    #pragma unroll
+    #pragma clang loop unroll(full)
     for (int k = FF - 2; k >= 0; k--) acc = f252::add(f252::mul(acc, beta), A[k]);
     st(P.dst, c, acc);
 }

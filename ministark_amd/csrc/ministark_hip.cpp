@@ -340,7 +340,10 @@ static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* 
     p->ctx = ctx; p->V = 4; p->log_n = log_n; p->inverse = inverse; p->coset = coset; p->is252 = true;
     const size_t n = (size_t)1 << log_n;
     const f252::E w = inverse ? f252::inv(gen) : gen;
-    p->lo_bits = std::min(10u, log_n);
+    // one-level tables up to 2^21 points: every twiddle / scale factor is a single 32-byte load.  (A two-level
+    // lookup costs a second Montgomery product per butterfly, and the product -- ~440 VALU instructions -- is
+    // what bounds this field.)  Larger domains split the exponent at 2^21.
+    p->lo_bits = std::min(21u, log_n);
     std::vector<uint64_t> host, t;
     auto append = [&](const std::vector<uint64_t>& v) { size_t off = host.size(); host.insert(host.end(), v.begin(), v.end()); return off; };
     powers252(t, (size_t)1 << p->lo_bits, w, f252::one()); const size_t o_lo = append(t);
@@ -519,10 +522,14 @@ static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst,
             ProfScope ps(ctx, "ntt252_local", 64.0 * n);
             hipLaunchKernelGGL(ms252::ntt252_local, dim3((unsigned)(n >> clog)), dim3(ms252::NT), 0, st, P);
         }
-        for (unsigned s = clog + 1; s <= p->log_n; s++) {
+        for (unsigned s = clog; s < p->log_n;) {                 // stages s+1 .. s+R per launch
+            const unsigned R = std::min(ms252::MAX_FUSED_STAGES, p->log_n - s);
             P.stage = s;
-            ProfScope ps(ctx, "ntt252_stage", 64.0 * n);
-            hipLaunchKernelGGL(ms252::ntt252_stage, dim3((unsigned)((n / 2 + ms252::NT - 1) / ms252::NT)), dim3(ms252::NT), 0, st, P);
+            const dim3 g((unsigned)(((n >> R) + ms252::NT - 1) / ms252::NT));
+            ProfScope ps(ctx, "ntt252_stages", 64.0 * n);
+            if (R == 1) hipLaunchKernelGGL(ms252::ntt252_stages<1>, g, dim3(ms252::NT), 0, st, P);
+            else hipLaunchKernelGGL(ms252::ntt252_stages<2>, g, dim3(ms252::NT), 0, st, P);
+            s += R;
         }
     }
     HIPCHK(hipGetLastError());
