@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Random constraint expressions through compile_expr -> ms_eval_program (table hoisting, x^e lookups,
+interpreter on small domains, hiprtc-specialised kernels on 2^16 points) against the oracle's direct
+evaluation at sampled points:   python scripts/fuzz_eval.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.setrecursionlimit(10000)
+from oracle import cref  # noqa: E402  (the checker)
+from oracle.pyref import evalexpr  # noqa: E402
+from oracle.pyref.fields import GL  # noqa: E402
+from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3, GpuVec, Planner  # noqa: E402
+from ministark_amd import expr as E  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+pl = Planner(0)
+P = GL.p
+
+
+def rand_expr(depth, nbase, next_, nch, log_n):
+    r = rng.random()
+    if depth == 0 or r < 0.18:
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            return E.X()
+        if k == 1:
+            return E.Constant(int(rng.integers(0, 1 << 62)))
+        if k == 2 and nch:
+            return E.Challenge(int(rng.integers(0, nch)))
+        if k == 3 and next_:
+            return E.Trace(nbase + int(rng.integers(0, next_)), int(rng.integers(-2, 3)))
+        if k == 4:
+            return E.X() ** int(rng.choice([1, 2, 3, 8, 64, 1 << int(rng.integers(3, log_n + 2)), int(rng.integers(5, 1 << 20))]))
+        return E.Trace(int(rng.integers(0, nbase)), int(rng.integers(-2, 3)))
+    a = rand_expr(depth - 1, nbase, next_, nch, log_n)
+    if r < 0.28:
+        return -a
+    if r < 0.36:
+        return a ** int(rng.integers(0, 9))
+    b = rand_expr(depth - 1, nbase, next_, nch, log_n)
+    if r < 0.62:
+        return a + b
+    if r < 0.72:
+        return a - b
+    if r < 0.92:
+        return a * b
+    return a / b                               # 0^-1 = 0 on both sides
+
+
+def canon(arr, V):
+    a = [GL.from_mont(int(x)) for x in arr]
+    return a if V == 1 else [tuple(a[3 * i:3 * i + 3]) for i in range(len(a) // 3)]
+
+
+t0, count, jit = time.time(), 0, 0
+while time.time() - t0 < budget:
+    log_n = int(rng.choice([6, 9, 12, 12, 13, 16]))
+    n = 1 << log_n
+    fq_is_ext = bool(rng.integers(0, 2))
+    nbase, next_, nch = int(rng.integers(1, 4)), (int(rng.integers(0, 3)) if fq_is_ext else 0), int(rng.integers(0, 3))
+    lde_step, offset = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 3, 7]))
+    expr = rand_expr(int(rng.integers(2, 6)), nbase, next_, nch, log_n)
+    qw = 3 if fq_is_ext else 1
+    base = [cref.random_elements(n, seed * 1000 + count * 7 + c) for c in range(nbase)]
+    ext = [cref.random_elements(3 * n, seed * 1000 + count * 7 + 50 + c) for c in range(next_)]
+    ch = cref.random_elements(max(nch, 1) * qw, count + 90).reshape(-1, qw)
+    prog = E.compile_expr(expr, nbase, fq_is_ext)
+    out = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
+                 [GpuVec.from_numpy(pl, c, FQ3) for c in ext]).to_numpy()
+    pts = sorted(set([0, 1, n - 1, n // 2] + [int(x) for x in rng.integers(0, n, size=6)]))
+    qc = (lambda r: tuple(GL.from_mont(int(x)) for x in r)) if fq_is_ext else (lambda r: GL.from_mont(int(r[0])))
+    cb = [canon(c, 1) for c in base] if log_n <= 13 else None
+    if cb is None:                              # large domain: convert only the rows the oracle will touch
+        need = sorted({(i + lde_step * o) % n for i in pts for o in range(-2, 3)})
+        cb = [{j: GL.from_mont(int(c[j])) for j in need} for c in base]
+        ce = [{j: tuple(GL.from_mont(int(x)) for x in c[3 * j:3 * j + 3]) for j in need} for c in ext]
+    else:
+        ce = [canon(c, 3) for c in ext]
+    want = evalexpr.eval_points(expr, pts, n, lde_step, offset, cb, ce, [qc(r) for r in ch], [qc(r) for r in ch[:1]], fq_is_ext)
+    for i, w in zip(pts, want):
+        got = tuple(GL.from_mont(int(x)) for x in out[qw * i:qw * i + qw])
+        if got != (w if fq_is_ext else (w,)):
+            print(f"MISMATCH case {count} (seed {seed}): log_n={log_n} fq_is_ext={fq_is_ext} lde_step={lde_step} offset={offset} point {i}; {len(prog.instrs)} instructions")
+            sys.exit(1)
+    count += 1
+    jit += log_n >= 16
+print(f"fuzz_eval ok: {count} random programs ({jit} through the specialised-kernel path) in {time.time() - t0:.0f} s (seed {seed})")
