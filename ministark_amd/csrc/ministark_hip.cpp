@@ -1301,11 +1301,47 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
             E.periodic[nperiodic + t] = tp; E.periodic_len[nperiodic + t] = (uint32_t)period;
             tp += split.table_words[t] * period;
         }
-        EvalParams Q = E;
-        Q.prog = (const Instr*)((char*)ctx->prog_buf + poff); Q.ninstr = pro_n;
-        Q.n = period; Q.log_n = split.log_period; Q.xshift = table_log - log_n;      // the first points of the same domain
-        ProfScope ps(ctx, "eval_prologue", 0.0);
-        launch(Q, nullptr);                                   // runs on a few points: not worth a compilation
+        // Fp252 with a handful of points: one lane running the 252-bit Fermat inverse is ~0.6 ms of pure latency on
+        // the device and microseconds on a host core -- the same fp252.h functions, so the same values
+        bool on_host = false;
+        if (is252 && period <= 64 && !d_x_lde) {
+            on_host = true;
+            for (auto& I : split.prologue) if (I.op == OP_PERIODIC_P) on_host = false;       // caller tables live on the device
+        }
+        if (on_host) {
+            std::vector<uint64_t> host_tabs(words, 0);
+            const f252::E w = f252::root_of_unity(log_n);
+            f252::E xi = h252;                                                                // x_i = h * w^i
+            std::vector<f252::E> rp(256);
+            for (size_t i = 0; i < period; i++) {
+                for (auto& I : split.prologue) {
+                    switch (I.op) {
+                    case OP_X_P: rp[I.dst] = xi; break;
+                    case OP_CONST_P: memcpy(rp[I.dst].l, &consts[I.a], 32); break;
+                    case OP_NEG_P: rp[I.dst] = f252::neg(rp[I.a]); break;
+                    case OP_ADD_PP: rp[I.dst] = f252::add(rp[I.a], rp[I.b]); break;
+                    case OP_MUL_PP: rp[I.dst] = f252::mul(rp[I.a], rp[I.b]); break;
+                    case OP_INV_P: rp[I.dst] = f252::inv(rp[I.a]); break;
+                    case OP_POW_P: rp[I.dst] = f252::pow_u64(rp[I.a], I.b); break;
+                    case OP_STORE_P: {
+                        size_t off = 0;
+                        for (unsigned t = 0; t + nperiodic + 1 < I.b; t++) off += split.table_words[t] * period;
+                        memcpy(&host_tabs[off + 4 * i], rp[I.a].l, 32);
+                    } break;
+                    default: break;
+                    }
+                }
+                xi = f252::mul(xi, w);
+            }
+            HIPCHK(hipMemcpyAsync(tables, host_tabs.data(), words * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));           // host_tabs is pageable and about to go out of scope
+        } else {
+            EvalParams Q = E;
+            Q.prog = (const Instr*)((char*)ctx->prog_buf + poff); Q.ninstr = pro_n;
+            Q.n = period; Q.log_n = split.log_period; Q.xshift = table_log - log_n;      // the first points of the same domain
+            ProfScope ps(ctx, "eval_prologue", 0.0);
+            launch(Q, nullptr);                                   // runs on a few points: not worth a compilation
+        }
     }
     E.prog = (const Instr*)ctx->prog_buf; E.ninstr = main_n; E.n = n; E.log_n = log_n; E.xshift = table_log - log_n;
     {

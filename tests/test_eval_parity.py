@@ -185,7 +185,7 @@ def test_specialised_kernels_2_16_hip():
     assert prof.get("eval_program_jit", {}).get("calls", 0) >= 3, prof.keys()
 
 
-def _check252(kind, log_n):
+def _check252(kind, log_n, small_period=False):
     from oracle.pyref.fields import F252
     from ministark_amd import STARK252_FP, f252_from_mont_limbs, f252_to_mont_limbs
     pl = backends.planner(kind)
@@ -197,7 +197,11 @@ def _check252(kind, log_n):
     ch = [int.from_bytes(rng.bytes(32), "little") % F252.p for _ in range(2)]
     x = E.X()
     expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) / (x ** 4 - 1) + E.Trace(2, -1) ** 3 * E.Challenge(1) + E.Constant(12345678901234567890123) / x + E.Challenge(0) \
-        + E.Trace(1) / ((x ** 128 - 1) * (x ** 64 - 7)) + x ** 77777 * E.Trace(0)       # hoisted table + x^e lookup (csrc/eval_opt.h)
+        + E.Trace(1) / ((x ** 128 - 1) * (x ** 8 - 7)) + x ** 77777 * E.Trace(0)       # hoisted table (128 points: device prologue) + x^e lookup (csrc/eval_opt.h)
+    if small_period:
+        # zerofier of a blow-up-4 LDE: 4 distinct values, tabulated on the host (the same fp252.h functions)
+        N = n // 4
+        expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) * (x - 5) / (x ** N - 1) * (E.Challenge(0) * x ** 3 + E.Challenge(1)) + E.Trace(2) / (x ** (2 * N) + 3)
     prog = E.compile_expr(expr, ncols, fq_is_ext=False, base_field=STARK252_FP)
     dev = [GpuVec.from_numpy(pl, np.concatenate([f252_to_mont_limbs(v) for v in c]), STARK252_FP) for c in cols]
     chm = np.stack([f252_to_mont_limbs(v) for v in ch])
@@ -216,6 +220,12 @@ def _check252(kind, log_n):
 def test_fp252_program(kind):                      # src/eval_gpu.rs:1054-1082: constants / columns on Fp252
     prof = _check252(kind, 10)
     assert "eval_prologue" in prof and "eval_program252" in prof
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fp252_small_tables_from_the_host(kind):
+    prof = _check252(kind, 10, small_period=True)
+    assert "eval_prologue" not in prof and "eval_program252" in prof
 
 
 @pytest.mark.gpu
