@@ -5,7 +5,7 @@
 //
 // p = 1 (mod 2^64), so -p^-1 = 2^64 - 1 (felt_u256.h.metal:104 N_PRIME's low limb) and a
 // Montgomery reduction step  t += m*p  with  m = -t0  costs ONE wide multiply: m*p = m + m*p3*2^192.
-// This field is compute-bound on any GPU (>= 20 64x64 products per multiplication); no attempt is
+// This field is compute-bound on any GPU (81 32x32 products per multiplication); no attempt is
 // made here to reach an HBM roofline.
 #pragma once
 #if !defined(__HIPCC_RTC__)
@@ -58,34 +58,70 @@ MS_HD E neg(const E& a) {
 }
 MS_HD E sub(const E& a, const E& b) { return add(a, neg(b)); }      // felt_u256.h.metal:134-140
 
-// Montgomery product a*b*2^-256 mod p (CIOS, 4 limbs), canonical in/out
+// Montgomery product a*b*2^-256 mod p, canonical in/out.
+// On gfx950 every carry-consuming instruction issues at half rate and the compiler's expansion of a 4-limb
+// CIOS with 128-bit temporaries costs ~440 VALU instructions (214 of them add-with-carry).  Here the operands
+// are cut into nine 28-bit digits: the 81 digit products accumulate into 64-bit columns that cannot overflow
+// (9 * 2^56 < 2^60), so the whole product is 81 v_mad_u64_u32 and no carry handling; the reduction stays in
+// the same lazy columns (p = 1 mod 2^28: m = -c_k mod 2^28, and m*p = m + 17m*2^192 + m*2^251 is two more
+// multiply-adds into columns k+6 and k+8); eight rounds of 28 bits and one of 32 make R = 2^256 exactly, so
+// the value is the arkworks Montgomery product bit for bit.  ~250 instructions.
 MS_HD E mul(const E& a, const E& b) {
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-    #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            c += (u128)a.l[j] * b.l[i] + t[j];
-            t[j] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t[4];
-        t[4] = (uint64_t)c;
-        t[5] = (uint64_t)(c >> 64);
-        // m = -t0 ; t += m*p = m + m*P3*2^192 ; then shift one limb
-        const uint64_t m = 0 - t[0];
-        u128 d = (u128)t[0] + m;                  // low limb becomes 0, carry = (t0 != 0)
-        uint64_t carry = (uint64_t)(d >> 64);
-        d = (u128)t[1] + carry; t[0] = (uint64_t)d; carry = (uint64_t)(d >> 64);
-        d = (u128)t[2] + carry; t[1] = (uint64_t)d; carry = (uint64_t)(d >> 64);
-        d = (u128)m * P3 + t[3] + carry; t[2] = (uint64_t)d;
-        d = (u128)t[4] + (uint64_t)(d >> 64); t[3] = (uint64_t)d;
-        t[4] = t[5] + (uint64_t)(d >> 64);
+    constexpr uint32_t M = (1u << 28) - 1;
+    uint32_t x[9], y[9];
+    {
+        const uint64_t w0 = a.l[0], w1 = a.l[1], w2 = a.l[2], w3 = a.l[3];
+        x[0] = (uint32_t)w0 & M; x[1] = (uint32_t)(w0 >> 28) & M; x[2] = (uint32_t)((w0 >> 56) | (w1 << 8)) & M;
+        x[3] = (uint32_t)(w1 >> 20) & M; x[4] = (uint32_t)((w1 >> 48) | (w2 << 16)) & M; x[5] = (uint32_t)(w2 >> 12) & M;
+        x[6] = (uint32_t)((w2 >> 40) | (w3 << 24)) & M; x[7] = (uint32_t)(w3 >> 4) & M; x[8] = (uint32_t)(w3 >> 32);
     }
-    E r = {{t[0], t[1], t[2], t[3]}};
-    return (t[4] || geq_p(r)) ? sub_p(r) : r;
+    {
+        const uint64_t w0 = b.l[0], w1 = b.l[1], w2 = b.l[2], w3 = b.l[3];
+        y[0] = (uint32_t)w0 & M; y[1] = (uint32_t)(w0 >> 28) & M; y[2] = (uint32_t)((w0 >> 56) | (w1 << 8)) & M;
+        y[3] = (uint32_t)(w1 >> 20) & M; y[4] = (uint32_t)((w1 >> 48) | (w2 << 16)) & M; y[5] = (uint32_t)(w2 >> 12) & M;
+        y[6] = (uint32_t)((w2 >> 40) | (w3 << 24)) & M; y[7] = (uint32_t)(w3 >> 4) & M; y[8] = (uint32_t)(w3 >> 32);
+    }
+    // columns c[k] = sum_{i+j=k} x_i y_j  (< 9 * 2^56: no overflow, no carries)
+    uint64_t c[19];
+    #pragma unroll
+    for (int k = 0; k < 19; k++) c[k] = 0;
+    #pragma unroll
+    for (int i = 0; i < 9; i++) {
+        #pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)x[i] * y[j];
+    }
+    // eight reduction rounds of 28 bits: m = -c_k mod 2^28, c += m * p * 2^(28k), p = 1 + 17*2^192 + 2^251
+    uint64_t carry = 0;
+    #pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint64_t t = c[k] + carry;
+        const uint32_t m = (0u - (uint32_t)t) & M;
+        carry = (t + m) >> 28;
+        c[k + 6] += (uint64_t)m * (17u << 24);
+        c[k + 8] += (uint64_t)m << 27;
+    }
+    // one round of 32 bits completes R = 2^256 (8*28 + 32)
+    {
+        c[8] += carry;
+        const uint32_t low = (uint32_t)c[8] + ((uint32_t)c[9] << 28);
+        const uint32_t m = 0u - low;
+        c[8] += m;
+        c[14] += ((uint64_t)m * 17u) << 24;
+        c[16] += (uint64_t)m << 27;
+    }
+    // digits d_8 .. d_18 (d_8 = 0 and the low 4 bits of d_9 are 0), result = sum_j d_j 2^(28(j-9) - 4)
+    uint32_t d[19];
+    uint64_t cr = 0;
+    #pragma unroll
+    for (int k = 8; k < 19; k++) { const uint64_t t = c[k] + cr; d[k] = (uint32_t)t & M; cr = t >> 28; }
+    E r;
+    r.l[0] = (uint64_t)(d[9] >> 4) | ((uint64_t)d[10] << 24) | ((uint64_t)d[11] << 52);
+    r.l[1] = (uint64_t)(d[11] >> 12) | ((uint64_t)d[12] << 16) | ((uint64_t)d[13] << 44);
+    r.l[2] = (uint64_t)(d[13] >> 20) | ((uint64_t)d[14] << 8) | ((uint64_t)d[15] << 36);
+    r.l[3] = (uint64_t)d[16] | ((uint64_t)d[17] << 28) | ((uint64_t)d[18] << 56);
+    return geq_p(r) ? sub_p(r) : r;
 }
+
 MS_HD E to_mont(const E& canon) { return mul(canon, E{{R2_L[0], R2_L[1], R2_L[2], R2_L[3]}}); }
 MS_HD E from_mont(const E& m) { return mul(m, E{{1, 0, 0, 0}}); }
 MS_HD E pow(E a, const uint64_t* e, int nlimbs) {

@@ -139,3 +139,38 @@ def test_fri_fold_252(kind, ff, offset):                # apply_drp, src/fri.rs:
     alpha = _rand_canon(1, 99)[0]
     got = _from_dev(apply_drp(_to_dev(pl, evals), f252_to_mont_limbs(alpha), ff, offset))
     assert got == ofri.apply_drp(F.F252, None, evals, offset, alpha, ff)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_mul_edge_values_252(kind):
+    # the product works on nine 28-bit digits with lazy 64-bit columns (csrc/fp252.h): digit boundaries, all-ones
+    # digits, values next to p and sparse limbs are where such a scheme would break
+    pl = backends.planner(kind)
+    n = 1 << (10 if kind == "emu" else 14)
+    rng = np.random.default_rng(11)
+    M = (1 << 28) - 1
+    edge = [0, 1, 2, P - 1, P - 2, P - (1 << 28), (1 << 28) - 1, 1 << 28, (1 << 252) - 1 - (1 << 200), (1 << 251), (1 << 251) + 17 * (1 << 192),
+            sum(M << (28 * k) for k in range(0, 9, 2)) % P, sum(M << (28 * k) for k in range(1, 9, 2)) % P, (1 << 224) - 1, 1 << 224, (1 << 192) * 17, P >> 1]
+    def draw():
+        out = []
+        for _ in range(n):
+            r = rng.random()
+            if r < 0.35:
+                out.append(edge[int(rng.integers(0, len(edge)))] % P)
+            elif r < 0.55:
+                v = 0
+                for k in range(9):
+                    v |= int(rng.choice([0, M, 1, M - 1, int(rng.integers(0, M + 1))])) << (28 * k)
+                out.append(v % P)
+            else:
+                out.append(int.from_bytes(rng.bytes(32), "little") % P)
+        return out
+    a, b = draw(), draw()              # these are the words the kernel sees (Montgomery representatives), patterns intact
+    limbs = lambda vals: np.array([(v >> (64 * k)) & ((1 << 64) - 1) for v in vals for k in range(4)], dtype=np.uint64)
+    A, B, D = GpuVec.from_numpy(pl, limbs(a), STARK252_FP), GpuVec.from_numpy(pl, limbs(b), STARK252_FP), GpuVec(pl, n, STARK252_FP)
+    S.MulIntoStage(pl, n, STARK252_FP).encode(D, A, B, 1)
+    got = D.to_numpy().reshape(n, 4)
+    rinv = pow(1 << 256, -1, P)
+    for i in range(n):
+        v = int(got[i][0]) | int(got[i][1]) << 64 | int(got[i][2]) << 128 | int(got[i][3]) << 192
+        assert v == a[i] * b[(i + 1) % n] * rinv % P, f"element {i}"
