@@ -341,3 +341,42 @@ def test_composition_poly_chunks(kind):                 # src/prover.rs:113-121
         elems = poly.reshape(n, V)
         for c in range(k):
             assert np.array_equal(cols[c].reshape(-1, V), elems[c::k])
+
+
+# --- the largest domains: known-answer transforms generated and sampled on the device ---------------
+def _big_known_answer(log_n):
+    """NTT of the polynomial c0 + c1*X + c2*X^(n-1) on coset(n, 7) is c0 + c1*x_i + c2*x_i^(n-1): checked at
+    sampled positions (8-byte downloads), then the inverse must restore the three coefficients and zeros."""
+    import ctypes
+    from oracle.pyref.fields import GL
+    from ministark_amd import stages as S, gl_to_mont
+    pl = backends.planner("hip")
+    L = pl.lib
+    n = 1 << log_n
+    v = GpuVec(pl, n, GOLDILOCKS_FP)
+    S.FillBuffStage(pl, n, GOLDILOCKS_FP).encode(v, np.zeros(1, dtype=np.uint64))
+    c0, c1, c2 = 0x1234567, 0xabcdef0123, 0x77777777777
+    for pos, c in ((0, c0), (1, c1), (n - 1, c2)):
+        w = ctypes.c_uint64(gl_to_mont(c))
+        L.check(L.ms_upload(pl.handle, v.ptr + 8 * pos, ctypes.byref(w), 8))
+    dom = Radix2EvaluationDomain(n, 7)
+    f = GpuFft(dom, GOLDILOCKS_FP, pl); f.encode(v); f.execute(); f.close()
+    rng = np.random.default_rng(log_n)
+    wn = GL.root_of_unity(n)
+    for i in [0, 1, n - 1, n // 2, n // 2 + 1] + [int(x) for x in rng.integers(0, n, size=40)]:
+        out = ctypes.c_uint64(0)
+        L.check(L.ms_download(pl.handle, ctypes.byref(out), v.ptr + 8 * i, 8))
+        x = 7 * pow(wn, i, GL.p) % GL.p
+        assert GL.from_mont(out.value) == (c0 + c1 * x + c2 * pow(x, n - 1, GL.p)) % GL.p, f"position {i}"
+    g = GpuIfft(dom, GOLDILOCKS_FP, pl); g.encode(v); g.execute(); g.close()
+    for pos, c in ((0, c0), (1, c1), (n - 1, c2), (2, 0), (n // 2, 0), (n - 2, 0), (12345678 % n, 0)):
+        out = ctypes.c_uint64(1)
+        L.check(L.ms_download(pl.handle, ctypes.byref(out), v.ptr + 8 * pos, 8))
+        assert GL.from_mont(out.value) == c, f"coefficient {pos}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [30, 32])
+def test_known_answer_largest_domains_hip(log_n):
+    # 2^32 is the field's whole two-adic subgroup (32 GiB column + 32 GiB of scratch): the maximum size there is
+    _big_known_answer(log_n)
