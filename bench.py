@@ -135,7 +135,7 @@ def main():
                      "algorithmic_bytes_per_transform": alg_bytes_col,
                      "us_per_transform_events": round(us_per_transform, 2), "kernels": kernels},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
         from oracle import cref
         x = host_cols[0].copy()
         cref.ntt(x[: 1 << 16], 16, 1, False, 7)          # warm the OpenMP pool
