@@ -83,7 +83,10 @@ struct ms_ctx {
     hipStream_t stream = nullptr;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
-    size_t group_bytes = (size_t)32 << 20;   // columns are processed in groups of about this size
+    // columns are processed in groups of about this size (= the scratch buffer).  Measured at 2^24: one column per
+    // launch (4096 tiles = exactly two rounds of resident workgroups) loses 5 % of kernel time to the launch tail
+    // against 8 columns per launch; the passes are VALU-bound, so there is no cache-locality argument for small groups.
+    size_t group_bytes = (size_t)1 << 30;
     std::mutex mu;
     // freed device blocks, by size: GpuVec churn (clone / resize in src/matrix.rs:155-208, the LdeCache of
     // src/eval_gpu.rs:857-898) must not cost a hipMalloc + hipFree pair per column.  All work is ordered on
