@@ -22,11 +22,13 @@ def one(pattern):
     return hits[0] if hits else None
 
 
-def counters(path):
-    """-> {kernel: {counter: [values per dispatch]}}"""
+def counters(path, per_column=False):
+    """-> {kernel: {counter: [values per dispatch]}}; per_column divides by the columns a launch covers
+    (grid = 4096 tiles x 256 threads per 2^24 column)."""
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        cols = max(1.0, float(r["Grid_Size"]) / (4096 * 256)) if per_column and "msntt" in r["Kernel_Name"] else 1.0
+        out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]) / cols)
     return out
 
 
@@ -39,17 +41,17 @@ if stats:
         w.writerows(rows)
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --cols 2 --no-cpu-baseline",
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream's bytes); WRITE_SIZE as reported. "
-                   "Units: KB = 1024 B. Per launch = one column (2^24 x 8 B).", "kernels": {}}
+                   "Units: KB = 1024 B. Normalised to one column (2^24 x 8 B); a launch covers several columns.", "kernels": {}}
 fetch, write = one("pmc_fetch/**/*counter_collection.csv"), one("pmc_write/**/*counter_collection.csv")
 if fetch and write:
-    fc, wc = counters(fetch), counters(write)
+    fc, wc = counters(fetch, True), counters(write, True)
     total = 0.0
     for k in fc:
         if "msntt" not in k:
             continue
-        fb = 2 * 1024 * sum(fc[k]["FETCH_SIZE"]) / len(fc[k]["FETCH_SIZE"])      # one 2^24 column per launch (128 MiB columns exceed the 32 MiB launch group)
+        fb = 2 * 1024 * sum(fc[k]["FETCH_SIZE"]) / len(fc[k]["FETCH_SIZE"])      # per 2^24 column
         wb = 1024 * sum(wc[k]["WRITE_SIZE"]) / len(wc[k]["WRITE_SIZE"])
-        traffic["kernels"][k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb}
+        traffic["kernels"][k] = {"fetch_bytes_per_column": fb, "write_bytes_per_column": wb}
         total += fb + wb
         shutil.copy(fetch, os.path.join(PROF, f"{tag}_ntt_pmc_fetch_size.csv"))
         shutil.copy(write, os.path.join(PROF, f"{tag}_ntt_pmc_write_size.csv"))
@@ -60,10 +62,10 @@ for name, dst in (("pmc_sq", "ntt_sq_counters"), ("pmc_sha", "sha256_sq_counters
     p = one(f"{name}/**/*counter_collection.csv")
     if not p:
         continue
-    c = counters(p)
+    c = counters(p, True)
     with open(os.path.join(PROF, f"{tag}_{dst}.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "dispatches", "counter", "mean_per_dispatch"])
+        w.writerow(["kernel", "dispatches", "counter", "mean_per_dispatch (NTT passes: per 2^24 column)"])
         for k in sorted(c):
             if "msntt" in k or "mssha" in k:
                 for cn, vals in sorted(c[k].items()):
