@@ -1,0 +1,139 @@
+"""The whole data-parallel prover pipeline against the oracle, bit for bit, on the shape of BASELINE config C1
+(examples/brainfuck: 17 base Fp + 9 extension Fq3 columns, blow-up 16, FRI folding factor 16,
+examples/brainfuck/main.rs:92-105; 128 rows here so that the big-integer oracle finishes in seconds).
+Every phase of default_prove (src/prover.rs:25-174) that touches column data runs through the library;
+the channel's draws are replaced by fixed values on both sides:
+
+    base / extension trace: interpolate -> bit-reversed LDE -> Merkle root          prover.rs:50-79
+    constraint evaluation on the LDE coset                                          prover.rs:98-107
+    composition polynomial: iNTT -> chunks -> bit-reversed LDE -> Merkle root       prover.rs:110-124
+    DEEP: out-of-domain evaluations, composition polynomial, its LDE                prover.rs:136-153
+    FRI: commit + fold layers down to the remainder                                 fri.rs:179-249
+    queries: rows and batched openings of the three trees                           trace.rs:113-157
+"""
+import numpy as np
+import pytest
+
+from oracle.pyref import deep as odeep
+from oracle.pyref import evalexpr, fri as ofri, merkle as omerkle
+from oracle.pyref import ntt as ontt
+from oracle.pyref.fields import FQ3, GL, bit_reverse
+from tests import backends
+from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3F, GpuVec, Matrix, MerkleTree, Queries, Radix2EvaluationDomain, apply_drp
+from ministark_amd import expr as E
+from ministark_amd.composer import DeepCompositionCoeffs, DeepPolyComposer
+
+P = GL.p
+KINDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+NBASE, NEXT, BLOWUP, FOLD, OFFSET = 17, 9, 16, 16, 7
+
+
+def _mont(vals, ext):
+    flat = [c for v in vals for c in v] if ext else vals
+    return np.array([GL.to_mont(c) for c in flat], dtype=np.uint64)
+
+
+def _canon(arr, ext):
+    a = [GL.from_mont(int(x)) for x in arr]
+    return [tuple(a[3 * i:3 * i + 3]) for i in range(len(a) // 3)] if ext else a
+
+
+def _mat(pl, cols, ext):
+    return Matrix([GpuVec.from_numpy(pl, _mont(c, ext), FQ3F if ext else FP) for c in cols])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_prover_pipeline_c1_shape(kind):
+    pl = backends.planner(kind)
+    rng = np.random.default_rng(2024)
+    n = 128
+    N = n * BLOWUP
+    rq = lambda: tuple(int(x) for x in rng.integers(0, 1 << 62, size=3))
+    base = [[int(x) for x in rng.integers(0, 1 << 62, size=n)] for _ in range(NBASE)]
+    ext = [[rq() for _ in range(n)] for _ in range(NEXT)]
+    challenges = [rq() for _ in range(4)]
+    trace_dom, lde_dom = Radix2EvaluationDomain(n), Radix2EvaluationDomain(N, OFFSET)
+    o_trace, o_lde = ontt.Domain(GL, n), ontt.Domain(GL, N, OFFSET)
+
+    # ---- base / extension trace commitments
+    base_polys = _mat(pl, base, False).interpolate(trace_dom)
+    ext_polys = _mat(pl, ext, True).interpolate(trace_dom)
+    base_lde, ext_lde = base_polys.bit_reversed_evaluate(lde_dom), ext_polys.bit_reversed_evaluate(lde_dom)
+    base_tree, ext_tree = MerkleTree.from_matrix(base_lde), MerkleTree.from_matrix(ext_lde)
+    o_base_polys = [ontt.ifft(o_trace, c) for c in base]
+    o_ext_polys = [ontt.ifft(o_trace, c) for c in ext]
+    o_base_nat = [ontt.fft(o_lde, c) for c in o_base_polys]
+    o_ext_nat = [ontt.fft(o_lde, c) for c in o_ext_polys]
+    o_base_lde, o_ext_lde = [bit_reverse(c) for c in o_base_nat], [bit_reverse(c) for c in o_ext_nat]
+    o_base_leaves, o_ext_leaves = omerkle.hash_rows(GL, o_base_lde), omerkle.hash_rows(FQ3, o_ext_lde)
+    o_base_nodes, o_ext_nodes = omerkle.build_merkle_nodes(o_base_leaves), omerkle.build_merkle_nodes(o_ext_leaves)
+    assert base_tree.root() == o_base_nodes[1] and ext_tree.root() == o_ext_nodes[1]
+
+    # ---- constraint evaluation over the LDE coset (natural order), 9 permutation-style constraints over a zerofier
+    x = E.X()
+    b = lambda c, o=0: E.Trace(c, o)
+    e = lambda c, o=0: E.Trace(NBASE + c, o)
+    expr = None
+    for k in range(NEXT):
+        t = (e(k, 1) - e(k) * (E.Challenge(k % 4) - b(k) * E.Challenge((k + 1) % 4) - b(k + 8, 1))) * (x - 1) / (x ** n - 1)
+        expr = t if expr is None else expr + t * E.Challenge(k % 4)
+    prog = E.compile_expr(expr, NBASE, True)
+    ch = _mont(challenges, True).reshape(-1, 3)
+    base_nat, ext_nat = base_lde.clone().bit_reverse_rows(), ext_lde.clone().bit_reverse_rows()
+    comp_evals = E.eval(prog, pl, ch, ch[:1], BLOWUP, OFFSET, N, base_nat.columns, ext_nat.columns)
+    o_comp_evals = evalexpr.eval_points(expr, list(range(N)), N, BLOWUP, OFFSET, o_base_nat, o_ext_nat, challenges, challenges[:1], True)
+    assert _canon(comp_evals.to_numpy(), True) == o_comp_evals
+
+    # ---- composition trace: coefficients, chunks(ce_blowup), LDE, commitment
+    comp_poly = Matrix([comp_evals]).into_polynomials(lde_dom).columns[0]
+    comp_polys = Matrix.from_chunks(comp_poly, BLOWUP)
+    comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)
+    comp_tree = MerkleTree.from_matrix(comp_lde)
+    o_comp_poly = ontt.ifft(o_lde, o_comp_evals)
+    o_comp_polys = [o_comp_poly[c::BLOWUP] for c in range(BLOWUP)]
+    o_comp_lde = [bit_reverse(ontt.fft(o_lde, c)) for c in o_comp_polys]
+    o_comp_leaves = omerkle.hash_rows(FQ3, o_comp_lde)
+    o_comp_nodes = omerkle.build_merkle_nodes(o_comp_leaves)
+    assert comp_tree.root() == o_comp_nodes[1]
+
+    # ---- DEEP composition
+    z = rq()
+    args = [(c, o) for c in range(NBASE + NEXT) for o in (0, 1)]
+    composer = DeepPolyComposer(args, n, z, base_polys, ext_polys, comp_polys)
+    got_exec, got_comp = composer.get_ood_evals()
+    g, g_inv = trace_dom.group_gen, trace_dom.group_gen_inv
+    want_exec, want_comp = odeep.get_ood_evals(z, g, g_inv, args, o_base_polys, o_ext_polys, o_comp_polys)
+    assert got_exec == want_exec and got_comp == want_comp
+    ea, ca, degree = [rq() for _ in args], [rq() for _ in range(BLOWUP)], (rq(), rq())
+    deep_poly = composer.into_deep_poly(DeepCompositionCoeffs(ea, ca, degree))
+    o_deep_poly = odeep.into_deep_poly(z, g, g_inv, args, o_base_polys, o_ext_polys, o_comp_polys, ea, ca, degree)
+    assert _canon(deep_poly.to_numpy(), True) == o_deep_poly
+    layer = Matrix([deep_poly]).into_bit_reversed_evaluations(lde_dom).columns[0]
+    o_layer = bit_reverse(ontt.fft(o_lde, o_deep_poly))
+    assert _canon(layer.to_numpy(), True) == o_layer
+
+    # ---- FRI layers (fri.rs:179-231): commit the layer, draw alpha, fold by 16, until the remainder is small
+    size, alphas = N, [rq() for _ in range(4)]
+    k = 0
+    while size > 64:
+        tree = MerkleTree.from_fri_layer(layer, FOLD)
+        rows = [[o_layer[r * FOLD + j] for r in range(size // FOLD)] for j in range(FOLD)]       # Matrix::from_arrays(as_chunks)
+        assert tree.root() == omerkle.merkle_root(omerkle.hash_rows(FQ3, rows))
+        layer = apply_drp(layer, _mont([alphas[k]], True), FOLD, 1)
+        o_layer = ofri.apply_drp(GL, FQ3, o_layer, 1, alphas[k], FOLD)
+        assert _canon(layer.to_numpy(), True) == o_layer
+        size //= FOLD
+        k += 1
+    assert k == 2 and size == 8
+
+    # ---- queries
+    positions = [int(p) for p in rng.integers(0, N, size=12)] + [0, N - 1]
+    q = Queries(base_lde, ext_lde, comp_lde, base_tree, ext_tree, comp_tree, positions)
+    for rows, o_cols, V in ((q.base_trace_values, o_base_lde, 1), (q.extension_trace_values, o_ext_lde, 3), (q.composition_trace_values, o_comp_lde, 3)):
+        for r, p in zip(rows, positions):
+            want = [c[p] for c in o_cols]
+            assert _canon(r, V == 3) == want
+    for proof, leaves, nodes in ((q.base_trace_proof, o_base_leaves, o_base_nodes), (q.extension_trace_proof, o_ext_leaves, o_ext_nodes),
+                                 (q.composition_trace_proof, o_comp_leaves, o_comp_nodes)):
+        assert proof == omerkle.prove(leaves, nodes, positions)
+        assert omerkle.verify(nodes[1], proof, positions)
