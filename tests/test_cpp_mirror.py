@@ -33,3 +33,29 @@ def test_cpp_mirror_parity_on_gpu():
     env = dict(os.environ, OMP_NUM_THREADS=str(cref._cpu_budget()))
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "cpp host mirror ok" in out.stdout, out.stdout + out.stderr
+
+
+EXAMPLE = os.path.join(ROOT, "examples", "fib_prover.cpp")
+EXAMPLE_BIN = os.path.join(ROOT, "tests", "cpp", "_build", "fib_prover")
+
+
+def _build_example():
+    from ministark_amd import build
+    so = build.build(verbose=False)
+    os.makedirs(os.path.dirname(EXAMPLE_BIN), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", EXAMPLE, "-o", EXAMPLE_BIN, so, "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"])
+    return EXAMPLE_BIN
+
+
+def test_fib_prover_example_compiles():
+    assert os.path.exists(_build_example())
+
+
+@pytest.mark.gpu
+def test_fib_prover_example_on_gpu():
+    # examples/fib on the device end to end: 2^14 rows here (the composition polynomial of the valid trace must have
+    # degree < n: checked inside), then once at 2^18 rows so that the specialised evaluator kernel is exercised
+    exe = _build_example()
+    for log_rows in ("14", "18"):
+        out = subprocess.run([exe, log_rows, "1"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "fib prover pipeline ok" in out.stdout, out.stdout + out.stderr
