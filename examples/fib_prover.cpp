@@ -93,16 +93,16 @@ int main(int argc, char** argv) {
         MerkleTree base_tree = MerkleTree::from_matrix(base_lde);
         auto base_root = base_tree.root();
         ph[0] = ms_since(t); t = Clock::now();
-        // 2. constraint evaluation over the LDE coset (natural order)                prover.rs:88-107
-        Matrix<Fp> nat = base_lde.clone();
-        nat.bit_reverse_rows();
+        // 2. constraint evaluation over the LDE coset, straight on the committed bit-reversed layout (the reference
+        //    re-orders all columns into natural order and back: bit_reverse_ce_trace)          prover.rs:88-107
         std::vector<const GpuVec<Fp>*> bc;
-        for (auto& c : nat.columns) bc.push_back(&c);
-        GpuVec<Fp> comp_evals = eval<Fp>(prog, pl, challenges, hints, 1u << log_blowup, 7, N, bc);
+        for (auto& c : base_lde.columns) bc.push_back(&c);
+        GpuVec<Fp> comp_evals = eval<Fp>(prog, pl, challenges, hints, 1u << log_blowup, 7, N, bc, {}, true);
         ph[1] = ms_since(t); t = Clock::now();
         // 3. composition trace: coefficients, LDE, commit                            prover.rs:110-124
         Matrix<Fp> cm;
         cm.columns.push_back(std::move(comp_evals));
+        cm.bit_reverse_rows();                                // one column back to natural order for the inverse transform
         cm.into_polynomials(lde_dom);
         if (!checked && log_rows <= 18) {                     // a valid trace gives a composition polynomial of degree < n
             auto coeffs = cm.columns[0].to_host();

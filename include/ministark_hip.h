@@ -188,6 +188,19 @@ int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const 
                     const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
                     int out_field, void* d_out);
 
+/* The same with flags.  MS_EVAL_BIT_REVERSED: the first 2^log_n entries of every trace column, and d_out, are in
+ * bit-reversed order over the evaluation domain (position R holds point bitrev(R)) -- the layout the LDE is committed in.
+ * The reference re-orders every column into natural order before evaluating and back afterwards
+ * (bit_reverse_ce_trace, src/prover.rs:88-91, 126-129, 185-194); here the evaluator reads the committed layout directly:
+ * consecutive positions differ in the high bits of the point index, so rotated rows are again consecutive positions
+ * and the loads stay coalesced.  d_out = the natural-order result, bit-reversed. */
+#define MS_EVAL_BIT_REVERSED 1u
+int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                       unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                       const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                       const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                       int out_field, void* d_out, unsigned flags);
+
 /* Diagnostics: compile the specialised kernel for a (validated-shape) program without launching it;
  * needs no device.  *code_bytes receives the size of the gfx950 code object; on failure returns
  * MS_ERR_UNSUPPORTED with the compiler log in ms_last_error(). */

@@ -64,6 +64,7 @@ class Lib:
             "ms_fill": (i, [vp, i, sz, vp, vp]),
             "ms_sum_columns": (i, [vp, i, sz, c_void_pp, u, vp]),
             "ms_eval_program": (i, [vp, vp, u, vp, u, u, u, vp, vp, c_void_pp, u, c_void_pp, u, c_void_pp, vp, u, i, vp]),
+            "ms_eval_program_ex": (i, [vp, vp, u, vp, u, u, u, vp, vp, c_void_pp, u, c_void_pp, u, c_void_pp, vp, u, i, vp, u]),
             "ms_eval_jit_check": (i, [vp, u, i, vp]),
             "ms_scan_affine": (i, [vp, i, sz, vp, vp, vp, i, vp]),
             "ms_gather_rows": (i, [vp, i, sz, c_void_pp, u, vp, sz, vp]),

@@ -29,7 +29,7 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
     s += "#include \"eval_kernels.h\"\nusing namespace mseval;\n";
     s += "extern \"C\" __global__ void __launch_bounds__(256) ms_eval_jit(EvalParams P) {\n";
     s += "    using F3 = msstage::Fq3T; using F1 = msstage::FpT; using F4 = msstage::Fp252T;\n";
-    s += "    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;\n    if (i >= P.n) return;\n";
+    s += "    const size_t R = (size_t)blockIdx.x * 256 + threadIdx.x;\n    if (R >= P.n) return;\n    const size_t i = ev_point(P, R);\n";
     char b[256];
     for (unsigned r = 0; r < maxp; r++) { snprintf(b, sizeof b, is252 ? "    f252::E p%u;\n" : "    uint64_t p%u;\n", r); s += b; }
     for (unsigned r = 0; r < maxq; r++) { snprintf(b, sizeof b, "    gl::Fq3 q%u;\n", r); s += b; }
@@ -48,7 +48,7 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
             case OP_MUL_PP: snprintf(b, sizeof b, "p%u = f252::mul(p%u, p%u);", d, x, y); break;
             case OP_INV_P: snprintf(b, sizeof b, "p%u = f252::inv(p%u);", d, x); break;
             case OP_POW_P: snprintf(b, sizeof b, "p%u = msstage::powu<F4>(p%u, %uu);", d, x, y); break;
-            case OP_STORE_P: snprintf(b, sizeof b, "ev252_store(P, i, %uu, p%u);", y, x); break;
+            case OP_STORE_P: snprintf(b, sizeof b, "ev252_store(P, R, %uu, p%u);", y, x); break;
             case OP_XPOW_P: snprintf(b, sizeof b, "p%u = ev252_xpow(P, i, %uu, %uu);", d, x, y); break;
             default: break;
             }
@@ -74,8 +74,8 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
             case OP_POW_P: snprintf(b, sizeof b, "p%u = msstage::powu<F1>(p%u, %uu);", d, x, y); break;
             case OP_POW_Q: snprintf(b, sizeof b, "q%u = msstage::powu<F3>(q%u, %uu);", d, x, y); break;
             case OP_EMBED: snprintf(b, sizeof b, "q%u = gl::Fq3{p%u, 0, 0};", d, x); break;
-            case OP_STORE_Q: snprintf(b, sizeof b, "ev_store_q(P, i, %uu, q%u);", y, x); break;
-            case OP_STORE_P: snprintf(b, sizeof b, "ev_store_p(P, i, %uu, p%u);", y, x); break;
+            case OP_STORE_Q: snprintf(b, sizeof b, "ev_store_q(P, R, %uu, q%u);", y, x); break;
+            case OP_STORE_P: snprintf(b, sizeof b, "ev_store_p(P, R, %uu, p%u);", y, x); break;
             case OP_XPOW_P: snprintf(b, sizeof b, "p%u = ev_xpow(P, i, %uu, %uu);", d, x, y); break;
             default: break;
             }

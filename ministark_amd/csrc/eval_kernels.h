@@ -50,13 +50,21 @@ struct EvalParams {
     size_t n;
     uint32_t ninstr, lo_bits, lde_step, log_n;
     uint32_t xshift;              // the w table belongs to a domain of 2^(log_n + xshift) points
+    uint32_t bitrev;              // columns and output are in bit-reversed order over the 2^log_n points: position R holds point bitrev(R)
 };
 
 
 // ---- the operations of the program, shared by the interpreter below and by the specialised kernels
 // eval_jit.h generates (one call per instruction, registers as named locals)
-__device__ __forceinline__ size_t ev_row(const EvalParams& P, size_t i, uint32_t off) {     // (i + lde_step*offset) mod n
-    return (i + (size_t)((long long)(int32_t)off * (long long)P.lde_step)) & (P.n - 1);       // n is a power of two
+// position R of the launch -> index i of the evaluation point x_i = h * w^i
+__device__ __forceinline__ size_t ev_point(const EvalParams& P, size_t R) {
+    return (P.bitrev && P.log_n) ? (size_t)(__brevll((unsigned long long)R) >> (64 - P.log_n)) : R;
+}
+// where row (i + lde_step*offset) mod n of a column lives.  In bit-reversed storage consecutive positions differ in
+// the HIGH bits of i, so a wave's 64 rotated rows are again 64 consecutive positions (unless a carry runs that far).
+__device__ __forceinline__ size_t ev_row(const EvalParams& P, size_t i, uint32_t off) {
+    const size_t j = (i + (size_t)((long long)(int32_t)off * (long long)P.lde_step)) & (P.n - 1);       // n is a power of two
+    return (P.bitrev && P.log_n) ? (size_t)(__brevll((unsigned long long)j) >> (64 - P.log_n)) : j;
 }
 __device__ __forceinline__ uint64_t ev_wpow(const EvalParams& P, size_t e) {                // w^e from the two-level table
     uint64_t x = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
@@ -111,8 +119,9 @@ template <int NP, int NQ>
 __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
     using F3 = msstage::Fq3T;
     using F1 = msstage::FpT;
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= P.n) return;
+    const size_t R = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (R >= P.n) return;
+    const size_t i = ev_point(P, R);
     uint64_t rp[NP];
     gl::Fq3 rq[NQ];
     for (uint32_t pc = 0; pc < P.ninstr; pc++) {
@@ -138,8 +147,8 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
         case OP_POW_P: rp[I.dst] = msstage::powu<F1>(rp[I.a], I.b); break;
         case OP_POW_Q: rq[I.dst] = msstage::powu<F3>(rq[I.a], I.b); break;
         case OP_EMBED: rq[I.dst] = {rp[I.a], 0, 0}; break;
-        case OP_STORE_Q: ev_store_q(P, i, I.b, rq[I.a]); break;
-        case OP_STORE_P: ev_store_p(P, i, I.b, rp[I.a]); break;
+        case OP_STORE_Q: ev_store_q(P, R, I.b, rq[I.a]); break;
+        case OP_STORE_P: ev_store_p(P, R, I.b, rp[I.a]); break;
         case OP_XPOW_P: rp[I.dst] = ev_xpow(P, i, I.a, I.b); break;
         default: break;
         }
@@ -151,8 +160,9 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
 template <int NP>
 __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
     using F = msstage::Fp252T;
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= P.n) return;
+    const size_t R = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (R >= P.n) return;
+    const size_t i = ev_point(P, R);
     f252::E rp[NP];
     for (uint32_t pc = 0; pc < P.ninstr; pc++) {
         const Instr I = P.prog[pc];
@@ -166,7 +176,7 @@ __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
         case OP_MUL_PP: rp[I.dst] = f252::mul(rp[I.a], rp[I.b]); break;
         case OP_INV_P: rp[I.dst] = f252::inv(rp[I.a]); break;
         case OP_POW_P: rp[I.dst] = msstage::powu<F>(rp[I.a], I.b); break;
-        case OP_STORE_P: ev252_store(P, i, I.b, rp[I.a]); break;
+        case OP_STORE_P: ev252_store(P, R, I.b, rp[I.a]); break;
         case OP_XPOW_P: rp[I.dst] = ev252_xpow(P, i, I.a, I.b); break;
         default: break;
         }

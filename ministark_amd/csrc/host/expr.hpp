@@ -193,7 +193,7 @@ inline GpuVec<Fp> periodic_lde(Planner& pl, const std::vector<uint64_t>& coeffs,
 template <class Fq>
 inline GpuVec<Fq> eval(const Program& prog, Planner& pl, const std::vector<uint64_t>& challenges, const std::vector<uint64_t>& hints,
                        unsigned lde_step, uint64_t domain_offset, size_t n, const std::vector<const GpuVec<Fp>*>& base_cols,
-                       const std::vector<const GpuVec<Fq3>*>& ext_cols = {}) {
+                       const std::vector<const GpuVec<Fq3>*>& ext_cols = {}, bool bit_reversed = false) {
     if (prog.fq_is_ext != (Fq::words == 3)) throw std::invalid_argument("program was compiled for the other Fq");
     std::vector<uint64_t> consts = prog.consts;
     auto fill = [&](const std::map<uint32_t, uint32_t>& table, const std::vector<uint64_t>& vals) {
@@ -214,9 +214,12 @@ inline GpuVec<Fq> eval(const Program& prog, Planner& pl, const std::vector<uint6
     GpuVec<Fq> out(pl, n);
     unsigned log_n = 0; while (((size_t)1 << log_n) < n) log_n++;
     const uint64_t off = gl::to_mont(domain_offset);
-    check(ms_eval_program(pl.ctx(), (const uint32_t*)prog.instrs.data(), (unsigned)prog.instrs.size(), consts.empty() ? nullptr : consts.data(), (unsigned)consts.size(),
-                          log_n, lde_step, &off, nullptr, bp.empty() ? nullptr : bp.data(), (unsigned)bp.size(), ep.empty() ? nullptr : ep.data(), (unsigned)ep.size(),
-                          pp.empty() ? nullptr : pp.data(), plen.empty() ? nullptr : plen.data(), (unsigned)pp.size(), Fq::id, out.ptr()));
+    // bit_reversed: the columns (their first n entries) and the result are in the committed, bit-reversed layout --
+    // instead of the reference's bit_reverse_ce_trace round trip (src/prover.rs:88-91, 126-129)
+    check(ms_eval_program_ex(pl.ctx(), (const uint32_t*)prog.instrs.data(), (unsigned)prog.instrs.size(), consts.empty() ? nullptr : consts.data(), (unsigned)consts.size(),
+                             log_n, lde_step, &off, nullptr, bp.empty() ? nullptr : bp.data(), (unsigned)bp.size(), ep.empty() ? nullptr : ep.data(), (unsigned)ep.size(),
+                             pp.empty() ? nullptr : pp.data(), plen.empty() ? nullptr : plen.data(), (unsigned)pp.size(), Fq::id, out.ptr(),
+                             bit_reversed ? MS_EVAL_BIT_REVERSED : 0u));
     pl.sync();
     return out;
 }

@@ -1138,7 +1138,16 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
                                const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
                                const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
                                int out_field, void* d_out) {
+    return ms_eval_program_ex(ctx, h_prog, ninstr, h_consts, nconst_words, log_n, lde_step, h_domain_offset, d_x_lde, d_base_cols, nbase,
+                              d_ext_cols, next, d_periodic, periodic_len, nperiodic, out_field, d_out, 0u);
+}
+extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                                  unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                                  const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                                  const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                                  int out_field, void* d_out, unsigned flags) {
     using namespace mseval;
+    if (flags & ~(unsigned)MS_EVAL_BIT_REVERSED) return fail(MS_ERR_INVALID, "ms_eval_program_ex: unknown flags 0x%x", flags);
     if (!ctx || !h_prog || !d_out || (nconst_words && !h_consts)) return fail(MS_ERR_INVALID, "ms_eval_program: null argument");
     if (nbase > (unsigned)MAXCOLS || next > (unsigned)MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d base and %d extension columns", MAXCOLS, MAXCOLS);
     if (nperiodic > 16u) return fail(MS_ERR_UNSUPPORTED, "at most 16 periodic columns");      // the other slots hold hoisted tables
@@ -1342,11 +1351,13 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
             EvalParams Q = E;
             Q.prog = (const Instr*)((char*)ctx->prog_buf + poff); Q.ninstr = pro_n;
             Q.n = period; Q.log_n = split.log_period; Q.xshift = table_log - log_n;      // the first points of the same domain
+        Q.bitrev = 0;
             ProfScope ps(ctx, "eval_prologue", 0.0);
             launch(Q, nullptr);                                   // runs on a few points: not worth a compilation
         }
     }
     E.prog = (const Instr*)ctx->prog_buf; E.ninstr = main_n; E.n = n; E.log_n = log_n; E.xshift = table_log - log_n;
+    E.bitrev = (flags & MS_EVAL_BIT_REVERSED) ? 1 : 0;
     {
         hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(main_prog, main_n) : nullptr;   // small domains: the interpreter is quicker than a compilation
         ProfScope ps(ctx, fn ? (is252 ? "eval_program252_jit" : "eval_program_jit") : (is252 ? "eval_program252" : "eval_program"),

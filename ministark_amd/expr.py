@@ -271,10 +271,12 @@ def periodic_lde(planner, coeffs, interval_size, domain_offset, trace_len, lde_s
     return v
 
 
-def eval(prog, planner, challenges, hints, lde_step, domain_offset, n, base_cols, ext_cols=(), x_lde=None):
+def eval(prog, planner, challenges, hints, lde_step, domain_offset, n, base_cols, ext_cols=(), x_lde=None, bit_reversed=False):
     """`eval_cpu::eval(expr, challenges, hints, lde_step, domain_offset, x_lde, base, ext)`
     (src/eval_cpu.rs:33-42) -> one GpuVec of n elements of Fq.  challenges / hints: numpy u64
-    limbs (Montgomery), one row per element."""
+    limbs (Montgomery), one row per element.  bit_reversed: the columns (their first n entries) and the
+    result are in bit-reversed order -- the committed LDE layout; replaces the reference's
+    bit_reverse_ce_trace round trip (src/prover.rs:88-91, 126-129)."""
     qwords = FIELD_WORDS[prog.out_field]
     is252 = prog.out_field == STARK252_FP
     consts = np.array(prog.consts, dtype=np.uint64)
@@ -295,9 +297,9 @@ def eval(prog, planner, challenges, hints, lde_step, domain_offset, n, base_cols
     ext_arr = (VP * max(1, len(ext_cols)))(*[c.ptr for c in ext_cols])
     per_arr = (VP * max(1, len(per)))(*[p.ptr for p in per])
     per_len = (ctypes.c_uint * max(1, len(per)))(*[len(p) for p in per])
-    L.check(L.ms_eval_program(planner.handle, code.ctypes.data, len(code), consts.ctypes.data if consts.size else None, consts.size,
-                              n.bit_length() - 1, lde_step, off.ctypes.data, x_lde.ptr if x_lde is not None else None,
-                              base_arr, len(base_cols), ext_arr, len(ext_cols), per_arr, per_len, len(per),
-                              prog.out_field, out.ptr))
+    L.check(L.ms_eval_program_ex(planner.handle, code.ctypes.data, len(code), consts.ctypes.data if consts.size else None, consts.size,
+                                 n.bit_length() - 1, lde_step, off.ctypes.data, x_lde.ptr if x_lde is not None else None,
+                                 base_arr, len(base_cols), ext_arr, len(ext_cols), per_arr, per_len, len(per),
+                                 prog.out_field, out.ptr, 1 if bit_reversed else 0))
     planner.sync()
     return out

@@ -163,11 +163,9 @@ def c5():
     lde_t = base_polys.bit_reversed_evaluate(lde_dom)                  # prover.rs:51
     tree_t = MerkleTree.from_matrix(lde_t); tree_t.root()              # prover.rs:52-55
     phase["base trace: interpolate + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
-    nat = lde_t.clone().bit_reverse_rows()                             # prover.rs:88-91 (ce domain = lde domain here)
-    comp_evals = E.eval(prog_c5, pl, ch, ch[:1], blow, 7, n_lde, nat.columns)   # prover.rs:98-107
-    del nat
+    comp_evals = E.eval(prog_c5, pl, ch, ch[:1], blow, 7, n_lde, lde_t.columns, bit_reversed=True)   # prover.rs:88-107, on the committed layout
     phase["constraint evaluation"] = time.perf_counter() - t; t = time.perf_counter()
-    comp_poly = Matrix([comp_evals]).into_polynomials(lde_dom).columns[0]   # prover.rs:111-112
+    comp_poly = Matrix([comp_evals]).bit_reverse_rows().into_polynomials(lde_dom).columns[0]   # prover.rs:111-112
     comp_polys = Matrix.from_chunks(comp_poly, blow)                   # prover.rs:113-121
     comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)               # prover.rs:122
     tree_c = MerkleTree.from_matrix(comp_lde); tree_c.root()           # prover.rs:123-124

@@ -114,6 +114,32 @@ def test_zerofier_tables_and_x_power_lookup(kind):
     assert "eval_prologue" in prof and "eval_program" in prof
 
 
+@pytest.mark.parametrize("kind,log_n", [pytest.param("emu", 10, id="emu"), pytest.param("hip", 12, id="hip", marks=pytest.mark.gpu),
+                                        pytest.param("hip", 16, id="hip-specialised", marks=pytest.mark.gpu)])
+def test_bit_reversed_storage(kind, log_n):
+    # MS_EVAL_BIT_REVERSED: evaluate straight on the committed (bit-reversed) LDE layout, on the first n entries of
+    # longer columns as bit_reverse_ce_trace does (src/prover.rs:185-194); must equal the natural-order evaluation,
+    # bit-reversed.  The natural-order path is checked against the oracle by the other tests.
+    pl = backends.planner(kind)
+    n, N = 1 << log_n, 4 << log_n
+    x = E.X()
+    per = E.Periodic([3, 1, 4, 1, 5, 9, 2, 6], 8)
+    b0, b1, b2 = (lambda o=0, c=c: E.Trace(c, o) for c in range(3))
+    e0, e1 = (lambda o=0, c=c: E.Trace(3 + c, o) for c in range(2))
+    expr = (b0(1) - b0() * b1(-1) + e0(1) * e1() - e0(2) * b2(-2)) * (x - 1) / (x ** (n // 4) - 1) + per * e1(1) + E.Challenge(0) * b1(3) \
+        + x ** 12345 * b2() + E.Hint(0)
+    prog = E.compile_expr(expr, 3, True)
+    base = [cref.random_elements(N, 300 + c) for c in range(3)]
+    ext = [cref.random_elements(3 * N, 350 + c) for c in range(2)]
+    ch = cref.random_elements(3, 390).reshape(-1, 3)
+    full = [GpuVec.from_numpy(pl, c, FP) for c in base], [GpuVec.from_numpy(pl, c, FQ3) for c in ext]
+    got = E.eval(prog, pl, ch, ch, 4, 7, n, full[0], full[1], bit_reversed=True).to_numpy()
+    nat_b = [GpuVec.from_numpy(pl, cref.bit_reverse(c[:n], log_n, 1), FP) for c in base]
+    nat_e = [GpuVec.from_numpy(pl, cref.bit_reverse(c[:3 * n], log_n, 3), FQ3) for c in ext]
+    want = E.eval(prog, pl, ch, ch, 4, 7, n, nat_b, nat_e).to_numpy()
+    assert np.array_equal(got, cref.bit_reverse(want, log_n, 3))
+
+
 def test_many_registers_emu():
     # a wide sum of products keeps many values alive -> larger register files
     terms = [E.Trace(k) * E.Trace(k + 1, 1) for k in range(0, 40, 2)]
