@@ -73,6 +73,13 @@ while time.time() - t0 < budget:
     prog = E.compile_expr(expr, nbase, fq_is_ext)
     out = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
                  [GpuVec.from_numpy(pl, c, FQ3) for c in ext]).to_numpy()
+    if rng.random() < 0.3:                      # the committed-layout mode must give the same values, bit-reversed
+        V3 = 3 if fq_is_ext else 1
+        br = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, cref.bit_reverse(c, log_n, 1), FP) for c in base],
+                    [GpuVec.from_numpy(pl, cref.bit_reverse(c, log_n, 3), FQ3) for c in ext], bit_reversed=True).to_numpy()
+        if not np.array_equal(br, cref.bit_reverse(out, log_n, V3)):
+            print(f"MISMATCH (bit-reversed layout) case {count} (seed {seed}): log_n={log_n} fq_is_ext={fq_is_ext} lde_step={lde_step} offset={offset}")
+            sys.exit(1)
     pts = sorted(set([0, 1, n - 1, n // 2] + [int(x) for x in rng.integers(0, n, size=6)]))
     qc = (lambda r: tuple(GL.from_mont(int(x)) for x in r)) if fq_is_ext else (lambda r: GL.from_mont(int(r[0])))
     cb = [canon(c, 1) for c in base] if log_n <= 13 else None
