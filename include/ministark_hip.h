@@ -212,7 +212,7 @@ int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int out_field, si
  *                        state = init;  for i in 0..n:  out[i] = state;  state = a[i]*state + b[i]
  *                    (inclusive != 0: out[i] = the state AFTER row i).  d_a NULL = all ones (running sum),
  *                    d_b NULL = all zeros (running product); masked rows are a = 1, b = 0.  a, b, init, out
- *                    are elements of `field` (Goldilocks Fp or Fq3); out may alias a or b.  Any n >= 0.
+ *                    are elements of `field` (any of the three); out may alias a or b.  Any n >= 0.
  * ms_gather_rows     out[p][c] = cols[c][positions[p]], row-major: Matrix::get_row over the query
  *                    positions (src/trace.rs:139-152, src/matrix.rs get_row)
  * ms_gather_digests  out[k] = digests[indices[k]] (32-byte records): the leaves / sibling leaves / nodes

@@ -1408,9 +1408,9 @@ static void scan_launch(ms_ctx* ctx, const msscan::ScanParams& P) {
 extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a, const void* d_b, const void* h_init, int inclusive, void* d_out) {
     if (!ctx || !d_out || !h_init) return fail(MS_ERR_INVALID, "ms_scan_affine: null argument");
     if (!d_a && !d_b) return fail(MS_ERR_INVALID, "ms_scan_affine: neither multipliers nor addends given");
-    if (field != MS_GOLDILOCKS_FP && field != MS_GOLDILOCKS_FQ3) return fail(MS_ERR_UNSUPPORTED, "ms_scan_affine: Goldilocks Fp / Fq3 only");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
     if (n == 0) return MS_OK;
-    const unsigned V = field == MS_GOLDILOCKS_FQ3 ? 3 : 1;
     if ((n + msscan::TILE - 1) / msscan::TILE > 0xFFFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "column too long");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
@@ -1422,9 +1422,11 @@ extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a,
     void* tmp = nullptr;
     MSCHK(pool_alloc(ctx, (size_t)P.nblocks * 3 * V * 8, &tmp));
     P.agg = (uint64_t*)tmp; P.block_state = (uint64_t*)tmp + (size_t)P.nblocks * 2 * V;
-    using msstage::FpT; using msstage::Fq3T;
+    using msstage::FpT; using msstage::Fq3T; using msstage::Fp252T;
     if (V == 1) {
         if (d_a && d_b) scan_launch<FpT, true, true>(ctx, P); else if (d_a) scan_launch<FpT, true, false>(ctx, P); else scan_launch<FpT, false, true>(ctx, P);
+    } else if (V == 4) {
+        if (d_a && d_b) scan_launch<Fp252T, true, true>(ctx, P); else if (d_a) scan_launch<Fp252T, true, false>(ctx, P); else scan_launch<Fp252T, false, true>(ctx, P);
     } else {
         if (d_a && d_b) scan_launch<Fq3T, true, true>(ctx, P); else if (d_a) scan_launch<Fq3T, true, false>(ctx, P); else scan_launch<Fq3T, false, true>(ctx, P);
     }

@@ -31,7 +31,7 @@ struct ScanParams {
     uint64_t* out;
     uint64_t* agg;           // [nblocks][2] elements: aggregate map of every block
     uint64_t* block_state;   // [nblocks] elements: state at the start of every block
-    uint64_t init[3];
+    uint64_t init[4];
     size_t n;
     unsigned nblocks;
     int inclusive;
@@ -42,6 +42,7 @@ template <class F> struct Map { typename F::T a, b; };
 template <class F> __device__ __forceinline__ typename F::T f_zero();
 template <> __device__ __forceinline__ uint64_t f_zero<msstage::FpT>() { return 0; }
 template <> __device__ __forceinline__ gl::Fq3 f_zero<msstage::Fq3T>() { return {0, 0, 0}; }
+template <> __device__ __forceinline__ f252::E f_zero<msstage::Fp252T>() { return f252::zero(); }
 
 // `l` first, then `r`:  x -> r.a*(l.a*x + l.b) + r.b
 template <class F, bool HAS_A, bool HAS_B>

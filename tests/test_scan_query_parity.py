@@ -80,7 +80,7 @@ def test_scan_rejects_bad_arguments_emu():
     v = GpuVec(pl, 8, FP)
     init = np.zeros(1, dtype=np.uint64)
     assert L.ms_scan_affine(pl.handle, FP, 8, None, None, init.ctypes.data, 0, v.ptr) == -1
-    assert L.ms_scan_affine(pl.handle, 2, 8, v.ptr, None, init.ctypes.data, 0, v.ptr) == -2      # Fp252 not supported
+    assert L.ms_scan_affine(pl.handle, 7, 8, v.ptr, None, init.ctypes.data, 0, v.ptr) == -1      # unknown field
     assert L.ms_scan_affine(pl.handle, FP, 0, v.ptr, None, init.ctypes.data, 0, v.ptr) == 0
 
 
@@ -152,3 +152,22 @@ def test_queries_rows_and_openings(kind):               # src/trace.rs:113-157
     assert not omerkle.verify(nb[1], bad, positions)
     with pytest.raises(IndexError):
         tb.prove([1 << 10])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_running_evaluation_252(kind):
+    from oracle.pyref.fields import F252
+    from ministark_amd import STARK252_FP, f252_to_mont_limbs, f252_from_mont_limbs
+    pl = backends.planner(kind)
+    n = 4500
+    rng = np.random.default_rng(8)
+    draw = lambda: [int.from_bytes(rng.bytes(32), "little") % F252.p for _ in range(n)]
+    a, b, init = draw(), draw(), int.from_bytes(rng.bytes(32), "little") % F252.p
+    for i in range(0, n, 5):
+        a[i], b[i] = 1, 0
+    dev = lambda v: GpuVec.from_numpy(pl, np.concatenate([f252_to_mont_limbs(x) for x in v]), STARK252_FP)
+    got = scan_affine(dev(a), dev(b), f252_to_mont_limbs(init)).to_numpy().reshape(n, 4)
+    state = init
+    for i in range(n):
+        assert f252_from_mont_limbs(got[i]) == state, f"row {i}"
+        state = (a[i] * state + b[i]) % F252.p
