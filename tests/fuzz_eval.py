@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random constraint expressions through compile_expr -> ms_eval_program (table hoisting, x^e lookups,
 interpreter on small domains, hiprtc-specialised kernels on 2^16 points) against the oracle's direct
-evaluation at sampled points:   python scripts/fuzz_eval.py [seconds] [seed]"""
+evaluation at sampled points:   python tests/fuzz_eval.py [seconds] [seed]"""
 import os
 import sys
 import time

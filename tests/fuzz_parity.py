@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential run of the library against the C oracle (oracle/c) on the GPU:
-    python scripts/fuzz_parity.py [seconds] [seed]
+    python tests/fuzz_parity.py [seconds] [seed]
 Random sizes (2^0 .. 2^18), fields, directions, coset offsets, blow-ups, folding factors, shifts and column
 counts; values are a mix of uniform elements and edge values (0, 1, p-1, 2^32-1, 2^32, p-2^32 ...).
 Complements tests/ (fixed shapes): any mismatch prints the failing case and exits non-zero."""
