@@ -334,7 +334,8 @@ def test_evaluate_short_columns_hip(log_n, log_b):
 @pytest.mark.parametrize("kind", [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)])
 def test_composition_poly_chunks(kind):                 # src/prover.rs:113-121
     pl = backends.planner(kind)
-    for field, V in ((GOLDILOCKS_FP, 1), (GOLDILOCKS_FQ3, 3)):
+    from ministark_amd import STARK252_FP
+    for field, V in ((GOLDILOCKS_FP, 1), (GOLDILOCKS_FQ3, 3), (STARK252_FP, 4)):
         n, k = 1 << 12, 4
         poly = _rand(n * V, 5)
         cols = Matrix.from_chunks(GpuVec.from_numpy(pl, poly, field), k).to_numpy()
