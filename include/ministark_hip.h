@@ -234,8 +234,9 @@ int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor,
 
 /* ---- DEEP composition (host-side and sequential in the reference):
  * DeepPolyComposer::get_ood_evals / into_deep_poly (src/composer.rs:43-188).  `point_field` is Fq
- * (MS_GOLDILOCKS_FQ3, or MS_GOLDILOCKS_FP for Fq = Fp AIRs); every host array of points / alphas / values
- * holds elements of point_field (3 or 1 Montgomery words each), packed.
+ * (MS_GOLDILOCKS_FQ3, or MS_GOLDILOCKS_FP / MS_STARK252_FP for Fq = Fp AIRs; with the 252-bit field all
+ * polynomials are passed as base columns and h_offset defaults to its generator 3); every host array of
+ * points / alphas / values holds elements of point_field (3, 1 or 4 Montgomery words each), packed.
  * ms_horner_eval   out[q] = P_{qcol[q]}(qpoint[q]) for coefficient-form columns of `coeff_field`
  *                  (horner_evaluate, src/utils.rs:124-133).  Blocks; results on the host.
  * ms_deep_compose  coefficients (2^log_n elements of point_field, d_out) of

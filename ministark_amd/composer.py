@@ -5,17 +5,18 @@ import ctypes
 
 import numpy as np
 
-from .api import FIELD_WORDS, GOLDILOCKS_FP, GOLDILOCKS_FQ3, GL_P, GpuVec, Radix2EvaluationDomain, gl_from_mont, gl_to_mont
+from .api import (FIELD_WORDS, GOLDILOCKS_FP, GOLDILOCKS_FQ3, STARK252_FP, GL_P, F252_P, GpuVec, Radix2EvaluationDomain, gl_from_mont, gl_to_mont,
+                  f252_from_mont_limbs, f252_to_mont_limbs)
 
 
-def _q_mul_base(q, s):      # Fq element (canonical tuple or int) times canonical Fp scalar
-    return tuple((c * s) % GL_P for c in q) if isinstance(q, tuple) else (q * s) % GL_P
+def _q_mul_base(q, s, p=GL_P):      # Fq element (canonical tuple or int) times canonical Fp scalar
+    return tuple((c * s) % p for c in q) if isinstance(q, tuple) else (q * s) % p
 
 
-def _q_pow(q, e):
+def _q_pow(q, e, p=GL_P):
     """Fq3 = Fp[x]/(x^3 - 2) power on canonical tuples (host bookkeeping of points only)."""
     if not isinstance(q, tuple):
-        return pow(q, e, GL_P)
+        return pow(q, e, p)
 
     def mul(a, b):
         a0, a1, a2 = a
@@ -30,11 +31,15 @@ def _q_pow(q, e):
     return r
 
 
-def _words(q):
+def _words(q, field=GOLDILOCKS_FP):
+    if field == STARK252_FP:
+        return [int(w) for w in f252_to_mont_limbs(q % F252_P)]
     return [gl_to_mont(c) for c in q] if isinstance(q, tuple) else [gl_to_mont(q)]
 
 
 def _from_words(w):
+    if len(w) == 4:
+        return f252_from_mont_limbs(w)
     return tuple(gl_from_mont(int(x)) for x in w) if len(w) == 3 else gl_from_mont(int(w[0]))
 
 
@@ -44,7 +49,8 @@ class DeepCompositionCoeffs:                      # src/composer.rs:191-198
 
 
 class DeepPolyComposer:
-    """z and all coefficients are canonical Fq values: 3-tuples (Fq3) or ints (Fq = Fp AIRs).
+    """z and all coefficients are canonical Fq values: 3-tuples (Fq3) or ints (Fq = Fp AIRs, over Goldilocks
+    or -- when the polynomial matrices are over it -- the 252-bit field).
     trace_arguments: the AIR's list of (column, offset) pairs (air.trace_arguments())."""
 
     def __init__(self, trace_arguments, trace_len, z, base_trace_polys, extension_trace_polys, composition_trace_polys):
@@ -55,8 +61,10 @@ class DeepPolyComposer:
         self.comp = composition_trace_polys
         self.n = trace_len
         self.planner = base_trace_polys.planner
-        self.fq = GOLDILOCKS_FQ3 if isinstance(z, tuple) else GOLDILOCKS_FP
-        d = Radix2EvaluationDomain(trace_len)
+        self.base_field = base_trace_polys.field
+        self.p = F252_P if self.base_field == STARK252_FP else GL_P
+        self.fq = GOLDILOCKS_FQ3 if isinstance(z, tuple) else self.base_field
+        d = Radix2EvaluationDomain(trace_len, 1, self.base_field)
         self.g, self.g_inv = d.group_gen, d.group_gen_inv
         self.nbase = base_trace_polys.num_cols()
         self.next = extension_trace_polys.num_cols() if extension_trace_polys is not None else 0
@@ -64,7 +72,7 @@ class DeepPolyComposer:
 
     def _point(self, offset):
         gen = self.g if offset >= 0 else self.g_inv
-        return _q_mul_base(self.z, pow(gen, abs(offset), GL_P))
+        return _q_mul_base(self.z, pow(gen, abs(offset), self.p), self.p)
 
     def _horner(self, matrix, field, queries):
         """queries: list of (column, point) -> list of Fq values."""
@@ -75,7 +83,7 @@ class DeepPolyComposer:
         pl, L = self.planner, self.planner.lib
         pw = FIELD_WORDS[self.fq]
         qcol = (ctypes.c_uint * len(queries))(*[c for c, _ in queries])
-        pts = np.array([w for _, p in queries for w in _words(p)], dtype=np.uint64)
+        pts = np.array([w for _, p in queries for w in _words(p, self.fq)], dtype=np.uint64)
         out = np.zeros(len(queries) * pw, dtype=np.uint64)
         arr = (ctypes.c_void_p * matrix.num_cols())(*[c.ptr for c in matrix.columns])
         L.check(L.ms_horner_eval(pl.handle, field, self.fq, matrix.num_rows(), arr, matrix.num_cols(), qcol, pts.ctypes.data,
@@ -85,9 +93,9 @@ class DeepPolyComposer:
     def get_ood_evals(self):                      # src/composer.rs:43-86
         base_q = [(c, self._point(o)) for c, o in self.args if c < self.nbase]
         ext_q = [(c - self.nbase, self._point(o)) for c, o in self.args if c >= self.nbase]
-        bv, ev = iter(self._horner(self.base, GOLDILOCKS_FP, base_q)), iter(self._horner(self.ext, self.fq, ext_q) if ext_q else [])
+        bv, ev = iter(self._horner(self.base, self.base_field, base_q)), iter(self._horner(self.ext, self.fq, ext_q) if ext_q else [])
         execution = [next(bv) if c < self.nbase else next(ev) for c, _ in self.args]
-        z_n = _q_pow(self.z, self.comp.num_cols())
+        z_n = _q_pow(self.z, self.comp.num_cols(), self.p)
         composition = self._horner(self.comp, self.fq, [(c, z_n) for c in range(self.comp.num_cols())])
         self._ood = (execution, composition)
         return execution, composition
@@ -105,20 +113,20 @@ class DeepPolyComposer:
                 pindex[p] = len(points)
                 points.append(p)
             return pindex[p]
-        z_n = _q_pow(self.z, self.comp.num_cols())
+        z_n = _q_pow(self.z, self.comp.num_cols(), self.p)
         ext_cols = (list(self.ext.columns) if self.ext is not None else []) + list(self.comp.columns)
         tcol, tpoint, talpha, tood = [], [], [], []
         for c in range(self.comp.num_cols()):
             tcol.append(self.nbase + self.next + c); tpoint.append(pid(z_n)); talpha.append(coeffs.composition_trace[c]); tood.append(composition[c])
         for (c, o), alpha, val in zip(self.args, coeffs.execution_trace, execution):
             tcol.append(c); tpoint.append(pid(self._point(o))); talpha.append(alpha); tood.append(val)
-        if self.fq == GOLDILOCKS_FP:
+        if self.fq != GOLDILOCKS_FQ3:
             base_cols, ext_list = list(self.base.columns) + ext_cols, []      # Fq = Fp: everything is a base column
         else:
             base_cols, ext_list = list(self.base.columns), ext_cols
         VP = ctypes.c_void_p
         out = GpuVec(pl, self.n, self.fq)
-        flat = lambda qs: np.array([w for q in qs for w in _words(q)], dtype=np.uint64)
+        flat = lambda qs: np.array([w for q in qs for w in _words(q, self.fq)], dtype=np.uint64)
         pts, al, od = flat(points), flat(talpha), flat(tood)
         da, db = flat([coeffs.degree[0]]), flat([coeffs.degree[1]])
         L.check(L.ms_deep_compose(pl.handle, self.fq, self.n.bit_length() - 1, None,

@@ -170,3 +170,92 @@ __global__ void __launch_bounds__(NT) deep_degree_adjust(uint64_t* dst, const ui
 }
 
 }  // namespace msdeep
+
+// ---- the same three kernels for the 252-bit field (Fq = Fp = Fp252: one word size, no extension) ----------
+namespace msdeep252 {
+
+static constexpr int NT = 256;
+using E = f252::E;
+__device__ __forceinline__ E ld(const uint64_t* p, size_t i) { return {{p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]}}; }
+__device__ __forceinline__ void st(uint64_t* p, size_t i, const E& x) { p[4 * i] = x.l[0]; p[4 * i + 1] = x.l[1]; p[4 * i + 2] = x.l[2]; p[4 * i + 3] = x.l[3]; }
+
+struct HornerParams {
+    const uint64_t* cols[msdeep::MAXCOLS];
+    const uint32_t* qcol;
+    const uint64_t* qpoint;    // 4 words per query
+    uint64_t* partial;         // [nq][nblocks][4]
+    size_t n;
+    unsigned nblocks;
+};
+__global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
+    __shared__ uint64_t sh[NT * 4];
+    const unsigned q = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const uint64_t* col = P.cols[P.qcol[q]];
+    E xp[9];
+    xp[0] = ld(P.qpoint, q);
+    for (int l = 1; l <= 8; l++) xp[l] = f252::mul(xp[l - 1], xp[l - 1]);
+    const size_t start = (size_t)b * 4096 + t;
+    E acc = f252::zero();
+    for (int k = 15; k >= 0; k--) {
+        const size_t i = start + (size_t)k * NT;
+        acc = f252::mul(acc, xp[8]);
+        if (i < P.n) acc = f252::add(acc, ld(col, i));
+    }
+    for (unsigned l = 0; l < 8; l++) {
+        st(sh, t, acc);
+        __syncthreads();
+        const unsigned step = 1u << l;
+        if ((t & (2 * step - 1)) == 0) acc = f252::add(acc, f252::mul(ld(sh, t + step), xp[l]));
+        __syncthreads();
+    }
+    if (t == 0) st(P.partial, (size_t)q * P.nblocks + b, acc);
+}
+
+struct Term { uint32_t col, point; uint64_t alpha[4]; uint64_t ood[4]; };
+struct DeepParams {
+    const uint64_t* cols[msdeep::MAXCOLS];   // coset evaluations, natural order
+    const Term* terms;
+    const uint64_t* tw_lo;                   // w_n^i tables of the forward 252 plan
+    const uint64_t* tw_hi;
+    uint64_t points[msdeep::MAXPOINTS][4];
+    uint64_t h[4];                           // coset offset
+    uint64_t* out;
+    size_t n;
+    unsigned nterms, npoints, lo_bits;
+};
+__global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= P.n) return;
+    E x = ld(P.tw_lo, i & ((1u << P.lo_bits) - 1));
+    if (i >> P.lo_bits) x = f252::mul(x, ld(P.tw_hi, i >> P.lo_bits));
+    x = f252::mul(x, E{{P.h[0], P.h[1], P.h[2], P.h[3]}});
+    // 1 / (x - z_k) for every point with one inversion
+    E d[msdeep::MAXPOINTS], pre[msdeep::MAXPOINTS];
+    E run = f252::one();
+    for (unsigned k = 0; k < P.npoints; k++) {
+        d[k] = f252::sub(x, E{{P.points[k][0], P.points[k][1], P.points[k][2], P.points[k][3]}});
+        pre[k] = run;
+        run = f252::mul(run, d[k]);
+    }
+    E inv = f252::inv(run);
+    for (int k = (int)P.npoints - 1; k >= 0; k--) {
+        const E dk = d[k];
+        d[k] = f252::mul(inv, pre[k]);
+        inv = f252::mul(inv, dk);
+    }
+    E acc = f252::zero();
+    for (unsigned t = 0; t < P.nterms; t++) {
+        const Term T = P.terms[t];
+        E v = f252::sub(ld(P.cols[T.col], i), E{{T.ood[0], T.ood[1], T.ood[2], T.ood[3]}});
+        acc = f252::add(acc, f252::mul(f252::mul(v, d[T.point]), E{{T.alpha[0], T.alpha[1], T.alpha[2], T.alpha[3]}}));
+    }
+    st(P.out, i, acc);
+}
+__global__ void __launch_bounds__(NT) deep_degree_adjust(uint64_t* dst, const uint64_t* src, size_t n, E alpha, E beta) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const E c = ld(src, i), prev = i ? ld(src, i - 1) : f252::zero();
+    st(dst, i, f252::add(f252::mul(c, alpha), f252::mul(prev, beta)));
+}
+
+}  // namespace msdeep252

@@ -79,3 +79,41 @@ def test_horner_large_hip():
     d = Radix2EvaluationDomain(n)
     assert ex[0] == pydeep.horner_evaluate(canon, z)
     assert ex[1] == pydeep.horner_evaluate(canon, pydeep.point_for(z, d.group_gen, d.group_gen_inv, 1))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_deep_252(kind):
+    # DeepPolyComposer over the 252-bit field (Fq = Fp): out-of-domain values against Python Horner, and the DEEP
+    # polynomial against its definition  Q(X) = (a + b X) * sum_t alpha_t (P_t(X) - P_t(z_t)) / (X - z_t)  at random points
+    from oracle.pyref.fields import F252
+    from ministark_amd import STARK252_FP, f252_to_mont_limbs, f252_from_mont_limbs
+    pl = backends.planner(kind)
+    p = F252.p
+    rng = np.random.default_rng(17)
+    log_n = 7 if kind == "emu" else 12
+    n = 1 << log_n
+    rnd = lambda: int.from_bytes(rng.bytes(32), "little") % p
+    nbase, ncomp = 3, 2
+    polys = [[rnd() for _ in range(n)] for _ in range(nbase + ncomp)]
+    mat = lambda cols: Matrix.from_numpy(pl, [np.concatenate([f252_to_mont_limbs(v) for v in c]) for c in cols], STARK252_FP)
+    args = [(0, 0), (0, 1), (1, 0), (2, 1), (2, -1)]
+    z = rnd()
+    composer = DeepPolyComposer(args, n, z, mat(polys[:nbase]), None, mat(polys[nbase:]))
+    got_exec, got_comp = composer.get_ood_evals()
+    horner = lambda c, x: __import__("functools").reduce(lambda acc, v: (acc * x + v) % p, reversed(c), 0)
+    g = F252.root_of_unity(n)
+    point = lambda off: z * pow(g, off % n, p) % p
+    z_n = pow(z, ncomp, p)
+    assert got_exec == [horner(polys[c], point(o)) for c, o in args]
+    assert got_comp == [horner(polys[nbase + c], z_n) for c in range(ncomp)]
+    ea, ca, degree = [rnd() for _ in args], [rnd() for _ in range(ncomp)], (rnd(), rnd())
+    q = composer.into_deep_poly(DeepCompositionCoeffs(ea, ca, degree)).to_numpy().reshape(n, 4)
+    qc = [f252_from_mont_limbs(r) for r in q]
+    terms = [(polys[nbase + c], z_n, ca[c]) for c in range(ncomp)] + [(polys[c], point(o), a) for (c, o), a in zip(args, ea)]
+    for _ in range(3):
+        r = rnd()
+        want = sum(a * (horner(c, r) - horner(c, zt)) * pow(r - zt, -1, p) for c, zt, a in terms) % p
+        want = want * (degree[0] + degree[1] * r) % p
+        assert horner(qc, r) == want
+    # degree bound: deg Q <= n - 2 before the adjustment, so the adjusted polynomial has n coefficients and no more
+    assert len(qc) == n
