@@ -25,8 +25,12 @@ def rand(n_words):
 
 
 def timed(fn, reps=3):
-    fn()
-    pl.sync()
+    t_settle = time.perf_counter()                 # plans, specialised kernels, pool and clocks settle before timing
+    while True:
+        fn()
+        pl.sync()
+        if time.perf_counter() - t_settle > 0.4:
+            break
     pl.profile(True)
     t0 = time.perf_counter()
     for _ in range(reps):
