@@ -141,6 +141,23 @@ def main():
                      "algorithmic_bytes_per_transform": alg_bytes_col,
                      "us_per_transform_events": round(us_per_transform, 2), "kernels": kernels},
     }
+    if world == 1:
+        # for information: the other transforms of configs[1] on the same columns (wall time per transform, 5 steps each)
+        from ministark_amd import GpuIfft
+        variants = {}
+        for name, plan in (("forward_subgroup", GpuFft(Radix2EvaluationDomain(n), GOLDILOCKS_FP, pl)),
+                           ("inverse_coset", GpuIfft(dom, GOLDILOCKS_FP, pl)),
+                           ("inverse_subgroup", GpuIfft(Radix2EvaluationDomain(n), GOLDILOCKS_FP, pl))):
+            for _ in range(2):
+                plan.enqueue(cols)
+            pl.sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                plan.enqueue(cols)
+            pl.sync()
+            variants[name + "_us_per_transform"] = round((time.perf_counter() - t1) / 5 / args.cols * 1e6, 2)
+            plan.close()
+        out["variants"] = variants
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
         from oracle import cref
         x = host_cols[0].copy()
