@@ -195,3 +195,80 @@ def c5():
 wall, k = timed(c5, reps=2)
 emit("C5-shaped single-GPU pipeline: 2^22 rows x 8 cols, blow-up 4, FRI fold 8, 32 queries, 8 grinding bits (fixed challenges instead of the channel)", wall, k,
      phases_ms={kk: round(v * 1e3, 2) for kk, v in phase.items()})
+
+# ---- C1-shaped pipeline at scale: examples/brainfuck's column mix (17 base Fp + 9 extension Fq3 columns, blow-up 16,
+# FRI folding 16, examples/brainfuck/main.rs:92-105) on 2^16 rows (LDE 2^20), every data-parallel phase on the device;
+# the extension columns are built on the device as running products of challenge-weighted base columns
+# (examples/brainfuck/trace.rs:131-145).  Bit-exactness of this chain is asserted in tests/test_pipeline_parity.py.
+from ministark_amd import running_product   # noqa: E402
+from ministark_amd import stages as S       # noqa: E402
+
+del trace
+log_r, blow1, fold1 = 16, 16, 16
+n_r, n_l = 1 << log_r, (1 << log_r) * 16
+base1 = Matrix.from_numpy(pl, [rand(n_r) for _ in range(17)], FP)
+x1 = E.X()
+b1 = lambda c, o=0: E.Trace(c, o)
+e1 = lambda c, o=0: E.Trace(17 + c, o)
+expr1 = None
+for kk in range(9):
+    t1 = (e1(kk, 1) - e1(kk) * (E.Challenge(kk % 4) - b1(kk) * E.Challenge((kk + 1) % 4) - b1(kk + 8, 1))) * (x1 - 1) / (x1 ** n_r - 1)
+    expr1 = t1 if expr1 is None else expr1 + t1 * E.Challenge(kk % 4)
+prog1 = E.compile_expr(expr1, 17, True)
+ch1 = rand(12).reshape(-1, 3)
+args1 = [(c, o) for c in range(26) for o in (0, 1)]
+q3 = lambda: tuple(int(v) for v in rand(3))
+coeffs1 = DeepCompositionCoeffs([q3() for _ in args1], [q3() for _ in range(blow1)], (q3(), q3()))
+pos1 = [int(p) for p in rng.integers(0, n_l, size=32)]
+one3 = np.array([0xFFFFFFFF, 0, 0], dtype=np.uint64)          # 1 in Montgomery form
+phase1 = {}
+
+
+def c1():
+    t = time.perf_counter()
+    td, ld = Radix2EvaluationDomain(n_r), Radix2EvaluationDomain(n_l, 7)
+    base_polys = base1.interpolate(td)
+    base_lde = base_polys.bit_reversed_evaluate(ld)
+    base_tree = MerkleTree.from_matrix(base_lde); base_tree.root()
+    phase1["base trace: interpolate + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
+    ext_cols = []                                                       # trace.rs:131-145: p[i+1] = p[i] * (alpha - a*col_k[i] - b*col_(k+8)[i])
+    for kk in range(9):
+        f = GpuVec(pl, n_r, FQ3)
+        S.ConvertIntoStage(pl, n_r, FQ3, FP).encode(f, base1.columns[kk])
+        S.MulAssignConstStage(pl, n_r, FQ3, FQ3).encode(f, ch1[(kk + 1) % 4])
+        g = GpuVec(pl, n_r, FQ3)
+        S.ConvertIntoStage(pl, n_r, FQ3, FP).encode(g, base1.columns[kk + 8])
+        S.AddAssignStage(pl, n_r, FQ3, FQ3).encode(f, g)
+        S.NegInPlaceStage(pl, n_r, FQ3).encode(f)
+        S.AddAssignConstStage(pl, n_r, FQ3, FQ3).encode(f, ch1[kk % 4])
+        ext_cols.append(running_product(f, one3))
+    ext_polys = Matrix(ext_cols).interpolate(td)
+    ext_lde = ext_polys.bit_reversed_evaluate(ld)
+    ext_tree = MerkleTree.from_matrix(ext_lde); ext_tree.root()
+    phase1["extension trace: build (stages + scans) + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
+    comp_evals = E.eval(prog1, pl, ch1, ch1[:1], blow1, 7, n_l, base_lde.columns, ext_lde.columns, bit_reversed=True)
+    phase1["constraint evaluation"] = time.perf_counter() - t; t = time.perf_counter()
+    comp_poly = Matrix([comp_evals]).bit_reverse_rows().into_polynomials(ld).columns[0]
+    comp_polys = Matrix.from_chunks(comp_poly, blow1)
+    comp_lde = comp_polys.bit_reversed_evaluate(ld)
+    comp_tree = MerkleTree.from_matrix(comp_lde); comp_tree.root()
+    phase1["composition trace: iNTT + split + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
+    composer = DeepPolyComposer(args1, n_r, q3(), base_polys, ext_polys, comp_polys)
+    composer.get_ood_evals()
+    layer = Matrix([composer.into_deep_poly(coeffs1)]).into_bit_reversed_evaluations(ld).columns[0]
+    phase1["DEEP: OOD evaluations + composition + LDE"] = time.perf_counter() - t; t = time.perf_counter()
+    size, last_root = n_l, None
+    while size > 64:
+        last_root = MerkleTree.from_fri_layer(layer, fold1).root()
+        layer = apply_drp(layer, rand(3), fold1, 1)
+        size //= fold1
+    pl.sync()
+    phase1["FRI layers (commit + fold)"] = time.perf_counter() - t; t = time.perf_counter()
+    grind_proof_of_work(pl, last_root, 8)
+    Queries(base_lde, ext_lde, comp_lde, base_tree, ext_tree, comp_tree, pos1)
+    phase1["proof of work + queries"] = time.perf_counter() - t
+
+
+wall, k = timed(c1, reps=2)
+emit("C1-shaped pipeline at scale: 2^16 rows, 17 Fp + 9 Fq3 columns (extension columns built on the device), blow-up 16, FRI fold 16, 32 queries", wall, k,
+     phases_ms={kk: round(v * 1e3, 2) for kk, v in phase1.items()})
