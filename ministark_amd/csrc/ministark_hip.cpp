@@ -1395,15 +1395,20 @@ extern "C" int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int ou
 // ---------------------------------------------------------------------------------------
 // running products / evaluations, query gathers
 // ---------------------------------------------------------------------------------------
-template <class F, bool HAS_A, bool HAS_B>
-static void scan_launch(ms_ctx* ctx, const msscan::ScanParams& P) {
+template <class F, bool HAS_A, bool HAS_B, int PER>
+static void scan_launch_per(ms_ctx* ctx, const msscan::ScanParams& P) {
     using namespace msscan;
     { ProfScope ps(ctx, "scan_reduce", 8.0 * P.n * F::V * ((HAS_A ? 1 : 0) + (HAS_B ? 1 : 0)));
-      hipLaunchKernelGGL((scan_reduce<F, HAS_A, HAS_B>), dim3(P.nblocks), dim3(NT), 0, ctx->stream, P); }
+      hipLaunchKernelGGL((scan_reduce<F, HAS_A, HAS_B, PER>), dim3(P.nblocks), dim3(NT), 0, ctx->stream, P); }
     { ProfScope ps(ctx, "scan_blocks", 0.0);
       hipLaunchKernelGGL((scan_blocks<F, HAS_A, HAS_B>), dim3(1), dim3(NT), 0, ctx->stream, P); }
     { ProfScope ps(ctx, "scan_apply", 8.0 * P.n * F::V * (1 + (HAS_A ? 1 : 0) + (HAS_B ? 1 : 0)));
-      hipLaunchKernelGGL((scan_apply<F, HAS_A, HAS_B>), dim3(P.nblocks), dim3(NT), 0, ctx->stream, P); }
+      hipLaunchKernelGGL((scan_apply<F, HAS_A, HAS_B, PER>), dim3(P.nblocks), dim3(NT), 0, ctx->stream, P); }
+}
+static unsigned scan_rows_per_lane(size_t n) { return n < ((size_t)1 << 20) ? 4 : 16; }
+template <class F, bool HAS_A, bool HAS_B>
+static void scan_launch(ms_ctx* ctx, const msscan::ScanParams& P) {
+    if (scan_rows_per_lane(P.n) == 4) scan_launch_per<F, HAS_A, HAS_B, 4>(ctx, P); else scan_launch_per<F, HAS_A, HAS_B, 16>(ctx, P);
 }
 extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a, const void* d_b, const void* h_init, int inclusive, void* d_out) {
     if (!ctx || !d_out || !h_init) return fail(MS_ERR_INVALID, "ms_scan_affine: null argument");
@@ -1411,14 +1416,15 @@ extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a,
     unsigned V = 0;
     MSCHK(field_words(field, &V));
     if (n == 0) return MS_OK;
-    if ((n + msscan::TILE - 1) / msscan::TILE > 0xFFFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "column too long");
+    const size_t tile = (size_t)msscan::NT * scan_rows_per_lane(n);
+    if ((n + tile - 1) / tile > 0xFFFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "column too long");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     msscan::ScanParams P;
     memset(&P, 0, sizeof P);
     P.a = (const uint64_t*)d_a; P.b = (const uint64_t*)d_b; P.out = (uint64_t*)d_out;
     memcpy(P.init, h_init, V * 8);
-    P.n = n; P.nblocks = (unsigned)((n + msscan::TILE - 1) / msscan::TILE); P.inclusive = inclusive != 0;
+    P.n = n; P.nblocks = (unsigned)((n + tile - 1) / tile); P.inclusive = inclusive != 0;
     void* tmp = nullptr;
     MSCHK(pool_alloc(ctx, (size_t)P.nblocks * 3 * V * 8, &tmp));
     P.agg = (uint64_t*)tmp; P.block_state = (uint64_t*)tmp + (size_t)P.nblocks * 2 * V;

@@ -7,7 +7,7 @@
 // (src/trace.rs:115-157, src/merkle.rs:149-206).
 //
 // scan: the maps x -> a*x + b compose associatively, so the column is scanned in three launches:
-//   scan_reduce  one workgroup per 4096 rows: each lane composes its 16 consecutive maps, the
+//   scan_reduce  one workgroup per 4096 (or 1024) rows: each lane composes its 16 (4) consecutive maps, the
 //                workgroup composes the 256 lane maps in order -> one aggregate map per block
 //   scan_blocks  one workgroup walks the block aggregates -> the state at the start of every block
 //   scan_apply   per block: lane maps again, an in-order prefix over the 256 lanes gives every
@@ -22,8 +22,8 @@
 namespace msscan {
 
 static constexpr int NT = 256;
-static constexpr int PER = 16;
-static constexpr int TILE = NT * PER;
+// rows per lane: 16 for long columns, 4 below 2^20 rows (four times the workgroups, a quarter of the serial chain per
+// lane: a 2^16-row column is latency-bound, not throughput-bound)
 
 struct ScanParams {
     const uint64_t* a;       // multipliers (nullptr: all one)
@@ -89,10 +89,10 @@ __device__ __forceinline__ Map<F> wg_scan(Map<F> m, Map<F>* sh, Map<F>* excl) {
     return m;
 }
 
-template <class F, bool HAS_A, bool HAS_B>
+template <class F, bool HAS_A, bool HAS_B, int PER>
 __global__ void __launch_bounds__(NT) scan_reduce(ScanParams P) {
     __shared__ Map<F> sh[NT];
-    const size_t i0 = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * PER;
+    const size_t i0 = (size_t)blockIdx.x * (NT * PER) + (size_t)threadIdx.x * PER;
     Map<F> m = load_map<F, HAS_A, HAS_B>(P, i0);
     for (int j = 1; j < PER; j++) m = compose<F, HAS_A, HAS_B>(m, load_map<F, HAS_A, HAS_B>(P, i0 + j));
     Map<F> excl;
@@ -125,10 +125,10 @@ __global__ void __launch_bounds__(NT) scan_blocks(ScanParams P) {
     }
 }
 
-template <class F, bool HAS_A, bool HAS_B>
+template <class F, bool HAS_A, bool HAS_B, int PER>
 __global__ void __launch_bounds__(NT) scan_apply(ScanParams P) {
     __shared__ Map<F> sh[NT];
-    const size_t i0 = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * PER;
+    const size_t i0 = (size_t)blockIdx.x * (NT * PER) + (size_t)threadIdx.x * PER;
     Map<F> m = load_map<F, HAS_A, HAS_B>(P, i0);
     for (int j = 1; j < PER; j++) m = compose<F, HAS_A, HAS_B>(m, load_map<F, HAS_A, HAS_B>(P, i0 + j));
     Map<F> excl;

@@ -171,3 +171,8 @@ def test_running_evaluation_252(kind):
     for i in range(n):
         assert f252_from_mont_limbs(got[i]) == state, f"row {i}"
         state = (a[i] * state + b[i]) % F252.p
+
+
+def test_long_column_rows_per_lane_emu():
+    # columns of >= 2^20 rows take 16 rows per lane (4 below): both instantiations must agree with the loop
+    _scan_case("emu", (1 << 20) + 5, False, True, False, False, seed=5, mask_every=7)
