@@ -217,33 +217,41 @@ MS_HD W4 w4_from(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3) {
     return r;
 }
 
-// (acc_lo, acc_hi) with value acc_lo + acc_hi * 2^32 < 2^96  ->  weak 64-bit residue.
-//   2^64 = 2^32 - 1 (mod p):  lo64 + t * (2^32 - 1), t < 2^32, one conditional +EPS for the carry-out
-//   (after a carry the sum is < 2^63 + 2^32, so the fix cannot carry again).
-MS_HD uint64_t fold(uint64_t acc_lo, uint64_t acc_hi) {
-    const u128 y = (u128)acc_lo + ((u128)acc_hi << 32);
-    const uint64_t lo = (uint64_t)y;
-    const uint32_t t = (uint32_t)(y >> 64);
-    const u128 z = (u128)lo + (u128)((uint64_t)t * 0xFFFFFFFFull);
-    uint64_t r = (uint64_t)z;
-    if ((uint64_t)(z >> 64)) r += gl::EPS;
-    return r;
+// (acc_lo, acc_hi) with value acc_lo + acc_hi * 2^32 < 2^96  ->  64-bit residue.
+//   y = a0 + (a1 + b0) 2^32 + (b1 + carry) 2^64;   2^64 = 2^32 - 1 (mod p):   z = (m : a0) + t * (2^32 - 1), t < 2^32.
+//   z is computed wrapping (one v_mad_u64_u32); it overflowed iff z < (m : a0), and then z < 2^63.1 + 2^32, so the
+//   +EPS that accounts for the lost 2^64 cannot overflow again -- and lands below p.  CANON: the same +EPS also
+//   maps a z in [p, 2^64) to z - p, so the canonical form costs one more compare.
+template <bool CANON>
+MS_HD uint64_t fold_t(uint64_t acc_lo, uint64_t acc_hi) {
+    const uint32_t a0 = (uint32_t)acc_lo, a1 = (uint32_t)(acc_lo >> 32), b0 = (uint32_t)acc_hi, b1 = (uint32_t)(acc_hi >> 32);
+    const uint32_t m = a1 + b0;
+    const uint32_t t = b1 + (uint32_t)(m < a1);
+    const uint64_t base = ((uint64_t)m << 32) | a0;
+    const uint64_t z = (uint64_t)t * 0xFFFFFFFFull + base;
+    bool fix = z < base;
+    if (CANON) fix = fix || (z >= gl::P);
+    return z + (fix ? gl::EPS : 0ull);
 }
+MS_HD uint64_t fold(uint64_t acc_lo, uint64_t acc_hi) { return fold_t<false>(acc_lo, acc_hi); }
 
 // x * w as a weak residue.  Limbs must be in [0, 2^30) (network outputs carry the bias).
+template <bool CANON = false>
 MS_HD uint64_t mul_fold(const L4& x, const W4& w) {
     uint64_t alo = (uint64_t)x.l[0] * w.lo[0], ahi = (uint64_t)x.l[0] * w.hi[0];
     #pragma unroll
     for (int i = 1; i < 4; i++) { alo += (uint64_t)x.l[i] * w.lo[i]; ahi += (uint64_t)x.l[i] * w.hi[i]; }
-    return fold(alo, ahi);
+    return fold_t<CANON>(alo, ahi);
 }
 
 // x as a weak residue (no twiddle): the W_i are the constants 2^(24 i) mod p
 //   1, 2^24, 2^48, 2^72 = 2^40 - 2^8.
+template <bool CANON = false>
 MS_HD uint64_t to_weak(const L4& x) {
     const uint64_t alo = (uint64_t)x.l[0] + (uint64_t)x.l[1] * 0x1000000ull + (uint64_t)x.l[3] * 0xFFFFFF00ull;
     const uint64_t ahi = (uint64_t)x.l[2] * 0x10000ull + (uint64_t)x.l[3] * 0xFFull;
-    return fold(alo, ahi);
+    return fold_t<CANON>(alo, ahi);
 }
+MS_HD uint64_t to_canon(const L4& x) { return to_weak<true>(x); }
 
 }  // namespace glimb

@@ -16,6 +16,7 @@
 #include "../../include/ministark_hip.h"
 #include "gl.h"
 #include "ntt_kernels.h"
+#include "ntt2_kernels.h"
 #include "sha256_kernels.h"
 #include "stage_kernels.h"
 #include "fri_kernels.h"
@@ -286,6 +287,10 @@ struct ms_ntt_plan {
     uint64_t scale_const = 0;
     int scale_mode = 0;                 // last pass: 0 none, 1 const, 2 table
     uint64_t* d_tables = nullptr;       // one allocation backing every table
+    // limb-form passes (ntt2_kernels.h): plain tables of 4 pre-shifted copies per twiddle
+    uint64_t* d_wr4[4] = {nullptr, nullptr, nullptr, nullptr};    // radix-256 passes: w_256^e
+    uint64_t* d_twu4[4] = {nullptr, nullptr, nullptr, nullptr};   // middle passes: per-tile factor [U][k]
+    uint64_t *d_sc4 = nullptr, *d_g_plain = nullptr;
     std::vector<void*> queue;
     // Fp252 path (V == 4): plain radix-2 plan, see fp252_kernels.h
     bool is252 = false;
@@ -455,6 +460,40 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
     }
     // device tables are in Montgomery form: gld::mmul(data, w * 2^64) = data * w
     for (auto& v : host) v = gl::to_mont(v);
+    // ... except the tables of the limb-form passes (ntt2_kernels.h): plain residues, four copies
+    // {w, w 2^24, w 2^48, w 2^72} per twiddle, appended after the conversion
+    size_t off_wr4[4] = {0, 0, 0, 0}, off_twu4[4] = {0, 0, 0, 0}, off_sc4 = 0, off_gp = 0;
+    bool has_wr4[4] = {false, false, false, false}, has_twu4[4] = {false, false, false, false}, has_gp = false;
+    if (!p->small) {
+        const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
+        auto append4 = [&](const std::vector<uint64_t>& plain) {
+            const size_t off = host.size();
+            host.reserve(off + 4 * plain.size());
+            for (uint64_t v : plain) for (int i = 0; i < 4; i++) host.push_back(gl::mul(v, sh[i]));
+            return off;
+        };
+        for (int q = 0; q < p->npass; q++) {
+            if (p->lr[q] != 8) continue;
+            powers(t, 256, gl::pow(w, (uint64_t)n >> 8)); off_wr4[q] = append4(t); has_wr4[q] = true;
+            if (q >= 1 && q < p->npass - 1) {
+                // w_U^k = w_n^((rev(U) k) << log_s): the factor ntt_mid_pass builds per tile in LDS (twl[])
+                const size_t nU = n >> (8 + p->log_s[q]);
+                const uint64_t ws = gl::pow(w, (uint64_t)1 << p->log_s[q]);
+                t.resize(nU * 256);
+                for (size_t U = 0; U < nU; U++) {
+                    unsigned rU = 0;
+                    for (unsigned f = 0; f < p->nfields[q]; f++)
+                        rU |= (((unsigned)U >> p->fields[q][f].in_shift) & p->fields[q][f].mask) << p->fields[q][f].out_shift;
+                    const uint64_t wu = gl::pow(ws, rU);
+                    uint64_t x = 1;
+                    for (unsigned k = 0; k < 256; k++) { t[U * 256 + k] = x; x = gl::mul(x, wu); }
+                }
+                off_twu4[q] = append4(t); has_twu4[q] = true;
+            }
+        }
+        t.assign(1, ninv); off_sc4 = append4(t);
+        if (!p->inverse && p->coset) { powers(t, 256, gl::pow(h, (uint64_t)(n >> 8))); off_gp = host.size(); host.insert(host.end(), t.begin(), t.end()); has_gp = true; }
+    }
     p->scale_const = gl::to_mont(p->scale_const);
     hipError_t e = hipMalloc(&p->d_tables, host.size() * 8);
     if (e != hipSuccess) { delete p; return fail(MS_ERR_NOMEM, "plan tables (%zu bytes): %s", host.size() * 8, hipGetErrorString(e)); }
@@ -469,6 +508,12 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         for (int q = 0; q < p->npass; q++) p->d_wr[q] = p->d_tables + off_wr[q];
         if (has_aux) { p->d_aux_lo = p->d_tables + off_alo; p->d_aux_hi = p->d_tables + off_ahi; }
         if (has_g) p->d_gtab = p->d_tables + off_g;
+        for (int q = 0; q < p->npass; q++) {
+            if (has_wr4[q]) p->d_wr4[q] = p->d_tables + off_wr4[q];
+            if (has_twu4[q]) p->d_twu4[q] = p->d_tables + off_twu4[q];
+        }
+        p->d_sc4 = p->d_tables + off_sc4;
+        if (has_gp) p->d_g_plain = p->d_tables + off_gp;
     }
     *out = p;
     return MS_OK;
@@ -591,6 +636,52 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             dim3 grid(tiles, nc);
             static const char* const pass_names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
             ProfScope ps(ctx, pass_names[q], 2.0 * col_bytes * nc);
+            // limb-form radix-256 passes (ntt2_kernels.h) wherever a pass has radix 256 and rows of >= 64 words;
+            // MS_NTT_V1=1 keeps the round-1 kernels (A/B measurements)
+            static const bool force_v1 = getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0;
+            const size_t pass_sw = ((size_t)1 << p->log_s[q]) * p->V;
+            const bool v2_ok = !force_v1 && p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
+                               (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0 : (pass_sw % msntt2::TW == 0 && !(last && bitrev_out)));
+            static const bool dbg = getenv("MS_NTT_DEBUG") != nullptr;
+            if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? "limb-form (ntt2)" : "round-1");
+            if (v2_ok) {
+                msntt2::Params Q;
+                memset(&Q, 0, sizeof Q);
+                for (unsigned c = 0; c < nc; c++) { Q.src[c] = P.src[c]; Q.dst[c] = P.dst[c]; }
+                Q.wr4 = p->d_wr4[q]; Q.twu4 = p->d_twu4[q]; Q.sc4 = p->d_sc4; Q.g_plain = p->d_g_plain;
+                Q.tw_lo = p->d_tw_lo; Q.tw_hi = p->d_tw_hi; Q.aux_lo = p->d_aux_lo; Q.aux_hi = p->d_aux_hi;
+                Q.log_n = p->log_n; Q.V = p->V; Q.valid_rows = valid_rows; Q.lo_bits = p->lo_bits; Q.log_s = p->log_s[q];
+                Q.nfields = P.nfields;
+                for (unsigned f = 0; f < P.nfields; f++) Q.fields[f] = P.fields[f];
+                const dim3 g2((unsigned)(n * p->V / msntt2::TILE), nc), b2(msntt2::NT);
+                if (q == 0) {
+                    const bool cos = (!p->inverse && p->coset);
+                    const int na = valid_rows == 64 ? 4 : valid_rows == 32 ? 2 : valid_rows == 16 ? 1 : 16;
+                    if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, 16>), g2, b2, 0, st, Q);
+                    else if (cos) {
+                        if (na == 4) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 4>), g2, b2, 0, st, Q);
+                        else if (na == 2) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 2>), g2, b2, 0, st, Q);
+                        else if (na == 1) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 1>), g2, b2, 0, st, Q);
+                        else hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16>), g2, b2, 0, st, Q);
+                    } else {
+                        if (na == 4) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 4>), g2, b2, 0, st, Q);
+                        else if (na == 2) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 2>), g2, b2, 0, st, Q);
+                        else if (na == 1) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 1>), g2, b2, 0, st, Q);
+                        else hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 16>), g2, b2, 0, st, Q);
+                    }
+                } else if (!last) {
+                    if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0>), g2, b2, 0, st, Q);
+                    else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0>), g2, b2, 0, st, Q);
+                } else {
+                    const int scale = p->scale_mode;
+                    if (p->inverse) {
+                        if (scale == 1) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 1>), g2, b2, 0, st, Q);
+                        else if (scale == 2) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 2>), g2, b2, 0, st, Q);
+                        else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 0>), g2, b2, 0, st, Q);
+                    } else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, st, Q);
+                }
+                continue;
+            }
             if (q == 0) {
                 const bool cos = (!p->inverse && p->coset);
                 if (p->inverse) hipLaunchKernelGGL((msntt::ntt_first_pass<true, false>), grid, dim3(msntt::NT), 0, st, P);

@@ -94,6 +94,8 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 // device intrinsics used by the kernels
+static inline unsigned __builtin_amdgcn_readfirstlane(unsigned x) { return x; }   // only applied to wave-uniform values
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline unsigned __brev(unsigned x) {
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
     x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
