@@ -228,7 +228,9 @@ int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_digests, const
  * was just committed); d_out receives 2^log_n / folding_factor elements, bit-reversed, the next
  * layer's evaluations.  folding_factor in {2,4,8,16} (src/fri.rs:186-192); h_alpha = the drawn
  * challenge (one element of `field`); h_offset = domain_offset (Fp, NULL = 1 as build_layer
- * passes).  Bit-identical to bit_reverse + ifft + fold + fft + bit_reverse.  Asynchronous. */
+ * passes).  Bit-identical to bit_reverse + ifft + fold + fft + bit_reverse.  Asynchronous.
+ * NOT in place: [d_out, d_out + 2^log_n / folding_factor) must not overlap [d_evals, d_evals + 2^log_n)
+ * (MS_ERR_INVALID otherwise). */
 int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
                 const void* h_offset, const void* d_evals, void* d_out);
 
@@ -271,7 +273,36 @@ int ms_sha256_pow_grind(ms_ctx* ctx, const void* h_seed32, unsigned bits, uint64
  *                             nodes[n/2 ..), nodes[1] = root, nodes[0] = zero */
 int ms_rpo256_rows(ms_ctx* ctx, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_digests);
 int ms_rpo256_rows_row_major(ms_ctx* ctx, size_t nrows, unsigned ncols, const void* d_matrix, void* d_digests);
+/* MatrixMerkleTree over RPO-256 (README.md:90 "coming soon"): the leaf of row r absorbs the
+ * row's elements column by column; an Fq3 element contributes c0, c1, c2, the order its SHA-256 leaf serialises
+ * (src/hash.rs:93-98).  field = MS_GOLDILOCKS_FP or MS_GOLDILOCKS_FQ3. */
+int ms_rpo256_rows_field(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_digests);
 int ms_rpo256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leaves, void* d_nodes);
+
+/* ---- multi-GPU exchange (new work: the reference has one metal::Device,
+ * gpu/src/plan.rs:465-468).  One context per process and GPU; RCCL (librccl.so.1, loaded on first use)
+ * over xGMI.  Transforms need no communication -- rank g owns the columns {c : c mod nranks == g}, in that
+ * order -- and exactly two steps do:
+ *   ms_cols_to_rows_alltoall  a Merkle leaf hashes one element of EVERY column of a row (src/merkle.rs:428-431):
+ *                             column shards -> row shards.  d_my_cols[j] = my j-th column, nrows elements (the
+ *                             bit-reversed LDE); d_shard_cols[c], c < total_cols, receives rows
+ *                             [rank * nrows/nranks, (rank+1) * nrows/nranks) of column c.  Row blocks are sent
+ *                             straight out of the LDE columns (ncclSend/ncclRecv pairs in one group: every pair
+ *                             of GPUs talks directly, all xGMI links carry payload at once); no staging copies.
+ *   ms_allgather_digests      the nranks subtree roots (32 bytes each) -> every rank, device memory; the top
+ *                             log2(nranks) levels are then ms_sha256_merkle / ms_rpo256_merkle over them, which
+ *                             gives the root MerkleTree::from_matrix computes on one device, byte for byte.
+ * ms_comm_unique_id is called by ONE rank; the 128 bytes reach the others by any host channel (the mirror uses
+ * the torch.distributed store, a Rust host would use its own launcher).  Asynchronous on the context's stream.
+ * nranks must be a power of two dividing nrows. */
+#define MS_COMM_ID_BYTES 128
+int ms_comm_unique_id(void* h_id128);
+int ms_comm_init(ms_ctx* ctx, int nranks, int rank, const void* h_id128);
+int ms_comm_destroy(ms_ctx* ctx);
+int ms_comm_rank(ms_ctx* ctx, int* rank, int* nranks);
+int ms_cols_to_rows_alltoall(ms_ctx* ctx, int field, size_t nrows, const void* const* d_my_cols, unsigned my_ncols,
+                             unsigned total_cols, void* const* d_shard_cols);
+int ms_allgather_digests(ms_ctx* ctx, const void* d_my_digest32, void* d_all_digests);
 
 #ifdef __cplusplus
 }

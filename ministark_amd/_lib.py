@@ -78,6 +78,13 @@ class Lib:
             "ms_rpo256_rows": (i, [vp, sz, c_void_pp, u, vp]),
             "ms_rpo256_rows_row_major": (i, [vp, sz, u, vp, vp]),
             "ms_rpo256_merkle": (i, [vp, sz, vp, vp]),
+            "ms_rpo256_rows_field": (i, [vp, i, sz, c_void_pp, u, vp]),
+            "ms_comm_unique_id": (i, [vp]),
+            "ms_comm_init": (i, [vp, i, i, vp]),
+            "ms_comm_destroy": (i, [vp]),
+            "ms_comm_rank": (i, [vp, ctypes.POINTER(i), ctypes.POINTER(i)]),
+            "ms_cols_to_rows_alltoall": (i, [vp, i, sz, c_void_pp, u, u, c_void_pp]),
+            "ms_allgather_digests": (i, [vp, vp, vp]),
             "ms_sha256_rows_row_major": (i, [vp, i, sz, u, vp, vp]),
         }
         self.optional = {}

@@ -193,30 +193,52 @@ def _gather_digests(planner, digests, ndigests, ids):
     return [raw[32 * k:32 * k + 32] for k in range(len(ids))]
 
 
-class MerkleTree:
-    """`MatrixMerkleTreeImpl<Sha256HashFn>` (src/merkle.rs:296-361): `from_matrix` hashes the
-    rows and builds the node array on device; `root` is nodes[1] (src/merkle.rs:145-147)."""
+HASHES = ("sha256", "rpo256")
 
-    def __init__(self, planner, leaves, nleaves):
+
+class MerkleTree:
+    """`MatrixMerkleTreeImpl<H>` (src/merkle.rs:296-361): `from_matrix` hashes the rows and builds the node
+    array on device; `root` is nodes[1] (src/merkle.rs:145-147).  H is selected by `hash`:
+      "sha256"  Sha256HashFn (src/hash.rs:58-100), the reference's default;
+      "rpo256"  RPO-256 over Goldilocks, the GPU-friendly commitment the reference prepared kernels for
+                (gpu/src/plan.rs:32-174, README.md:90): leaves by ms_rpo256_rows_field, nodes by
+                gen_rpo_merkle_tree.  A digest is 4 Fp elements = 32 bytes, so proofs have the same shape."""
+
+    def __init__(self, planner, leaves, nleaves, hash="sha256"):
+        if hash not in HASHES:
+            raise ValueError(f"unknown hash {hash!r} (one of {HASHES})")
         self.planner = planner
         self.leaves = leaves
         self.nleaves = nleaves
+        self.hash = hash
         self.nodes = DeviceBytes(planner, nleaves * 32)
-        planner.lib.check(planner.lib.ms_sha256_merkle(planner.handle, nleaves, leaves.ptr, self.nodes.ptr))
+        L = planner.lib
+        if hash == "sha256":
+            L.check(L.ms_sha256_merkle(planner.handle, nleaves, leaves.ptr, self.nodes.ptr))
+        else:
+            L.check(L.ms_rpo256_merkle(planner.handle, nleaves, leaves.ptr, self.nodes.ptr))
 
     @classmethod
-    def from_matrix(cls, matrix):
-        return cls(matrix.planner, matrix.hash_rows(), matrix.num_rows())
+    def from_matrix(cls, matrix, hash="sha256"):
+        return cls(matrix.planner, matrix.hash_rows(hash), matrix.num_rows(), hash)
 
     @classmethod
-    def from_fri_layer(cls, evaluations, folding_factor):
+    def from_fri_layer(cls, evaluations, folding_factor, hash="sha256"):
         """`Matrix::from_arrays(evaluations.as_chunks::<N>())` + `M::from_matrix` (src/fri.rs:213-216):
         commit to a bit-reversed FRI layer whose rows are the cosets of N consecutive evaluations."""
         pl = evaluations.planner
         nrows = len(evaluations) // folding_factor
         leaves = DeviceBytes(pl, nrows * 32)
-        pl.lib.check(pl.lib.ms_sha256_rows_row_major(pl.handle, evaluations.field, nrows, folding_factor, evaluations.ptr, leaves.ptr))
-        return cls(pl, leaves, nrows)
+        if hash == "sha256":
+            pl.lib.check(pl.lib.ms_sha256_rows_row_major(pl.handle, evaluations.field, nrows, folding_factor, evaluations.ptr, leaves.ptr))
+        elif hash == "rpo256":
+            if evaluations.field == STARK252_FP:
+                raise ValueError("RPO-256 absorbs Goldilocks elements")
+            words = folding_factor * FIELD_WORDS[evaluations.field]          # a row is N elements = N (or 3 N) Fp words in memory order
+            pl.lib.check(pl.lib.ms_rpo256_rows_row_major(pl.handle, nrows, words, evaluations.ptr, leaves.ptr))
+        else:
+            raise ValueError(f"unknown hash {hash!r} (one of {HASHES})")
+        return cls(pl, leaves, nrows, hash)
 
     def prove(self, indices):
         """`MerkleTreeImpl::prove` (src/merkle.rs:149-206): the batched opening of `indices` as the
@@ -480,13 +502,18 @@ class Matrix:
         L.check(L.ms_gather_rows(pl.handle, self.field, self.num_rows(), _ptr_array(self.columns), self.num_cols(), pos.ctypes.data, len(pos), out.ptr))
         return out.to_numpy().view(np.uint64)[: len(pos) * words].reshape(len(pos), words)
 
-    def hash_rows(self):
-        """`hash_rows::<F, Sha256HashFn>` (src/merkle.rs:412-436, src/matrix.rs:254-280):
-        one SHA-256 digest per row -> DeviceBytes of num_rows x 32."""
+    def hash_rows(self, hash="sha256"):
+        """`hash_rows::<F, H>` (src/merkle.rs:412-436, src/matrix.rs:254-280): one digest per row ->
+        DeviceBytes of num_rows x 32.  H = Sha256HashFn ("sha256") or RPO-256 ("rpo256", Goldilocks columns)."""
         pl = self.planner
         n = self.num_rows()
         leaves = DeviceBytes(pl, n * 32)
-        pl.lib.check(pl.lib.ms_sha256_rows(pl.handle, self.field, n, _ptr_array(self.columns), len(self.columns), leaves.ptr))
+        if hash == "sha256":
+            pl.lib.check(pl.lib.ms_sha256_rows(pl.handle, self.field, n, _ptr_array(self.columns), len(self.columns), leaves.ptr))
+        elif hash == "rpo256":
+            pl.lib.check(pl.lib.ms_rpo256_rows_field(pl.handle, self.field, n, _ptr_array(self.columns), len(self.columns), leaves.ptr))
+        else:
+            raise ValueError(f"unknown hash {hash!r} (one of {HASHES})")
         return leaves
 
     def lde(self, blowup, offset=GL_GENERATOR, bit_reversed=True):

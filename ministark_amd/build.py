@@ -45,15 +45,36 @@ def embed_headers():
             f.write(new)
 
 
+STAMP = SO + ".srchash"
+
+
+def source_hash(cmd):
+    """Content hash of every source the library is compiled from, plus the command line: the binary is rebuilt
+    when this changes, whatever the file times say (the .so is git-ignored and travels with snapshots)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for p in sorted(_deps()):
+        h.update(os.path.relpath(p, ROOT).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
     embed_headers()
-    newest = max(os.path.getmtime(p) for p in _deps())
-    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
+    cmd = [HIPCC] + FLAGS + os.environ.get("MS_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO, "-lhiprtc", "-ldl"]
+    want = source_hash(cmd)
+    if not force and os.path.exists(SO) and os.path.exists(STAMP) and open(STAMP).read().strip() == want:
         return SO
-    cmd = [HIPCC] + FLAGS + os.environ.get("MS_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO, "-lhiprtc"]
+    if not os.path.exists(HIPCC):
+        # a box without the compiler (none is expected): keep a binary that is at least present
+        if os.path.exists(SO):
+            return SO
+        raise FileNotFoundError(f"{HIPCC} not found and {SO} has not been built")
     if verbose:
         print("[ministark_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(want + "\n")
     return SO
 
 

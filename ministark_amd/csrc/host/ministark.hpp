@@ -204,23 +204,29 @@ public:
     std::vector<void*> ptrs() const { std::vector<void*> p; for (auto& c : columns) p.push_back(c.ptr()); return p; }
 };
 
+// H of MatrixMerkleTreeImpl<H> (src/merkle.rs:296-361): Sha256HashFn (src/hash.rs:58-100) or RPO-256 over
+// Goldilocks (gpu/src/plan.rs:32-174, README.md:90).  Both digests are 32 bytes, proofs have the same shape.
+enum class Hash { Sha256, Rpo256 };
+
 class MerkleTree {
 public:
     template <class F>
-    static MerkleTree from_matrix(const Matrix<F>& m) {                // src/merkle.rs:356-361
+    static MerkleTree from_matrix(const Matrix<F>& m, Hash h = Hash::Sha256) {                // src/merkle.rs:356-361
         MerkleTree t(m.planner(), m.num_rows());
         std::vector<const void*> in; for (auto& c : m.columns) in.push_back(c.ptr());
-        check(ms_sha256_rows(t.pl_->ctx(), F::id, t.n_, in.data(), (unsigned)in.size(), t.leaves_));
-        check(ms_sha256_merkle(t.pl_->ctx(), t.n_, t.leaves_, t.nodes_));
+        if (h == Hash::Sha256) check(ms_sha256_rows(t.pl_->ctx(), F::id, t.n_, in.data(), (unsigned)in.size(), t.leaves_));
+        else check(ms_rpo256_rows_field(t.pl_->ctx(), F::id, t.n_, in.data(), (unsigned)in.size(), t.leaves_));
+        t.build(h);
         return t;
     }
     // Matrix::from_arrays(evaluations.as_chunks::<N>()) + from_matrix (src/fri.rs:213-216): commit to a bit-reversed
     // FRI layer whose rows are the cosets of `folding_factor` consecutive evaluations
     template <class F>
-    static MerkleTree from_fri_layer(const GpuVec<F>& evaluations, unsigned folding_factor) {
+    static MerkleTree from_fri_layer(const GpuVec<F>& evaluations, unsigned folding_factor, Hash h = Hash::Sha256) {
         MerkleTree t(evaluations.planner(), evaluations.len() / folding_factor);
-        check(ms_sha256_rows_row_major(t.pl_->ctx(), F::id, t.n_, folding_factor, evaluations.ptr(), t.leaves_));
-        check(ms_sha256_merkle(t.pl_->ctx(), t.n_, t.leaves_, t.nodes_));
+        if (h == Hash::Sha256) check(ms_sha256_rows_row_major(t.pl_->ctx(), F::id, t.n_, folding_factor, evaluations.ptr(), t.leaves_));
+        else check(ms_rpo256_rows_row_major(t.pl_->ctx(), t.n_, folding_factor * (unsigned)(ms_field_bytes(F::id) / 8), evaluations.ptr(), t.leaves_));
+        t.build(h);
         return t;
     }
     using Digest = std::array<uint8_t, 32>;
@@ -265,6 +271,10 @@ public:
     MerkleTree(MerkleTree&& o) noexcept : pl_(o.pl_), n_(o.n_), leaves_(o.leaves_), nodes_(o.nodes_) { o.leaves_ = o.nodes_ = nullptr; }
 private:
     MerkleTree(Planner& pl, size_t n) : pl_(&pl), n_(n) { check(ms_alloc(pl.ctx(), n * 32, &leaves_)); check(ms_alloc(pl.ctx(), n * 32, &nodes_)); }
+    void build(Hash h) {
+        if (h == Hash::Sha256) check(ms_sha256_merkle(pl_->ctx(), n_, leaves_, nodes_));
+        else check(ms_rpo256_merkle(pl_->ctx(), n_, leaves_, nodes_));
+    }
     std::vector<Digest> gather(const void* digests, const std::vector<uint64_t>& ids) const {
         std::vector<Digest> out(ids.size());
         if (ids.empty()) return out;

@@ -95,11 +95,13 @@ struct ms_ctx {
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)96 << 30;
     std::map<void*, size_t> live;            // size of every block handed out by ms_alloc
+    void* comm = nullptr;                    // ncclComm_t once ms_comm_init has run
+    int comm_rank = 0, comm_size = 1;
     void* prog_buf = nullptr;                // device copy of the current constraint program + constants
     size_t prog_bytes = 0;
     // constraint programs compiled to specialised kernels (eval_jit.h), by hash of the generated source;
     // nullptr = compilation failed once, use the interpreter
-    std::map<uint64_t, hipFunction_t> jit_cache;
+    std::map<std::string, hipFunction_t> jit_cache;   // keyed by the full source text, not a hash of it
     std::vector<hipModule_t> jit_modules;
     // optional per-launch timing (ms_profile_*): hipEvent pairs around every kernel launch
     bool profiling = false;
@@ -154,9 +156,11 @@ extern "C" int ms_ctx_create(int device, ms_ctx** out) {
     return MS_OK;
 }
 extern "C" int ms_ntt_plan_destroy(ms_ntt_plan* plan);
+extern "C" int ms_comm_destroy(ms_ctx* ctx);
 extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     if (!ctx) return MS_OK;
     (void)hipStreamSynchronize(ctx->stream);
+    (void)ms_comm_destroy(ctx);
     for (auto& kv : ctx->plan_cache) ms_ntt_plan_destroy(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
@@ -246,6 +250,24 @@ extern "C" int ms_free(ms_ctx* ctx, void* d_ptr) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     return pool_free(ctx, d_ptr);
 }
+// Pooled temporaries of an entry point, returned to the pool on EVERY exit path (an early return through
+// MSCHK / HIPCHK used to strand them in ctx->live until ms_ctx_destroy).  PoolGuard goes through the locking
+// public calls and must outlive the function's lock scope; LockedPoolGuard is for code that already holds
+// ctx->mu and must be declared after the lock_guard (so that it is destroyed first).
+struct PoolGuard {
+    ms_ctx* ctx; std::vector<void*> blocks;
+    explicit PoolGuard(ms_ctx* c) : ctx(c) {}
+    int alloc(size_t bytes, void** p) { const int rc = ms_alloc(ctx, bytes, p); if (rc == MS_OK) blocks.push_back(*p); return rc; }
+    ~PoolGuard() { for (void* b : blocks) (void)ms_free(ctx, b); }
+    PoolGuard(const PoolGuard&) = delete; PoolGuard& operator=(const PoolGuard&) = delete;
+};
+struct LockedPoolGuard {
+    ms_ctx* ctx; std::vector<void*> blocks;
+    explicit LockedPoolGuard(ms_ctx* c) : ctx(c) {}
+    int alloc(size_t bytes, void** p) { const int rc = pool_alloc(ctx, bytes, p); if (rc == MS_OK) blocks.push_back(*p); return rc; }
+    ~LockedPoolGuard() { for (void* b : blocks) (void)pool_free(ctx, b); }
+    LockedPoolGuard(const LockedPoolGuard&) = delete; LockedPoolGuard& operator=(const LockedPoolGuard&) = delete;
+};
 extern "C" int ms_copy(ms_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
     if (!ctx || (bytes && (!d_dst || !d_src))) return fail(MS_ERR_INVALID, "ms_copy: null argument");
     HIPCHK(hipSetDevice(ctx->device));
@@ -296,6 +318,7 @@ struct ms_ntt_plan {
     bool is252 = false;
     uint64_t *d252_tw_lo = nullptr, *d252_tw_hi = nullptr, *d252_sc_lo = nullptr, *d252_sc_hi = nullptr;
     int scale_in252 = 0, scale_out252 = 0;
+    uint64_t off252[4] = {0, 0, 0, 0};  // the coset offset itself: cache lookups compare it, not just its hash
 };
 
 static void powers(std::vector<uint64_t>& out, size_t count, uint64_t base, uint64_t first = 1) {
@@ -346,6 +369,7 @@ static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* 
     const bool coset = !f252::eq(h, f252::one());
     ms_ntt_plan* p = new ms_ntt_plan();
     p->ctx = ctx; p->V = 4; p->log_n = log_n; p->inverse = inverse; p->coset = coset; p->is252 = true;
+    memcpy(p->off252, h.l, 32);
     const size_t n = (size_t)1 << log_n;
     const f252::E w = inverse ? f252::inv(gen) : gen;
     // one-level tables up to 2^21 points: every twiddle / scale factor is a single 32-byte load.  (A two-level
@@ -373,12 +397,38 @@ static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* 
     return MS_OK;
 }
 
-// plan owned by the context, reused by the fused entry points (ms_lde, ms_fri_fold)
+// Plans owned by the context, reused by the fused entry points (ms_lde, ms_fri_fold, ...).  The cache is bounded:
+// most recently used at the back, and beyond PLAN_CACHE_MAX entries the least recently used plan is destroyed
+// (a prover that varies sizes / offsets -- FRI layers, periodic-column cosets -- would otherwise accumulate twiddle
+// tables until ms_ctx_destroy).  One call uses at most a handful of plans, so a plan handed out in a call cannot
+// be evicted by the same call.
+static constexpr size_t PLAN_CACHE_MAX = 32;
+static ms_ntt_plan* plan_cache_find(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uint64_t h, const uint64_t* off252 = nullptr) {
+    auto& pc = ctx->plan_cache;
+    for (size_t i = 0; i < pc.size(); i++) {
+        const PlanKey& k = pc[i].first;
+        if (k.V != V || k.log_n != log_n || k.inverse != inverse || k.h != h) continue;
+        if (off252 && memcmp(pc[i].second->off252, off252, 32) != 0) continue;       // same hash, different offset
+        auto hit = pc[i];
+        pc.erase(pc.begin() + (long)i);
+        pc.push_back(hit);
+        return hit.second;
+    }
+    return nullptr;
+}
+static void plan_cache_insert(ms_ctx* ctx, const PlanKey& key, ms_ntt_plan* plan) {
+    ctx->plan_cache.push_back({key, plan});
+    while (ctx->plan_cache.size() > PLAN_CACHE_MAX) {
+        ms_ntt_plan* old = ctx->plan_cache.front().second;
+        ctx->plan_cache.erase(ctx->plan_cache.begin());
+        (void)ms_ntt_plan_destroy(old);                        // synchronises the stream before freeing the tables
+    }
+}
+static int plan252_cached(ms_ctx* ctx, unsigned log_n, bool inverse, const f252::E& h, ms_ntt_plan** out);   // Fp252: keyed by the offset itself
 static int ctx_plan(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uint64_t h, ms_ntt_plan** out) {
-    for (auto& kv : ctx->plan_cache)
-        if (kv.first.V == V && kv.first.log_n == log_n && kv.first.inverse == inverse && kv.first.h == h) { *out = kv.second; return MS_OK; }
+    if ((*out = plan_cache_find(ctx, V, log_n, inverse, h)) != nullptr) return MS_OK;
     MSCHK(plan_build(ctx, V, log_n, inverse, h, out));
-    ctx->plan_cache.push_back({PlanKey{V, log_n, inverse, h}, *out});
+    plan_cache_insert(ctx, PlanKey{V, log_n, inverse, h}, *out);
     return MS_OK;
 }
 
@@ -640,8 +690,12 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             // MS_NTT_V1=1 keeps the round-1 kernels (A/B measurements)
             static const bool force_v1 = getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0;
             const size_t pass_sw = ((size_t)1 << p->log_s[q]) * p->V;
+            // (the fused bit-reversed store and the per-element scale walk of an inverse coset transform stay with the
+            // round-1 last pass: the walk is two table loads and a Montgomery product per word, which the 4-wave limb kernel
+            // hides worse -- 91 vs 75 us per 2^24 column)
             const bool v2_ok = !force_v1 && p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
-                               (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0 : (pass_sw % msntt2::TW == 0 && !(last && bitrev_out)));
+                               (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0
+                                       : (pass_sw % msntt2::TW == 0 && !(last && (bitrev_out || p->scale_mode == 2))));
             static const bool dbg = getenv("MS_NTT_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? "limb-form (ntt2)" : "round-1");
             if (v2_ok) {
@@ -676,7 +730,6 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                     const int scale = p->scale_mode;
                     if (p->inverse) {
                         if (scale == 1) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 1>), g2, b2, 0, st, Q);
-                        else if (scale == 2) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 2>), g2, b2, 0, st, Q);
                         else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 0>), g2, b2, 0, st, Q);
                     } else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, st, Q);
                 }
@@ -715,6 +768,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
 
 extern "C" int ms_ntt_encode(ms_ntt_plan* plan, void* d_column) {
     if (!plan || !d_column) return fail(MS_ERR_INVALID, "ms_ntt_encode: null argument");
+    std::lock_guard<std::mutex> lk(plan->ctx->mu);
     plan->queue.push_back(d_column);
     return MS_OK;
 }
@@ -727,7 +781,7 @@ extern "C" int ms_ntt_enqueue(ms_ntt_plan* plan, void* const* d_columns, unsigne
 extern "C" int ms_ntt_execute(ms_ntt_plan* plan) {
     if (!plan) return fail(MS_ERR_INVALID, "ms_ntt_execute: null plan");
     std::vector<void*> q;
-    q.swap(plan->queue);
+    { std::lock_guard<std::mutex> lk(plan->ctx->mu); q.swap(plan->queue); }
     if (!q.empty()) MSCHK(ms_ntt_enqueue(plan, q.data(), (unsigned)q.size()));
     HIPCHK(hipStreamSynchronize(plan->ctx->stream));
     return MS_OK;
@@ -800,16 +854,10 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         f252::E h252 = f252::one();
         if (h_offset) memcpy(h252.l, h_offset, 32);
         std::lock_guard<std::mutex> lk(ctx->mu);
+        if (f252::is_zero(h252) || f252::geq_p(h252)) return fail(MS_ERR_INVALID, "coset offset must be a non-zero canonical element");
         ms_ntt_plan *inv = nullptr, *fwd = nullptr;
-        uint64_t hkey = 1469598103934665603ull;                  // cache key of the forward plan: a hash of the offset
-        for (int w = 0; w < 4; w++) { hkey ^= h252.l[w]; hkey *= 1099511628211ull; }
-        hkey |= (uint64_t)1 << 63;
-        for (auto& kv : ctx->plan_cache) {
-            if (kv.first.V == 4 && kv.first.log_n == log_n && kv.first.inverse && kv.first.h == 1) inv = kv.second;
-            if (kv.first.V == 4 && kv.first.log_n == log_N && !kv.first.inverse && kv.first.h == hkey) fwd = kv.second;
-        }
-        if (!inv) { MSCHK(plan_build252(ctx, log_n, true, nullptr, nullptr, &inv)); ctx->plan_cache.push_back({PlanKey{4, log_n, true, 1}, inv}); }
-        if (!fwd) { MSCHK(plan_build252(ctx, log_N, false, h252.l, nullptr, &fwd)); ctx->plan_cache.push_back({PlanKey{4, log_N, false, hkey}, fwd}); }
+        MSCHK(plan252_cached(ctx, log_n, true, f252::one(), &inv));
+        MSCHK(plan252_cached(ctx, log_N, false, h252, &fwd));
         MSCHK(plan_run252(inv, d_in, d_out, ncols));
         const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
         if (N > n)
@@ -865,11 +913,8 @@ extern "C" int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_
         if (log_domain > 40) return fail(MS_ERR_INVALID, "domain 2^%u too large", log_domain);
         f252::E h252 = f252::one();
         if (h_offset) memcpy(h252.l, h_offset, 32);
-        uint64_t hkey = 1469598103934665603ull;
-        for (int w = 0; w < 4; w++) { hkey ^= h252.l[w]; hkey *= 1099511628211ull; }
-        hkey |= (uint64_t)1 << 63;
-        for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_domain && !kv.first.inverse && kv.first.h == hkey) fwd = kv.second;
-        if (!fwd) { MSCHK(plan_build252(ctx, log_domain, false, h252.l, nullptr, &fwd)); ctx->plan_cache.push_back({PlanKey{4, log_domain, false, hkey}, fwd}); }
+        if (f252::is_zero(h252) || f252::geq_p(h252)) return fail(MS_ERR_INVALID, "coset offset must be a non-zero canonical element");
+        MSCHK(plan252_cached(ctx, log_domain, false, h252, &fwd));
     } else {
         if (log_domain > 32) return fail(MS_ERR_INVALID, "domain 2^%u exceeds the two-adicity", log_domain);
         uint64_t h = 1;
@@ -1163,6 +1208,11 @@ extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned fold
     unsigned log_ff = 0;
     while ((1u << log_ff) < folding_factor) log_ff++;
     if (log_n < log_ff || log_n > 32) return fail(MS_ERR_INVALID, "bad layer size 2^%u for folding factor %u", log_n, folding_factor);
+    {   // lane c reads d_evals[c*ff .. c*ff + ff) and writes d_out[c]: overlapping buffers would corrupt the next layer
+        const size_t in_bytes = ((size_t)1 << log_n) * V * 8, out_bytes = in_bytes / folding_factor;
+        const char *a = (const char*)d_evals, *b = (const char*)d_out;
+        if (a < b + out_bytes && b < a + in_bytes) return fail(MS_ERR_INVALID, "ms_fri_fold: d_out overlaps d_evals (the fold is not an in-place operation)");
+    }
     if (V == 4) {
         f252::E h252 = f252::one();
         if (h_offset) memcpy(h252.l, h_offset, 32);
@@ -1170,8 +1220,7 @@ extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned fold
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIPCHK(hipSetDevice(ctx->device));
         ms_ntt_plan* plan = nullptr;
-        for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_n && kv.first.inverse && kv.first.h == 1) plan = kv.second;
-        if (!plan) { MSCHK(plan_build252(ctx, log_n, true, nullptr, nullptr, &plan)); ctx->plan_cache.push_back({PlanKey{4, log_n, true, 1}, plan}); }
+        MSCHK(plan252_cached(ctx, log_n, true, f252::one(), &plan));
         ms252::Fold252Params P;
         memset(&P, 0, sizeof P);
         P.src = (const uint64_t*)d_evals; P.dst = (uint64_t*)d_out;
@@ -1341,8 +1390,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     if (!d_x_lde) {
         ms_ntt_plan* plan = nullptr;
         if (is252) {
-            for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_n && !kv.first.inverse && kv.first.h == 1) plan = kv.second;
-            if (!plan) { MSCHK(plan_build252(ctx, log_n, false, nullptr, nullptr, &plan)); ctx->plan_cache.push_back({PlanKey{4, log_n, false, 1}, plan}); }
+            MSCHK(plan252_cached(ctx, log_n, false, f252::one(), &plan));
             E.tw_lo = plan->d252_tw_lo; E.tw_hi = plan->d252_tw_hi; E.lo_bits = plan->lo_bits;
         } else {
             table_log = std::max(log_n, 12u);
@@ -1356,7 +1404,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         static const bool off = getenv("MS_EVAL_JIT") && !strcmp(getenv("MS_EVAL_JIT"), "0");
         if (off) return nullptr;
         const std::string src = jit_source(pr, cnt, is252, maxp, maxq);
-        const uint64_t key = jit_hash(src);
+        const std::string& key = src;
         auto it = ctx->jit_cache.find(key);
         if (it != ctx->jit_cache.end()) return it->second;
         hipFunction_t fn = nullptr;
@@ -1379,8 +1427,11 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         if (fn) {
             EvalParams A = Q;
             void* args[] = {&A};
-            (void)hipModuleLaunchKernel(fn, g.x, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
-            return;
+            if (hipModuleLaunchKernel(fn, g.x, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr) == hipSuccess) return;
+            // a module-API launch error does not reliably surface in hipGetLastError(): do not leave d_out unwritten,
+            // run the interpreter instead and stop offering this kernel
+            (void)hipGetLastError();
+            for (auto& kv : ctx->jit_cache) if (kv.second == fn) kv.second = nullptr;
         }
         if (is252) {
             if (maxp <= 16) hipLaunchKernelGGL((eval_program252<16>), g, dim3(NT), 0, ctx->stream, Q);
@@ -1394,11 +1445,12 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     };
     // ---- prologue: the short-period values on the first 2^log_period points -> tables
     void* tables = nullptr;
+    LockedPoolGuard pooled(ctx);                              // stream-ordered: the next user of a block queues behind these kernels
     if (pro_n) {
         const size_t period = (size_t)1 << split.log_period;
         size_t words = 0;
         for (unsigned w : split.table_words) words += w * period;
-        MSCHK(pool_alloc(ctx, words * 8, &tables));
+        MSCHK(pooled.alloc(words * 8, &tables));
         uint64_t* tp = (uint64_t*)tables;
         for (size_t t = 0; t < split.table_words.size(); t++) {
             E.periodic[nperiodic + t] = tp; E.periodic_len[nperiodic + t] = (uint32_t)period;
@@ -1455,7 +1507,6 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
                      is252 ? 32.0 * n * (nbase + 1) : 8.0 * n * (nbase + 3.0 * next + (out_field == MS_GOLDILOCKS_FQ3 ? 3 : 1)));
         launch(E, fn);
     }
-    if (tables) pool_free(ctx, tables);                      // stream-ordered: the next user of the block queues behind this kernel
     HIPCHK(hipGetLastError());
     return MS_OK;
 }
@@ -1517,7 +1568,8 @@ extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a,
     memcpy(P.init, h_init, V * 8);
     P.n = n; P.nblocks = (unsigned)((n + tile - 1) / tile); P.inclusive = inclusive != 0;
     void* tmp = nullptr;
-    MSCHK(pool_alloc(ctx, (size_t)P.nblocks * 3 * V * 8, &tmp));
+    LockedPoolGuard pooled(ctx);
+    MSCHK(pooled.alloc((size_t)P.nblocks * 3 * V * 8, &tmp));
     P.agg = (uint64_t*)tmp; P.block_state = (uint64_t*)tmp + (size_t)P.nblocks * 2 * V;
     using msstage::FpT; using msstage::Fq3T; using msstage::Fp252T;
     if (V == 1) {
@@ -1527,7 +1579,6 @@ extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a,
     } else {
         if (d_a && d_b) scan_launch<Fq3T, true, true>(ctx, P); else if (d_a) scan_launch<Fq3T, true, false>(ctx, P); else scan_launch<Fq3T, false, true>(ctx, P);
     }
-    pool_free(ctx, tmp);
     HIPCHK(hipGetLastError());
     return MS_OK;
 }
@@ -1542,17 +1593,17 @@ extern "C" int ms_gather_rows(ms_ctx* ctx, int field, size_t nrows, const void* 
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     void* d_pos = nullptr;
-    MSCHK(pool_alloc(ctx, npos * 8, &d_pos));
+    LockedPoolGuard pooled(ctx);
+    MSCHK(pooled.alloc(npos * 8, &d_pos));
     HIPCHK(hipMemcpyAsync(d_pos, h_positions, npos * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));               // h_positions is pageable caller memory
     msscan::GatherRowsParams P;
     memset(&P, 0, sizeof P);
-    for (unsigned c = 0; c < ncols; c++) { if (!d_cols[c]) { pool_free(ctx, d_pos); return fail(MS_ERR_INVALID, "null column %u", c); } P.cols[c] = (const uint64_t*)d_cols[c]; }
+    for (unsigned c = 0; c < ncols; c++) { if (!d_cols[c]) return fail(MS_ERR_INVALID, "null column %u", c); P.cols[c] = (const uint64_t*)d_cols[c]; }
     P.pos = (const uint64_t*)d_pos; P.out = (uint64_t*)d_out; P.npos = npos; P.ncols = ncols; P.V = (unsigned)(fb / 8);
     const size_t total = npos * ncols * P.V;
     { ProfScope ps(ctx, "gather_rows", 16.0 * total);
       hipLaunchKernelGGL(msscan::gather_rows, dim3(stream_grid(total)), dim3(msscan::NT), 0, ctx->stream, P); }
-    pool_free(ctx, d_pos);
     HIPCHK(hipGetLastError());
     return MS_OK;
 }
@@ -1563,13 +1614,13 @@ extern "C" int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_dig
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     void* d_idx = nullptr;
-    MSCHK(pool_alloc(ctx, count * 8, &d_idx));
+    LockedPoolGuard pooled(ctx);
+    MSCHK(pooled.alloc(count * 8, &d_idx));
     HIPCHK(hipMemcpyAsync(d_idx, h_indices, count * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     { ProfScope ps(ctx, "gather_digests", 64.0 * count);
       hipLaunchKernelGGL(msscan::gather_records, dim3(stream_grid(count * 4)), dim3(msscan::NT), 0, ctx->stream,
                          (const uint64_t*)d_digests, (const uint64_t*)d_idx, (uint64_t*)d_out, count, 4u); }
-    pool_free(ctx, d_idx);
     HIPCHK(hipGetLastError());
     return MS_OK;
 }
@@ -1597,6 +1648,20 @@ extern "C" int ms_rpo256_rows(ms_ctx* ctx, size_t nrows, const void* const* d_co
     std::vector<const uint64_t*> cols(ncols);
     for (unsigned c = 0; c < ncols; c++) cols[c] = (const uint64_t*)d_cols[c];
     return rpo_rows(ctx, nrows, cols.data(), ncols, 1, d_digests);
+}
+// rows of a column-major matrix of `field`: an Fq3 column contributes its components c0, c1, c2 in the order
+// the SHA-256 leaves serialise them (src/hash.rs:93-98) -- the column pointers are simply taken at word stride 3
+extern "C" int ms_rpo256_rows_field(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols, void* d_digests) {
+    if (!ctx || !d_cols || !d_digests) return fail(MS_ERR_INVALID, "ms_rpo256_rows_field: null argument");
+    unsigned V = 0;
+    MSCHK(field_words(field, &V));
+    if (V != 1 && V != 3) return fail(MS_ERR_UNSUPPORTED, "RPO-256 absorbs Goldilocks elements (Fp or Fq3 columns)");
+    std::vector<const uint64_t*> cols;
+    for (unsigned c = 0; c < ncols; c++) {
+        if (!d_cols[c]) return fail(MS_ERR_INVALID, "null column %u", c);
+        for (unsigned k = 0; k < V; k++) cols.push_back((const uint64_t*)d_cols[c] + k);
+    }
+    return rpo_rows(ctx, nrows, cols.data(), (unsigned)cols.size(), V, d_digests);
 }
 extern "C" int ms_rpo256_rows_row_major(ms_ctx* ctx, size_t nrows, unsigned ncols, const void* d_matrix, void* d_digests) {
     if (!ctx || !d_matrix || !d_digests) return fail(MS_ERR_INVALID, "ms_rpo256_rows_row_major: null argument");
@@ -1640,9 +1705,10 @@ static int horner_eval252(ms_ctx* ctx, size_t n, const void* const* d_cols, unsi
     for (unsigned q = 0; q < nq; q++) if (h_qcol[q] >= ncols) return fail(MS_ERR_INVALID, "query %u names column %u of %u", q, h_qcol[q], ncols);
     const unsigned nblocks = (unsigned)std::max<size_t>(1, (n + 4095) / 4096);
     void *d_qcol = nullptr, *d_pts = nullptr, *d_part = nullptr;
-    MSCHK(ms_alloc(ctx, (size_t)nq * 4, &d_qcol));
-    MSCHK(ms_alloc(ctx, (size_t)nq * 32, &d_pts));
-    MSCHK(ms_alloc(ctx, (size_t)nq * nblocks * 32, &d_part));
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
+    MSCHK(pooled.alloc((size_t)nq * 32, &d_pts));
+    MSCHK(pooled.alloc((size_t)nq * nblocks * 32, &d_part));
     std::vector<uint64_t> part((size_t)nq * nblocks * 4);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1661,7 +1727,6 @@ static int horner_eval252(ms_ctx* ctx, size_t n, const void* const* d_cols, unsi
         HIPCHK(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    ms_free(ctx, d_qcol); ms_free(ctx, d_pts); ms_free(ctx, d_part);
     for (unsigned q = 0; q < nq; q++) {                       // sum_b E_b * (x^4096)^b
         f252::E xb;
         memcpy(xb.l, h_qpoints + 4 * (size_t)q, 32);
@@ -1684,9 +1749,9 @@ static uint64_t offset_key252(const f252::E& h) {
 static int plan252_cached(ms_ctx* ctx, unsigned log_n, bool inverse, const f252::E& h, ms_ntt_plan** out) {
     const bool coset = !f252::eq(h, f252::one());
     const uint64_t key = coset ? offset_key252(h) : 1;
-    for (auto& kv : ctx->plan_cache) if (kv.first.V == 4 && kv.first.log_n == log_n && kv.first.inverse == inverse && kv.first.h == key) { *out = kv.second; return MS_OK; }
+    if ((*out = plan_cache_find(ctx, 4, log_n, inverse, key, h.l)) != nullptr) return MS_OK;
     MSCHK(plan_build252(ctx, log_n, inverse, h.l, nullptr, out));
-    ctx->plan_cache.push_back({PlanKey{4, log_n, inverse, key}, *out});
+    plan_cache_insert(ctx, PlanKey{4, log_n, inverse, key}, *out);
     return MS_OK;
 }
 static int deep_compose252(ms_ctx* ctx, unsigned log_n, const void* h_offset, const void* const* d_polys, unsigned ncols,
@@ -1704,9 +1769,10 @@ static int deep_compose252(ms_ctx* ctx, unsigned log_n, const void* h_offset, co
     const size_t n = (size_t)1 << log_n;
     std::vector<void*> ev(ncols, nullptr);
     void *d_terms = nullptr, *d_q = nullptr;
-    for (unsigned c = 0; c < ncols; c++) MSCHK(ms_alloc(ctx, n * 32, &ev[c]));
-    MSCHK(ms_alloc(ctx, std::max<size_t>(1, nterms) * sizeof(msdeep252::Term), &d_terms));
-    MSCHK(ms_alloc(ctx, n * 32, &d_q));
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    for (unsigned c = 0; c < ncols; c++) MSCHK(pooled.alloc(n * 32, &ev[c]));
+    MSCHK(pooled.alloc(std::max<size_t>(1, nterms) * sizeof(msdeep252::Term), &d_terms));
+    MSCHK(pooled.alloc(n * 32, &d_q));
     std::vector<msdeep252::Term> terms(nterms);
     for (unsigned t = 0; t < nterms; t++) {
         terms[t].col = h_term_col[t]; terms[t].point = h_term_point[t];
@@ -1744,8 +1810,6 @@ static int deep_compose252(ms_ctx* ctx, unsigned log_n, const void* h_offset, co
           hipLaunchKernelGGL(msdeep252::deep_degree_adjust, g, dim3(msdeep252::NT), 0, ctx->stream, (uint64_t*)d_out, (const uint64_t*)d_q, n, da, db); }
         HIPCHK(hipGetLastError());
     }
-    for (void* p : ev) ms_free(ctx, p);
-    ms_free(ctx, d_terms); ms_free(ctx, d_q);
     return MS_OK;
 }
 
@@ -1768,9 +1832,10 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
     std::vector<uint64_t> pts((size_t)nq * 3, 0);
     for (unsigned q = 0; q < nq; q++) memcpy(&pts[3 * q], (const uint64_t*)h_qpoints + (size_t)q * PW, PW * 8);
     void *d_qcol = nullptr, *d_pts = nullptr, *d_part = nullptr;
-    MSCHK(ms_alloc(ctx, (size_t)nq * 4, &d_qcol));
-    MSCHK(ms_alloc(ctx, (size_t)nq * 24, &d_pts));
-    MSCHK(ms_alloc(ctx, (size_t)nq * nblocks * 24, &d_part));
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
+    MSCHK(pooled.alloc((size_t)nq * 24, &d_pts));
+    MSCHK(pooled.alloc((size_t)nq * nblocks * 24, &d_part));
     std::vector<uint64_t> part((size_t)nq * nblocks * 3);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1792,7 +1857,6 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
         HIPCHK(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    ms_free(ctx, d_qcol); ms_free(ctx, d_pts); ms_free(ctx, d_part);
     // combine the block values on the host: sum_b E_b * (x^4096)^b
     for (unsigned q = 0; q < nq; q++) {
         gl::Fq3 x = q3_load(&pts[3 * q], 3), xb = x;
@@ -1836,10 +1900,11 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
     // scratch: coset evaluations of every polynomial + the evaluation/coefficient column of Q
     std::vector<void*> ev(nbase + next, nullptr);
     void *d_terms = nullptr, *d_q = nullptr;
-    for (unsigned c = 0; c < nbase; c++) MSCHK(ms_alloc(ctx, n * 8, &ev[c]));
-    for (unsigned c = 0; c < next; c++) MSCHK(ms_alloc(ctx, n * 24, &ev[nbase + c]));
-    MSCHK(ms_alloc(ctx, std::max<size_t>(1, nterms) * sizeof(msdeep::Term), &d_terms));
-    MSCHK(ms_alloc(ctx, n * PW * 8, &d_q));
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    for (unsigned c = 0; c < nbase; c++) MSCHK(pooled.alloc(n * 8, &ev[c]));
+    for (unsigned c = 0; c < next; c++) MSCHK(pooled.alloc(n * 24, &ev[nbase + c]));
+    MSCHK(pooled.alloc(std::max<size_t>(1, nterms) * sizeof(msdeep::Term), &d_terms));
+    MSCHK(pooled.alloc(n * PW * 8, &d_q));
     std::vector<msdeep::Term> terms(nterms);
     for (unsigned t = 0; t < nterms; t++) {
         memset(&terms[t], 0, sizeof(msdeep::Term));
@@ -1887,8 +1952,6 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
         }
         HIPCHK(hipGetLastError());
     }
-    for (void* p : ev) ms_free(ctx, p);            // back to the pool; stream order keeps the kernels above safe
-    ms_free(ctx, d_terms); ms_free(ctx, d_q);
     return MS_OK;
 }
 
@@ -1899,7 +1962,8 @@ extern "C" int ms_sha256_pow_grind(ms_ctx* ctx, const void* h_seed32, unsigned b
     if (!ctx || !h_seed32 || !nonce) return fail(MS_ERR_INVALID, "ms_sha256_pow_grind: null argument");
     if (bits > 64) return fail(MS_ERR_INVALID, "proof-of-work bits must be <= 64");
     void* d_found = nullptr;
-    MSCHK(ms_alloc(ctx, 8, &d_found));
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    MSCHK(pooled.alloc(8, &d_found));
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     mssha::PowParams P;
@@ -1919,13 +1983,134 @@ extern "C" int ms_sha256_pow_grind(ms_ctx* ctx, const void* h_seed32, unsigned b
         if (hipMemcpyAsync(&found, d_found, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail(MS_ERR_HIP, "pow: readback"); break; }
         if (found != none) break;
     }
-    // d_found goes back to the pool (cannot call ms_free here: it takes the same mutex)
-    {
-        auto it = ctx->live.find(d_found);
-        if (it != ctx->live.end()) { ctx->pool.insert({it->second, d_found}); ctx->pool_bytes += it->second; ctx->live.erase(it); }
-    }
     if (rc != MS_OK) return rc;
     if (found == none) return fail(MS_ERR_INVALID, "no nonce below %llu has %u leading zero bits", (unsigned long long)max_nonce, bits);
     *nonce = found;
     return MS_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// multi-GPU exchange over RCCL.  librccl is loaded on first use: a single-GPU user never
+// touches it, and a host that already carries an RCCL (torch does) gets that same copy by soname.
+// ---------------------------------------------------------------------------------------
+#ifndef MS_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return MS_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!h) return fail(MS_ERR_UNSUPPORTED, "librccl.so.1 not found: %s", dlerror());
+    RcclApi a;
+    a.lib = h;
+#define MS_SYM(field, name) do { *(void**)(&a.field) = dlsym(h, name); if (!a.field) return fail(MS_ERR_UNSUPPORTED, "librccl: missing symbol %s", name); } while (0)
+    MS_SYM(GetUniqueId, "ncclGetUniqueId"); MS_SYM(CommInitRank, "ncclCommInitRank"); MS_SYM(CommDestroy, "ncclCommDestroy");
+    MS_SYM(Send, "ncclSend"); MS_SYM(Recv, "ncclRecv"); MS_SYM(AllGather, "ncclAllGather");
+    MS_SYM(GroupStart, "ncclGroupStart"); MS_SYM(GroupEnd, "ncclGroupEnd"); MS_SYM(GetErrorString, "ncclGetErrorString");
+#undef MS_SYM
+    g_rccl = a;
+    return MS_OK;
+}
+}  // namespace
+#define NCCLCHK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail(MS_ERR_HIP, "%s: %s", #call, g_rccl.GetErrorString(r_)); } while (0)
+
+extern "C" int ms_comm_unique_id(void* h_id128) {
+    if (!h_id128) return fail(MS_ERR_INVALID, "ms_comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == MS_COMM_ID_BYTES, "RCCL unique id size");
+    MSCHK(rccl_load());
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(h_id128, &id, sizeof id);
+    return MS_OK;
+}
+extern "C" int ms_comm_init(ms_ctx* ctx, int nranks, int rank, const void* h_id128) {
+    if (!ctx || !h_id128) return fail(MS_ERR_INVALID, "ms_comm_init: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks & (nranks - 1))) return fail(MS_ERR_INVALID, "ms_comm_init: rank %d of %d (a power of two)", rank, nranks);
+    MSCHK(rccl_load());
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->comm) return fail(MS_ERR_INVALID, "ms_comm_init: this context already has a communicator");
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, h_id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&comm, nranks, id, rank));
+    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_size = nranks;
+    return MS_OK;
+}
+extern "C" int ms_comm_destroy(ms_ctx* ctx) {
+    if (!ctx || !ctx->comm) return MS_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_size = 1;
+    return MS_OK;
+}
+extern "C" int ms_comm_rank(ms_ctx* ctx, int* rank, int* nranks) {
+    if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    if (rank) *rank = ctx->comm_rank;
+    if (nranks) *nranks = ctx->comm_size;
+    return MS_OK;
+}
+extern "C" int ms_cols_to_rows_alltoall(ms_ctx* ctx, int field, size_t nrows, const void* const* d_my_cols, unsigned my_ncols,
+                                        unsigned total_cols, void* const* d_shard_cols) {
+    if (!ctx || (my_ncols && !d_my_cols) || (total_cols && !d_shard_cols)) return fail(MS_ERR_INVALID, "ms_cols_to_rows_alltoall: null argument");
+    if (!ctx->comm) return fail(MS_ERR_INVALID, "ms_cols_to_rows_alltoall: no communicator (ms_comm_init)");
+    const size_t fb = ms_field_bytes(field);
+    if (!fb) return fail(MS_ERR_UNSUPPORTED, "unknown field %d", field);
+    const unsigned G = (unsigned)ctx->comm_size, me = (unsigned)ctx->comm_rank;
+    if (nrows % G) return fail(MS_ERR_INVALID, "%zu rows do not split over %u ranks", nrows, G);
+    const unsigned mine = total_cols > me ? (total_cols - me + G - 1) / G : 0;       // columns c = me, me + G, ...
+    if (my_ncols != mine) return fail(MS_ERR_INVALID, "rank %u of %u owns %u of %u columns, %u given", me, G, mine, total_cols, my_ncols);
+    for (unsigned j = 0; j < my_ncols; j++) if (!d_my_cols[j]) return fail(MS_ERR_INVALID, "null column %u", j);
+    for (unsigned c = 0; c < total_cols; c++) if (!d_shard_cols[c]) return fail(MS_ERR_INVALID, "null shard column %u", c);
+    const size_t blk = nrows / G * fb;                                                // bytes of one rank's rows of one column
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    ProfScope ps(ctx, "cols_to_rows_alltoall", (double)blk * total_cols * 2.0);
+    NCCLCHK(g_rccl.GroupStart());
+    for (unsigned peer = 0; peer < G; peer++) {
+        if (peer == me) continue;
+        for (unsigned j = 0; j < my_ncols; j++)                                       // my columns, the peer's rows
+            NCCLCHK(g_rccl.Send((const char*)d_my_cols[j] + (size_t)peer * blk, blk, ncclUint8, (int)peer, comm, ctx->stream));
+        for (unsigned c = peer; c < total_cols; c += G)                               // the peer's columns, my rows
+            NCCLCHK(g_rccl.Recv(d_shard_cols[c], blk, ncclUint8, (int)peer, comm, ctx->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    for (unsigned j = 0; j < my_ncols; j++)                                           // my own block never leaves the device
+        HIPCHK(hipMemcpyAsync(d_shard_cols[me + (size_t)j * G], (const char*)d_my_cols[j] + (size_t)me * blk, blk, hipMemcpyDeviceToDevice, ctx->stream));
+    return MS_OK;
+}
+extern "C" int ms_allgather_digests(ms_ctx* ctx, const void* d_my_digest32, void* d_all_digests) {
+    if (!ctx || !d_my_digest32 || !d_all_digests) return fail(MS_ERR_INVALID, "ms_allgather_digests: null argument");
+    if (!ctx->comm) return fail(MS_ERR_INVALID, "ms_allgather_digests: no communicator (ms_comm_init)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    ProfScope ps(ctx, "allgather_digests", 32.0 * ctx->comm_size);
+    NCCLCHK(g_rccl.AllGather(d_my_digest32, d_all_digests, 32, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));
+    return MS_OK;
+}
+#else   // the execution-model simulator of tests/emu has no RCCL: the exchange is exercised there through the mirror's test hook
+extern "C" int ms_comm_unique_id(void*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
+extern "C" int ms_comm_init(ms_ctx*, int, int, const void*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
+extern "C" int ms_comm_destroy(ms_ctx*) { return MS_OK; }
+extern "C" int ms_comm_rank(ms_ctx* ctx, int* rank, int* nranks) { if (rank) *rank = 0; if (nranks) *nranks = 1; (void)ctx; return MS_OK; }
+extern "C" int ms_cols_to_rows_alltoall(ms_ctx*, int, size_t, const void* const*, unsigned, unsigned, void* const*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
+extern "C" int ms_allgather_digests(ms_ctx*, const void*, void*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
+#endif

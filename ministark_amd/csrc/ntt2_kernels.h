@@ -112,7 +112,7 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, b
 
 // ---- middle / last pass, radix 256 ---------------------------------------------------------------------
 // grid = (n V / 16384, columns); rows at stride sw = 2^log_s V words (>= 64), tile = 64 consecutive words.
-// SCALE (last pass): 0 none, 1 the constant in sc4, 2 c * hinv^k by table walk (inverse coset transform).
+// SCALE (last pass): 0 none, 1 the constant in sc4 (n^-1 of an inverse transform on the subgroup).
 template <bool INV, bool LAST, int SCALE>
 __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
@@ -170,7 +170,6 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
             uint64_t val;
             if constexpr (!LAST) val = glimb::mul_fold<true>(v[d], w4_at(P.twu4, U * 256 + k));
             else if constexpr (SCALE == 1) val = glimb::mul_fold<true>(v[d], w4_at(P.sc4, 0));
-            else if constexpr (SCALE == 2) val = gld::mmul(glimb::to_weak(v[d]), aux_pow(P, pos / P.V));
             else val = glimb::to_canon(v[d]);
             dst[pos] = val;
             if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);

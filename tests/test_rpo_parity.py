@@ -68,3 +68,76 @@ def test_identical_rows_identical_digests_hip():       # gpu/tests/rpo.rs:62-92 
     d = h.finish().to_numpy().reshape(n, 4)
     assert (d == d[0]).all()
     assert _canon(d[0]) == pyrpo.hash_row([1] * 8)
+
+
+# ---- external known-answer vectors (tests/golden/rpo256_miden_kat.json) -----------------------------
+def _kat():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rpo256_miden_kat.json")))
+
+
+def test_oracle_matches_external_kat():
+    """Pins the oracle (restated from hash_shaders.h.metal) to vectors that do not come from the reference tree."""
+    k = _kat()
+    assert pyrpo.RC0[:12] == k["ark1_first_row"] and pyrpo.RC1[:12] == k["ark2_first_row"]
+    assert pyrpo.MDS_ROW == k["mds_first_row"]
+    for v in k["hash_elements"]:
+        assert pyrpo.hash_row(v["input"]) == v["digest"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_device_matches_external_kat(kind):
+    pl = backends.planner(kind)
+    for v in _kat()["hash_elements"]:
+        cols = [np.array([GL.to_mont(x)] * 4, dtype=np.uint64) for x in v["input"]]    # 4 identical rows
+        h = GpuRpo256ColumnMajor(4, len(cols) % 8 != 0, pl)
+        for c in cols:
+            h.update(GpuVec.from_numpy(pl, c))
+        got = h.finish().to_numpy().reshape(4, 4)
+        for r in range(4):
+            assert _canon(got[r]) == v["digest"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("field_name", ["fp", "fq3"])
+def test_matrix_merkle_tree_over_rpo(kind, field_name):
+    """MerkleTree.from_matrix(matrix, hash="rpo256") (f2): leaves, every node, the root and a batched opening
+    against the oracle; Fq3 columns absorb c0, c1, c2 in serialisation order."""
+    from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3, Matrix, MerkleTree
+    pl = backends.planner(kind)
+    field, V = (GOLDILOCKS_FP, 1) if field_name == "fp" else (GOLDILOCKS_FQ3, 3)
+    n, ncols = (256, 5) if kind == "hip" else (16, 3)
+    cols = [cref.random_elements(n * V, 900 + c) for c in range(ncols)]
+    m = Matrix.from_numpy(pl, cols, field)
+    tree = MerkleTree.from_matrix(m, hash="rpo256")
+    want_leaves = []
+    for r in range(n):
+        row = []
+        for c in cols:
+            row += [GL.from_mont(int(x)) for x in c[r * V:(r + 1) * V]]
+        want_leaves.append(pyrpo.hash_row(row))
+    want_nodes = pyrpo.merkle_nodes(want_leaves)
+    got_leaves = tree.leaves.to_numpy().view(np.uint64).reshape(n, 4)
+    got_nodes = tree.nodes.to_numpy().view(np.uint64).reshape(n, 4)
+    assert [_canon(g) for g in got_leaves] == want_leaves
+    assert [_canon(g) for g in got_nodes[1:]] == want_nodes[1:]
+    assert _canon(np.frombuffer(tree.root(), dtype=np.uint64)) == want_nodes[1]
+    view = tree.prove([3, 4, n - 1])
+    assert view["height"] == n.bit_length() - 1 and len(view["initial_leaves"]) == 3
+    assert _canon(np.frombuffer(view["initial_leaves"][0], dtype=np.uint64)) == want_leaves[3]
+    with pytest.raises(ValueError):
+        MerkleTree.from_matrix(m, hash="md5")
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fri_layer_commitment_over_rpo(kind):
+    from ministark_amd import GOLDILOCKS_FQ3, MerkleTree
+    pl = backends.planner(kind)
+    n, ff = (512, 8) if kind == "hip" else (32, 4)
+    ev = cref.random_elements(n * 3, 31)
+    tree = MerkleTree.from_fri_layer(GpuVec.from_numpy(pl, ev, GOLDILOCKS_FQ3), ff, hash="rpo256")
+    rows = n // ff
+    want_leaves = [pyrpo.hash_row([GL.from_mont(int(x)) for x in ev[r * ff * 3:(r + 1) * ff * 3]]) for r in range(rows)]
+    want_nodes = pyrpo.merkle_nodes(want_leaves)
+    assert _canon(np.frombuffer(tree.root(), dtype=np.uint64)) == want_nodes[1]
