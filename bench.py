@@ -20,6 +20,19 @@ Extra objects on the JSON line:
                  rocprofv3 PMC passes when bench is run with --traffic-json, else null.
   cpu_baseline : oracle/c (C/OpenMP restatement of the reference CPU path, kind "port")
                  timed on this box's host cores on one 2^24 column, same data.
+  lde_commit   : configs[2] (C3): 2^20 rows x 32 columns, blow-up 8, fused LDE + SHA-256 row hashing + Merkle tree,
+                 with its own roofline (LDE kernels against HBM; algorithmic bytes n s + beta n s per column,
+                 SURVEY.md 8(d)) and cpu_baseline (oracle/c on the same matrix).                       [N = 1 only]
+  prove        : the second half of BASELINE's metric, "end-to-end prove time": every data-parallel phase of
+                 default_prove on configs[4]'s shape (2^22 rows x 8 columns, ProofOptions::new(32, 4, 8, 8, 64)),
+                 device-resident, fixed challenges in place of the channel (ministark_amd/pipeline.py); phases,
+                 per-kernel time, and the oracle chain timed on a bounded sample (2^18 rows).           [N = 1 only]
+  sharded_lde_commit : configs[4]'s multi-GPU step for any N (also N = 1, where RCCL runs with one rank): a
+                 2^22-row x 32-column trace, blow-up 4, columns sharded over the ranks -> LDE (no communication) ->
+                 ms_cols_to_rows_alltoall -> row hashing + subtree -> ms_allgather_digests -> top levels.  The total
+                 work is fixed ("strong"): the driver's N = 1, 2, 4, 8 runs give the scaling curve of the north
+                 star's "column-sharded LDE"; `lde_ms` is the phase its >= 6x target refers to.
+  --mode lde-commit runs only that last measurement and prints it as the line's `value` (GB/s algorithmic).
 """
 import argparse
 import json
@@ -36,6 +49,169 @@ LOG_N = 24
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def sharded_lde_commit(pl, comm, steps, warmup, log_rows=22, total_cols=32, log_blowup=2, barrier=lambda: None):
+    """configs[4]: column-sharded LDE + row-sharded commitment through the C ABI (ministark_amd/distributed.py).
+    Fixed total work; returns the dict for the JSON line (times are max over ranks where `reduce_max` is given)."""
+    import numpy as np
+    from ministark_amd import GOLDILOCKS_FP, GpuVec, Matrix, MerkleTree
+    from ministark_amd.distributed import owned_columns
+    rank, world = comm.rank, comm.world
+    n = 1 << log_rows
+    N = n << log_blowup
+    mine = owned_columns(total_cols, rank, world)
+    rng = np.random.default_rng(0xC5 + rank)
+    P = (1 << 64) - (1 << 32) + 1
+    trace = Matrix([GpuVec.from_numpy(pl, rng.integers(0, P, size=n, dtype=np.uint64)) for _ in mine])
+    t_lde = t_x = t_c = 0.0
+    root = None
+    for it in range(warmup + steps):
+        barrier()
+        t0 = time.perf_counter()
+        lde = trace.lde(1 << log_blowup, 7, True).columns
+        pl.sync()
+        t1 = time.perf_counter()
+        shard = comm.cols_to_rows(lde, total_cols)
+        pl.sync()
+        barrier()
+        t2 = time.perf_counter()
+        tree = MerkleTree.from_matrix(Matrix(shard))
+        if world > 1:
+            roots = comm.allgather_digests(tree.nodes.ptr + 32)
+            root = MerkleTree(pl, roots, world).root()
+        else:
+            root = tree.root()
+        pl.sync()
+        t3 = time.perf_counter()
+        if it >= warmup:
+            t_lde += t1 - t0; t_x += t2 - t1; t_c += t3 - t2
+        del lde, shard, tree
+    k = max(steps, 1)
+    lde_bytes = float(total_cols) * (n * 8 + N * 8)                       # n s + beta n s per column (SURVEY.md 8(d))
+    return {"workload": f"2^{log_rows} rows x {total_cols} columns, blow-up {1 << log_blowup}, SHA-256 commitment; columns c mod N on rank c, rows r N/G.. after the exchange",
+            "scaling": "strong", "n_gpus": world, "columns_this_rank": len(mine),
+            "lde_ms": t_lde / k * 1e3, "exchange_ms": t_x / k * 1e3, "commit_ms": t_c / k * 1e3,
+            "lde_algorithmic_bytes": lde_bytes, "exchange_bytes_sent_per_rank": float(len(mine)) * N * 8 * (world - 1) / world,
+            "root": root.hex() if root else None}
+
+
+class _stdout_to_stderr:
+    """RCCL prints a version banner on the C stdout at communicator creation (flushed at exit when stdout is a file):
+    the contract is ONE JSON line on stdout, so file descriptor 1 points at stderr while RCCL is in use."""
+
+    def __enter__(self):
+        import ctypes
+        self.libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def _profiled(pl, fn, reps):
+    """-> (wall seconds per call, {kernel: microseconds per call}) with hipEvents around every launch."""
+    fn(); pl.sync()                                            # plans, pool, specialised kernels
+    pl.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    pl.sync()
+    wall = (time.perf_counter() - t0) / reps
+    prof = pl.profile_read()
+    pl.profile(False)
+    return wall, {k: round(v["total_us"] / reps, 1) for k, v in sorted(prof.items())}
+
+
+def bench_lde_commit(pl, with_cpu):
+    """configs[2] (C3): 2^20 rows x 32 columns, blow-up 8, coset NTT + Merkle commit on one GPU."""
+    import numpy as np
+    from ministark_amd import GOLDILOCKS_FP, Matrix, MerkleTree
+    log_n, log_b, ncols = 20, 3, 32
+    n, N = 1 << log_n, 1 << (log_n + log_b)
+    rng = np.random.default_rng(3)
+    P = (1 << 64) - (1 << 32) + 1
+    host = [rng.integers(0, P, size=n, dtype=np.uint64) for _ in range(ncols)]
+    trace = Matrix.from_numpy(pl, host, GOLDILOCKS_FP)
+    state = {}
+
+    def run():
+        state.clear()
+        lde = trace.lde(1 << log_b, 7, True)
+        state["root"] = MerkleTree.from_matrix(lde).root()
+    wall, k = _profiled(pl, run, 3)
+    lde_us = sum(v for name, v in k.items() if name.startswith("ntt"))
+    lde_bytes = float(ncols) * (n * 8 + N * 8)
+    hash_bytes = float(N) * ncols * 8 + 32.0 * N + 96.0 * N
+    out = {"workload": "configs[2]: 2^20 rows x 32 columns (Fp), blow-up 8: interpolate + coset LDE (bit-reversed) + SHA-256 rows + Merkle tree",
+           "wall_ms": round(wall * 1e3, 3), "kernel_us": k, "lde_kernel_ms": round(lde_us / 1e3, 3),
+           "roofline": {"bound": "hbm", "kernel": "LDE passes (ntt_pass*)", "algorithmic_bytes": lde_bytes,
+                        "achieved": round(lde_bytes / (lde_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(lde_bytes / (lde_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+           "commit": {"bound": "integer ALU (SHA-256)", "algorithmic_bytes": hash_bytes,
+                      "compressions_per_s": round((N * (ncols * 8 // 64 + 1) + 2 * N) / (sum(v for nm, v in k.items() if nm.startswith("sha256")) * 1e-6), 0)},
+           "root": state["root"].hex()}
+    if with_cpu:
+        from oracle import cref
+        t0 = time.perf_counter()
+        cols = [cref.lde(c, log_n, log_b, 1, 7, True) for c in host]
+        t1 = time.perf_counter()
+        root = cref.sha256_merkle(cref.sha256_rows(cols, 1))[1].tobytes()
+        t2 = time.perf_counter()
+        out["cpu_baseline"] = {"value": round((t2 - t0) * 1e3, 1), "unit": "ms", "cores": cref.num_threads(), "kind": "port",
+                               "lde_ms": round((t1 - t0) * 1e3, 1), "commit_ms": round((t2 - t1) * 1e3, 1), "root_matches": root == state["root"],
+                               "sample": "the whole configs[2] matrix once, oracle/c (C/OpenMP restatement, not the reference binary)"}
+    return out
+
+
+def bench_prove(pl, with_cpu):
+    """configs[4] on one GPU = BASELINE's "end-to-end prove time": ministark_amd/pipeline.py, 2^22 rows x 8 columns."""
+    import numpy as np
+    from ministark_amd import GOLDILOCKS_FP, Matrix, pipeline
+    log_t, blowup, folding, ncols = 22, 4, 8, 8
+    n_t = 1 << log_t
+    rng = np.random.default_rng(5)
+    P = (1 << 64) - (1 << 32) + 1
+    trace = Matrix.from_numpy(pl, [rng.integers(0, P, size=n_t, dtype=np.uint64) for _ in range(ncols)], GOLDILOCKS_FP)
+    comp, nch = pipeline.fib_constraints(n_t, ncols)
+    draws = pipeline.Draws(0xC5, ncols, nch, blowup, 32, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64))
+    res = {}
+
+    def run():
+        res.clear()
+        res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8))
+    wall, k = _profiled(pl, run, 2)
+    n_lde = n_t * blowup
+    # algorithmic bytes per SURVEY.md 8(d): LDEs n s + beta n s per column, in-place transforms 2 n s, row hashing n cols s + 32 n,
+    # trees 96 n, constraint evaluation sum of columns + result, FRI layers n s + n s / ff
+    alg = (ncols * (n_t * 8 + n_lde * 8) + (n_lde * ncols * 8 + 128 * n_lde) + (ncols + 1) * n_lde * 8 + 2 * n_lde * 8
+           + blowup * (n_t * 8 + n_lde * 8) + (n_lde * blowup * 8 + 128 * n_lde) + (ncols + blowup + 1) * n_t * 8 + (n_t * 8 + n_lde * 8)
+           + sum((n_lde >> (3 * i)) * 8 * (1 + 1 / 8) + 128 * (n_lde >> (3 * i + 3)) for i in range(len(draws.fri_alphas))))
+    kernel_ms = sum(k.values()) / 1e3
+    out = {"workload": "configs[4] on one GPU: 2^22 rows x 8 columns (Fp, Fq = Fp), ProofOptions::new(32, 4, 8, 8, 64): every data-parallel phase of default_prove, fixed challenges in place of the channel",
+           "prove_ms": round(wall * 1e3, 3), "kernel_ms": round(kernel_ms, 3), "phases_ms": res["phases_ms"], "kernel_us": k,
+           "roofline": {"bound": "hbm (NTT / evaluation / FRI) + integer ALU (SHA-256)", "algorithmic_bytes": float(alg),
+                        "achieved": round(alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+           "base_root": res["base_root"].hex(), "nonce": res["nonce"]}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import cref
+        from tests.test_pipeline_parity import _c5_oracle_chain
+        lt = 18                                                    # bounded sample: the same chain on 2^18 rows (1/16 of the work)
+        cols = [cref.random_elements(1 << lt, 77 + c) for c in range(ncols)]
+        comp_s, nch_s = pipeline.fib_constraints(1 << lt, ncols)
+        draws_s = pipeline.Draws(0xC5, ncols, nch_s, blowup, 32, (1 << lt) * blowup, pipeline.fri_num_layers((1 << lt) * blowup, blowup, folding, 64))
+        t0 = time.perf_counter()
+        _c5_oracle_chain(cols, lt, blowup, folding, draws_s, comp_s)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(dt * 1e3, 1), "unit": "ms", "cores": cref.num_threads(), "kind": "port",
+                               "sample": f"the same chain on 2^{lt} rows x {ncols} columns (1/16 of the rows), oracle/c + numpy glue; not extrapolated"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,7 +221,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed transforms before the warm-up steps (clock ramp)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
+    ap.add_argument("--mode", choices=["ntt", "lde-commit"], default="ntt", help="lde-commit: only the column-sharded LDE + commitment (any N)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the lde_commit / prove / sharded objects")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -60,10 +238,51 @@ def main():
         dist = dist_mod
 
     from ministark_amd import GOLDILOCKS_FP, GpuFft, GpuVec, Planner, Radix2EvaluationDomain
+    from ministark_amd.distributed import RcclComm
 
     log_n = args.log_n
     n = 1 << log_n
     pl = Planner(local_rank)
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def dist_barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_sharded():
+        with _stdout_to_stderr():
+            comm = RcclComm.from_torch_distributed(pl) if dist is not None else RcclComm(pl, 0, 1, RcclComm.unique_id(pl.lib))
+            try:
+                r = sharded_lde_commit(pl, comm, max(2, min(args.steps, 5)), 1, barrier=dist_barrier)
+            finally:
+                comm.close()
+        for key in ("lde_ms", "exchange_ms", "commit_ms"):
+            r[key] = round(reduce_max(r[key]), 3)
+        r["total_ms"] = round(r["lde_ms"] + r["exchange_ms"] + r["commit_ms"], 3)
+        r["lde_GBps"] = round(r["lde_algorithmic_bytes"] / (r["lde_ms"] * 1e-3) / 1e9, 1)
+        r["lde_hbm_frac_of_all_gpus"] = round(r["lde_GBps"] / (HBM_PEAK_GBS * world), 4)
+        return r
+
+    if args.mode == "lde-commit":
+        r = run_sharded()
+        if rank == 0:
+            print(json.dumps({"metric": "column-sharded LDE + commitment (configs[4]), algorithmic GB/s of the LDE phase", "value": r["lde_GBps"],
+                              "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["total_ms"],
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                              "config": {"workload": r["workload"], "parallelism": f"columns x{world}, rows x{world} after the exchange"},
+                              "sharded_lde_commit": r}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     rng = np.random.default_rng(0x6D696E69 + rank)
     P = (1 << 64) - (1 << 32) + 1
     host_cols = [rng.integers(0, P, size=n, dtype=np.uint64) for _ in range(args.cols)]
@@ -104,6 +323,9 @@ def main():
     prof = pl.profile_read()
     pl.profile(False)
 
+    sharded = None
+    if not args.no_extras:
+        sharded = run_sharded()                                  # every rank takes part
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -158,6 +380,13 @@ def main():
             variants[name + "_us_per_transform"] = round((time.perf_counter() - t1) / 5 / args.cols * 1e6, 2)
             plan.close()
         out["variants"] = variants
+    if sharded is not None:
+        out["sharded_lde_commit"] = sharded
+    if world == 1 and not args.no_extras:
+        for c in cols:
+            c.free()
+        out["lde_commit"] = bench_lde_commit(pl, not args.no_cpu_baseline)
+        out["prove"] = bench_prove(pl, not args.no_cpu_baseline)
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
         from oracle import cref
         x = host_cols[0].copy()

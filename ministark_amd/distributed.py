@@ -1,8 +1,7 @@
 """Multi-GPU commitment of a column-sharded trace; new work, the reference is
 single-device (one metal::Device, gpu/src/plan.rs:465-468).
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
-the CPU tests).  What the reference's prover does on one device (src/prover.rs:50-52):
+One process per GPU.  What the reference's prover does on one device (src/prover.rs:50-52):
 
     lde  = trace.interpolate(trace_domain).bit_reversed_evaluate(lde_domain)
     tree = MerkleTree::from_matrix(&lde)
@@ -12,108 +11,117 @@ shards as follows:
      {c : c mod G == g} and runs the fused LDE on them -- no communication;
   2. a Merkle leaf hashes one element of EVERY column of a row (src/merkle.rs:428-431), so one
      exchange step turns column shards into row shards: rank r receives rows
-     [r*N/G, (r+1)*N/G) of every column (point-to-point sends, every pair of GPUs talks directly,
-     so all xGMI links carry payload at once);
+     [r*N/G, (r+1)*N/G) of every column.  ms_cols_to_rows_alltoall sends the row blocks straight out
+     of the LDE columns as RCCL send/recv pairs in one group (every pair of GPUs talks directly, all
+     xGMI links carry payload at once);
   3. each rank hashes its rows and builds the Merkle subtree over them: its root is node G + r of
      the single-device tree (nodes[k] has children 2k, 2k+1, src/merkle.rs:145-147);
-  4. an all-gather of the G subtree roots (32 B each) and log2(G) more hash levels give every
+  4. ms_allgather_digests of the G subtree roots (32 B each) and log2(G) more hash levels give every
      rank the same root as `MerkleTree::from_matrix` on one device, byte for byte.
-torch is plumbing only (device buffers that RCCL can see, the process group); every transform and
-hash runs in libministark_hip.so.
+
+Everything on the data path is the C ABI (include/ministark_hip.h, "multi-GPU exchange"); this file
+only sequences the calls.  The communicator's 128-byte id reaches the ranks through whatever the
+host launcher offers -- `RcclComm.from_torch_distributed` uses the torch.distributed store, nothing
+else of torch is involved.
 """
 import ctypes
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
-from .api import FIELD_WORDS, GOLDILOCKS_FP, GL_GENERATOR, DeviceBytes, GpuVec, Matrix, MerkleTree, gl_to_mont
+from .api import FIELD_WORDS, GOLDILOCKS_FP, GL_GENERATOR, DeviceBytes, GpuVec, Matrix, MerkleTree, _ptr_array
+
+COMM_ID_BYTES = 128
 
 
 def owned_columns(total_cols, rank, world):
     return list(range(rank, total_cols, world))
 
 
-class _TensorVec(GpuVec):
-    """A GpuVec living inside a torch tensor (so that torch.distributed can move it)."""
+class RcclComm:
+    """The exchange steps of the sharded commitment on one rank: ms_comm_init / ms_cols_to_rows_alltoall /
+    ms_allgather_digests over RCCL.  `planner` must be this rank's own context (its own GPU)."""
 
-    def __init__(self, planner, tensor, field):
-        self.tensor = tensor
-        super().__init__(planner, tensor.numel() // FIELD_WORDS[field], field, ptr=tensor.data_ptr(), owner=False)
+    def __init__(self, planner, rank, world, unique_id):
+        if world < 1 or world & (world - 1):
+            raise ValueError("world size must be a power of two (Merkle subtrees)")
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("the communicator id is 128 bytes")
+        self.planner, self.rank, self.world = planner, rank, world
+        buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        planner.lib.check(planner.lib.ms_comm_init(planner.handle, world, rank, buf))
+
+    @staticmethod
+    def unique_id(lib):
+        """ncclGetUniqueId; called by ONE rank, the bytes go to the others over a host channel."""
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        lib.check(lib.ms_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, planner, group=None):
+        """Rank / world size / id exchange from an initialised torch.distributed process group (any backend)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id(planner.lib) if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(planner, rank, world, box[0])
+
+    def cols_to_rows(self, my_cols, total_cols):
+        """my_cols: this rank's columns of the whole domain (GpuVecs).  -> one GpuVec per column of the
+        matrix, holding this rank's rows."""
+        pl, L = self.planner, self.planner.lib
+        field = my_cols[0].field if my_cols else GOLDILOCKS_FP
+        nrows = len(my_cols[0]) if my_cols else 0
+        if nrows % self.world:
+            raise ValueError("rows do not split over the ranks")
+        shard = [GpuVec(pl, nrows // self.world, field) for _ in range(total_cols)]
+        L.check(L.ms_cols_to_rows_alltoall(pl.handle, field, nrows, _ptr_array(my_cols), len(my_cols), total_cols, _ptr_array(shard)))
+        return shard
+
+    def allgather_digests(self, my_digest_ptr):
+        out = DeviceBytes(self.planner, 32 * self.world)
+        L = self.planner.lib
+        L.check(L.ms_allgather_digests(self.planner.handle, my_digest_ptr, out.ptr))
+        return out
+
+    def close(self):
+        if self.planner is not None and self.planner.handle:
+            self.planner.lib.ms_comm_destroy(self.planner.handle)
+        self.planner = None
 
 
-def lde_commit_sharded(planner, local_cols, total_cols, log_n, log_blowup, offset=GL_GENERATOR, field=GOLDILOCKS_FP,
-                       group=None, device=None):
-    """local_cols: this rank's trace columns (numpy u64, Montgomery words), in the order of
-    owned_columns(total_cols, rank, world).  Returns (root_bytes, my_row_shard) where my_row_shard
-    is a list over ALL columns of GpuVecs holding this rank's rows of the bit-reversed LDE."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if world & (world - 1):
-        raise ValueError("world size must be a power of two (Merkle subtrees)")
-    V = FIELD_WORDS[field]
+def lde_commit_sharded(planner, comm, local_cols, total_cols, log_n, log_blowup, offset=GL_GENERATOR, field=GOLDILOCKS_FP,
+                       hash="sha256"):
+    """local_cols: this rank's trace columns (numpy u64 Montgomery words, or GpuVecs), in the order of
+    owned_columns(total_cols, rank, world).  `comm` provides rank, world, cols_to_rows and allgather_digests
+    (RcclComm on GPUs).  Returns (root_bytes, my_row_shard): my_row_shard is a list over ALL columns of
+    GpuVecs holding this rank's rows of the bit-reversed LDE."""
+    rank, world = comm.rank, comm.world
     N = 1 << (log_n + log_blowup)
     if N % world or N // world < 2:
         raise ValueError("LDE domain too small for this many ranks")
-    rows = N // world
     mine = owned_columns(total_cols, rank, world)
-    assert len(local_cols) == len(mine)
-    dev = device if device is not None else torch.device("cpu")
-    i64 = torch.int64                                      # torch has no u64 arithmetic; raw 8-byte words
+    if len(local_cols) != len(mine):
+        raise ValueError(f"rank {rank} of {world} owns {len(mine)} of {total_cols} columns, {len(local_cols)} given")
+    V = FIELD_WORDS[field]
 
-    # 1. local fused LDE, bit-reversed, into one tensor [n_local, N*V]
-    lde = torch.empty((max(len(mine), 1), N * V), dtype=i64, device=dev)
-    if mine:
-        m = Matrix([GpuVec.from_numpy(planner, c, field) for c in local_cols])
-        outs = [_TensorVec(planner, lde[j], field) for j in range(len(mine))]
-        off = ctypes.c_uint64(gl_to_mont(offset))
-        L = planner.lib
-        VP = ctypes.c_void_p
-        L.check(L.ms_lde(planner.handle, field, log_n, log_blowup, ctypes.byref(off),
-                         (VP * len(mine))(*[c.ptr for c in m.columns]), (VP * len(mine))(*[o.ptr for o in outs]), len(mine), 1))
-        planner.sync()
+    # 1. local fused LDE (interpolate + bit-reversed coset evaluation), no communication
+    vecs = [c if isinstance(c, GpuVec) else GpuVec.from_numpy(planner, np.asarray(c, dtype=np.uint64), field) for c in local_cols]
+    for v in vecs:
+        if len(v) != (1 << log_n) or v.words != (1 << log_n) * V:
+            raise ValueError("column of the wrong length or field")
+    lde = Matrix(vecs).lde(1 << log_blowup, offset, True).columns if vecs else []
 
     # 2. column shards -> row shards
-    shard = torch.empty((total_cols, rows * V), dtype=i64, device=dev)
-    ops, keep = [], []
-    for peer in range(world):
-        theirs = owned_columns(total_cols, peer, world)
-        if peer == rank:
-            for j, c in enumerate(mine):
-                shard[c].copy_(lde[j, rank * rows * V:(rank + 1) * rows * V])
-            continue
-        if mine:
-            snd = lde[: len(mine), peer * rows * V:(peer + 1) * rows * V].contiguous()
-            keep.append(snd)
-            ops.append(dist.P2POp(dist.isend, snd, peer, group))
-        if theirs:
-            rcv = torch.empty((len(theirs), rows * V), dtype=i64, device=dev)
-            keep.append((rcv, theirs))
-            ops.append(dist.P2POp(dist.irecv, rcv, peer, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    for item in keep:
-        if isinstance(item, tuple):
-            rcv, theirs = item
-            for j, c in enumerate(theirs):
-                shard[c].copy_(rcv[j])
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)
+    shard = comm.cols_to_rows(lde, total_cols) if total_cols else []
 
     # 3. hash my rows, build my subtree
-    cols = [_TensorVec(planner, shard[c], field) for c in range(total_cols)]
-    tree = MerkleTree.from_matrix(Matrix(cols))
-    my_root = np.frombuffer(tree.root(), dtype=np.uint8).copy()
-
-    # 4. all-gather the subtree roots, finish the top log2(G) levels (same kernels)
+    tree = MerkleTree.from_matrix(Matrix(shard), hash)
     if world == 1:
-        return tree.root(), cols
-    roots = torch.empty((world, 32), dtype=torch.uint8, device=dev)
-    mine_t = torch.from_numpy(my_root).to(dev)
-    dist.all_gather_into_tensor(roots.view(-1), mine_t, group=group) if dev.type == "cuda" else \
-        dist.all_gather(list(roots.unbind(0)), mine_t, group=group)
-    top_leaves = DeviceBytes(planner, world * 32)
-    host_roots = roots.cpu().numpy().copy()
-    planner.lib.check(planner.lib.ms_upload(planner.handle, top_leaves.ptr, host_roots.ctypes.data, world * 32))
-    top = MerkleTree(planner, top_leaves, world)
-    return top.root(), cols
+        return tree.root(), shard
+
+    # 4. all-gather the subtree roots (nodes[1] of every rank), finish the top log2(G) levels with the same kernels
+    roots = comm.allgather_digests(tree.nodes.ptr + 32)
+    top = MerkleTree(planner, roots, world, hash)
+    return top.root(), shard

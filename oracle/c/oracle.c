@@ -444,3 +444,255 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ======================================================================================================
+ * Constraint evaluation: restatement of eval_cpu::eval (src/eval_cpu.rs:33-150).
+ *
+ * The reference walks the expression DAG once per CHUNK of 512 consecutive LDE points (eval_cpu.rs:44-52,
+ * `chunks_mut(CHUNK_SIZE)` under rayon), every node producing an array of 512 values; a division is
+ * x * batch_inverse(y) over the chunk (eval_cpu.rs:280-294, ark_ff::batch_inversion: zeros stay zero); a
+ * node is Fp iff all its operands are Fp, else Fq (eval_cpu.rs:306-428); Trace(col, off) reads row
+ * (i + lde_step * off) mod n (eval_cpu.rs:115-134); the result is returned as Fq (into_fq_array, :262-275).
+ *
+ * The DAG arrives flattened in topological order (children first): node k = (kind, a, b)
+ *   0 X            value offset * w^i
+ *   1 CONST        a = word offset into consts[] (Montgomery words), b = 1 if Fq
+ *   2 CHALLENGE    a = index   (Fq when fq_words = 3, Fp when fq_words = 1 / the 252-bit field)
+ *   3 HINT         a = index
+ *   4 TRACE        a = column (base columns first, then extension columns), b = offset (int32)
+ *   5 PERIODIC     a = table index: periodic[a] holds periodic_len[a] Fp values, value = table[i mod len]
+ *   6 NEG a        7 ADD a b      8 MUL a b      9 DIV a b      10 POW a, exponent b
+ * mode 0: Goldilocks, Fq = Fq3 (fq_words 3) or Fq = Fp (fq_words 1); mode 1: the 252-bit field (4 words, Fq = Fp).
+ * ====================================================================================================== */
+#define EV_CHUNK 512
+
+/* ---- the 252-bit StarkWare prime, Montgomery R = 2^256 (felt_u256.h.metal:101-203), 4 LE limbs ---- */
+static const uint64_t F252_P[4] = {1ULL, 0ULL, 0ULL, 0x0800000000000011ULL};
+static const uint64_t F252_NPRIME = 0xFFFFFFFFFFFFFFFFULL;          /* -p^-1 mod 2^64 (p = 1 mod 2^64) */
+typedef struct { uint64_t l[4]; } f252;
+static inline int f252_geq_p(const uint64_t* a) {
+    for (int i = 3; i >= 0; i--) { if (a[i] > F252_P[i]) return 1; if (a[i] < F252_P[i]) return 0; }
+    return 1;
+}
+static inline f252 f252_add(f252 a, f252 b) {
+    f252 r; u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    if (c || f252_geq_p(r.l)) { u128 bw = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)r.l[i] - F252_P[i] - bw; r.l[i] = (uint64_t)d; bw = (d >> 64) & 1; } }
+    return r;
+}
+static inline f252 f252_sub(f252 a, f252 b) {
+    f252 r; u128 bw = 0;
+    for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - b.l[i] - bw; r.l[i] = (uint64_t)d; bw = (d >> 64) & 1; }
+    if (bw) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + F252_P[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+    return r;
+}
+/* CIOS Montgomery product (the textbook form arkworks' MontBackend computes) */
+static f252 f252_mul(f252 a, f252 b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * F252_NPRIME;
+        c = (u128)m * F252_P[0] + t[0]; c >>= 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * F252_P[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    f252 r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || f252_geq_p(r.l)) { u128 bw = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)r.l[i] - F252_P[i] - bw; r.l[i] = (uint64_t)d; bw = (d >> 64) & 1; } }
+    return r;
+}
+static const f252 F252_ONE = {{0xFFFFFFFFFFFFFFE1ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x07FFFFFFFFFFFDF0ULL}};   /* R mod p (felt_u256.h.metal:101) */
+static f252 f252_pow(f252 a, const uint64_t* e, int elimbs) {
+    f252 r = F252_ONE;
+    for (int i = elimbs - 1; i >= 0; i--)
+        for (int b = 63; b >= 0; b--) { r = f252_mul(r, r); if ((e[i] >> b) & 1) r = f252_mul(r, a); }
+    return r;
+}
+static f252 f252_inv(f252 a) {
+    const uint64_t ee[4] = {0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x0800000000000010ULL};   /* p - 2 */
+    int zero = !(a.l[0] | a.l[1] | a.l[2] | a.l[3]);
+    if (zero) return a;
+    return f252_pow(a, ee, 4);
+}
+void oracle_f252_mul(const uint64_t* a, const uint64_t* b, uint64_t* out) { f252 x, y; memcpy(x.l, a, 32); memcpy(y.l, b, 32); x = f252_mul(x, y); memcpy(out, x.l, 32); }
+void oracle_f252_inv(const uint64_t* a, uint64_t* out) { f252 x; memcpy(x.l, a, 32); x = f252_inv(x); memcpy(out, x.l, 32); }
+
+typedef struct { int kind; int64_t a, b; } ev_node;
+
+/* one value slot of a chunk: up to 4 words per point; `w` = words per point of this node (1, 3 or 4) */
+static void ev_batch_inverse(uint64_t* v, unsigned w, size_t cnt, int mode) {
+    /* ark_ff::batch_inversion: prefix products of the non-zero entries, one inversion, walk back; zeros stay zero */
+    uint64_t* pre = (uint64_t*)malloc(cnt * w * 8);
+    if (mode == 1) {
+        f252 acc = F252_ONE;
+        for (size_t i = 0; i < cnt; i++) { f252 x; memcpy(x.l, v + 4 * i, 32); memcpy(pre + 4 * i, acc.l, 32); if (x.l[0] | x.l[1] | x.l[2] | x.l[3]) acc = f252_mul(acc, x); }
+        acc = f252_inv(acc);
+        for (size_t i = cnt; i-- > 0;) {
+            f252 x, p; memcpy(x.l, v + 4 * i, 32); memcpy(p.l, pre + 4 * i, 32);
+            if (!(x.l[0] | x.l[1] | x.l[2] | x.l[3])) continue;
+            f252 inv = f252_mul(acc, p); acc = f252_mul(acc, x); memcpy(v + 4 * i, inv.l, 32);
+        }
+    } else if (w == 1) {
+        uint64_t acc = GL_ONE;
+        for (size_t i = 0; i < cnt; i++) { pre[i] = acc; if (v[i]) acc = gl_mul(acc, v[i]); }
+        acc = gl_inv(acc);
+        for (size_t i = cnt; i-- > 0;) { if (!v[i]) continue; uint64_t inv = gl_mul(acc, pre[i]); acc = gl_mul(acc, v[i]); v[i] = inv; }
+    } else {
+        fq3 acc = {GL_ONE, 0, 0};
+        for (size_t i = 0; i < cnt; i++) { fq3 x = {v[3*i], v[3*i+1], v[3*i+2]}; pre[3*i] = acc.c0; pre[3*i+1] = acc.c1; pre[3*i+2] = acc.c2; if (x.c0 | x.c1 | x.c2) acc = fq3_mul(acc, x); }
+        acc = fq3_inv(acc);
+        for (size_t i = cnt; i-- > 0;) {
+            fq3 x = {v[3*i], v[3*i+1], v[3*i+2]}, p = {pre[3*i], pre[3*i+1], pre[3*i+2]};
+            if (!(x.c0 | x.c1 | x.c2)) continue;
+            fq3 inv = fq3_mul(acc, p); acc = fq3_mul(acc, x); v[3*i] = inv.c0; v[3*i+1] = inv.c1; v[3*i+2] = inv.c2;
+        }
+    }
+    free(pre);
+}
+
+/* returns 0 on success.  out: n * out_words words (out_words = fq_words in mode 0, 4 in mode 1). */
+int oracle_eval_expr(const int32_t* nodes3, unsigned nnodes, const uint64_t* consts, int mode, unsigned fq_words,
+                     unsigned log_n, unsigned lde_step, uint64_t offset_canon, const uint64_t* offset252,
+                     const uint64_t* const* base_cols, unsigned nbase, const uint64_t* const* ext_cols,
+                     const uint64_t* challenges, const uint64_t* hints,
+                     const uint64_t* const* periodic, const uint32_t* periodic_len, const uint64_t* w252, uint64_t* out) {
+    const size_t n = (size_t)1 << log_n;
+    const unsigned pw = mode == 1 ? 4 : 1, qw = mode == 1 ? 4 : fq_words;
+    /* static typing pass: words per point of every node */
+    unsigned* ww = (unsigned*)malloc(nnodes * sizeof(unsigned));
+    for (unsigned k = 0; k < nnodes; k++) {
+        const int kind = nodes3[3 * k]; const int64_t a = nodes3[3 * k + 1], b = nodes3[3 * k + 2];
+        switch (kind) {
+        case 0: ww[k] = pw; break;
+        case 1: ww[k] = b ? qw : pw; break;
+        case 2: case 3: ww[k] = qw; break;
+        case 4: ww[k] = ((unsigned)a < nbase) ? pw : qw; break;
+        case 5: ww[k] = pw; break;
+        case 6: case 10: ww[k] = ww[a]; break;
+        case 7: case 8: case 9: ww[k] = ww[a] > ww[b] ? ww[a] : ww[b]; break;
+        default: free(ww); return -1;
+        }
+    }
+    const uint64_t wroot = mode == 0 ? oracle_gl_root_of_unity(log_n) : 0;
+    const uint64_t hm = mode == 0 ? gl_to_mont(offset_canon % GL_P) : 0;
+    int err = 0;
+    const size_t nchunks = (n + EV_CHUNK - 1) / EV_CHUNK;
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (size_t ch = 0; ch < nchunks; ch++) {
+        const size_t i0 = ch * EV_CHUNK, cnt = (n - i0 < EV_CHUNK) ? n - i0 : EV_CHUNK;
+        uint64_t** val = (uint64_t**)calloc(nnodes, sizeof(uint64_t*));
+        for (unsigned k = 0; k < nnodes; k++) {
+            const int kind = nodes3[3 * k]; const int64_t a = nodes3[3 * k + 1], b = nodes3[3 * k + 2];
+            const unsigned w = ww[k];
+            uint64_t* v = (uint64_t*)malloc(cnt * w * 8);
+            val[k] = v;
+            if (kind == 0) {
+                if (mode == 0) { uint64_t x = gl_mul(hm, gl_pow(wroot, i0)); for (size_t i = 0; i < cnt; i++) { v[i] = x; x = gl_mul(x, wroot); } }
+                else {
+                    f252 wr, x, e; memcpy(wr.l, w252, 32); memcpy(x.l, offset252, 32);
+                    uint64_t ee[1] = {i0}; e = f252_pow(wr, ee, 1); x = f252_mul(x, e);
+                    for (size_t i = 0; i < cnt; i++) { memcpy(v + 4 * i, x.l, 32); x = f252_mul(x, wr); }
+                }
+            } else if (kind == 1) { for (size_t i = 0; i < cnt; i++) memcpy(v + w * i, consts + a, w * 8); }
+            else if (kind == 2) { for (size_t i = 0; i < cnt; i++) memcpy(v + w * i, challenges + (size_t)a * qw, w * 8); }
+            else if (kind == 3) { for (size_t i = 0; i < cnt; i++) memcpy(v + w * i, hints + (size_t)a * qw, w * 8); }
+            else if (kind == 4) {
+                const uint64_t* col = ((unsigned)a < nbase) ? base_cols[a] : ext_cols[a - nbase];
+                const int64_t shift = (int64_t)lde_step * b;
+                for (size_t i = 0; i < cnt; i++) {
+                    const size_t j = (size_t)(((int64_t)(i0 + i) + shift) % (int64_t)n + (int64_t)n) % n;
+                    memcpy(v + w * i, col + w * j, w * 8);
+                }
+            } else if (kind == 5) {
+                const uint64_t* t = periodic[a]; const size_t len = periodic_len[a];
+                for (size_t i = 0; i < cnt; i++) memcpy(v + w * i, t + w * ((i0 + i) % len), w * 8);
+            } else if (kind == 6) {
+                const uint64_t* x = val[a];
+                if (mode == 1) { for (size_t i = 0; i < cnt; i++) { f252 z = {{0,0,0,0}}, y; memcpy(y.l, x + 4 * i, 32); y = f252_sub(z, y); memcpy(v + 4 * i, y.l, 32); } }
+                else for (size_t i = 0; i < cnt * w; i++) v[i] = gl_neg(x[i]);
+            } else if (kind == 7 || kind == 8 || kind == 9) {
+                const unsigned wa = ww[a], wb = ww[b];
+                uint64_t* y = val[b];
+                uint64_t* yinv = NULL;
+                if (kind == 9) { yinv = (uint64_t*)malloc(cnt * wb * 8); memcpy(yinv, y, cnt * wb * 8); ev_batch_inverse(yinv, wb, cnt, mode); y = yinv; }
+                const uint64_t* x = val[a];
+                for (size_t i = 0; i < cnt; i++) {
+                    if (mode == 1) {
+                        f252 p, q; memcpy(p.l, x + 4 * i, 32); memcpy(q.l, y + 4 * i, 32);
+                        p = (kind == 7) ? f252_add(p, q) : f252_mul(p, q); memcpy(v + 4 * i, p.l, 32);
+                    } else if (w == 1) {
+                        v[i] = (kind == 7) ? gl_add(x[i], y[i]) : gl_mul(x[i], y[i]);
+                    } else {
+                        fq3 p = wa == 3 ? (fq3){x[3*i], x[3*i+1], x[3*i+2]} : (fq3){x[i], 0, 0};
+                        fq3 q = wb == 3 ? (fq3){y[3*i], y[3*i+1], y[3*i+2]} : (fq3){y[i], 0, 0};
+                        fq3 r;
+                        if (kind == 7) r = fq3_add(p, q);
+                        else if (wa == 3 && wb == 3) r = fq3_mul(p, q);
+                        else if (wa == 3) r = fq3_mul_fp(p, y[i]);
+                        else r = fq3_mul_fp(q, x[i]);
+                        v[3*i] = r.c0; v[3*i+1] = r.c1; v[3*i+2] = r.c2;
+                    }
+                }
+                if (yinv) free(yinv);
+            } else if (kind == 10) {
+                const uint64_t* x = val[a];
+                for (size_t i = 0; i < cnt; i++) {
+                    if (mode == 1) { f252 p; memcpy(p.l, x + 4 * i, 32); uint64_t ee[1] = {(uint64_t)b}; p = f252_pow(p, ee, 1); memcpy(v + 4 * i, p.l, 32); }
+                    else if (w == 1) v[i] = gl_pow(x[i], (uint64_t)b);
+                    else { fq3 p = {x[3*i], x[3*i+1], x[3*i+2]}; p = fq3_pow(p, (uint64_t)b); v[3*i] = p.c0; v[3*i+1] = p.c1; v[3*i+2] = p.c2; }
+                }
+            }
+        }
+        /* into_fq_array */
+        const unsigned wl = ww[nnodes - 1];
+        const uint64_t* r = val[nnodes - 1];
+        for (size_t i = 0; i < cnt; i++) {
+            uint64_t* o = out + (i0 + i) * qw;
+            if (wl == qw) memcpy(o, r + (size_t)qw * i, qw * 8);
+            else { o[0] = r[i]; for (unsigned t = 1; t < qw; t++) o[t] = 0; }
+        }
+        for (unsigned k = 0; k < nnodes; k++) free(val[k]);
+        free(val);
+    }
+    free(ww);
+    return err;
+}
+
+/* ======================================================================================================
+ * DEEP composition: horner_evaluate (src/utils.rs:124-133), divide_out_point(s)_into (src/utils.rs:151-175),
+ * DeepPolyComposer::into_deep_poly's sum and degree adjustment (src/composer.rs:100-188).  Coefficients are
+ * V-word elements (1 = Fp, 3 = Fq3), points / alphas are PW-word Fq elements (PW = 3, or 1 when Fq = Fp).
+ * ====================================================================================================== */
+static inline fq3 ld_q(const uint64_t* p, unsigned w) { fq3 r = {p[0], w == 3 ? p[1] : 0, w == 3 ? p[2] : 0}; return r; }
+void oracle_horner_eval(const uint64_t* coeffs, size_t n, unsigned V, const uint64_t* point, unsigned PW, uint64_t* out) {
+    if (PW == 1 && V == 1) { uint64_t acc = 0; for (size_t i = n; i-- > 0;) acc = gl_add(gl_mul(acc, point[0]), coeffs[i]); out[0] = acc; return; }
+    fq3 z = ld_q(point, PW), acc = {0, 0, 0};
+    for (size_t i = n; i-- > 0;) acc = fq3_add(fq3_mul(acc, z), ld_q(coeffs + (size_t)V * i, V));
+    out[0] = acc.c0; if (PW == 3) { out[1] = acc.c1; out[2] = acc.c2; }
+}
+/* acc[i] += sum_k cs[k] * (coefficient i of coeffs(X) / (X - zs[k]))   -- divide_out_points_into, accumulated */
+void oracle_divide_out_points_acc(const uint64_t* coeffs, size_t n, unsigned V, const uint64_t* zs, const uint64_t* cs, unsigned k,
+                                  unsigned PW, uint64_t* acc) {
+    fq3 rem[64], z[64], c[64];
+    if (k > 64) return;
+    for (unsigned t = 0; t < k; t++) { rem[t] = (fq3){0, 0, 0}; z[t] = ld_q(zs + (size_t)PW * t, PW); c[t] = ld_q(cs + (size_t)PW * t, PW); }
+    for (size_t i = n; i-- > 0;) {
+        const fq3 tmp = ld_q(coeffs + (size_t)V * i, V);
+        fq3 s = {0, 0, 0};
+        for (unsigned t = 0; t < k; t++) { s = fq3_add(s, fq3_mul(c[t], rem[t])); rem[t] = fq3_add(fq3_mul(z[t], rem[t]), tmp); }
+        uint64_t* o = acc + (size_t)PW * i;
+        o[0] = gl_add(o[0], s.c0); if (PW == 3) { o[1] = gl_add(o[1], s.c1); o[2] = gl_add(o[2], s.c2); }
+    }
+}
+/* out[i] = acc[i] * da + acc[i-1] * db  (composer.rs:172-187; db == 0 skips the shifted term) */
+void oracle_degree_adjust(const uint64_t* acc, size_t n, unsigned PW, const uint64_t* da, const uint64_t* db, uint64_t* out) {
+    const fq3 a = ld_q(da, PW), b = ld_q(db, PW);
+    fq3 last = {0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        const fq3 cur = ld_q(acc + (size_t)PW * i, PW);
+        fq3 r = fq3_add(fq3_mul(cur, a), fq3_mul(last, b));
+        last = cur;
+        out[(size_t)PW * i] = r.c0; if (PW == 3) { out[(size_t)PW * i + 1] = r.c1; out[(size_t)PW * i + 2] = r.c2; }
+    }
+}

@@ -15,8 +15,10 @@ from ministark_amd import _lib, api  # noqa: E402
 _cache = {}
 
 
-def planner(kind):
-    if kind not in _cache:
+def planner(kind, device=0):
+    """One Planner per (backend, GPU): a rank of a multi-GPU test must run its kernels on ITS device."""
+    key = (kind, device)
+    if key not in _cache:
         if kind == "hip":
             lib = _lib.Lib()
         elif kind == "emu":
@@ -25,5 +27,5 @@ def planner(kind):
             lib = _lib.Lib(build_emu.build())
         else:
             raise ValueError(kind)
-        _cache[kind] = api.Planner(0, lib)
-    return _cache[kind]
+        _cache[key] = api.Planner(device, lib)
+    return _cache[key]

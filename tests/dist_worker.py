@@ -17,14 +17,21 @@ def main():
     from oracle import cref
     from tests import backends
     from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3
-    from ministark_amd.distributed import lde_commit_sharded, owned_columns
-    pl = backends.planner(kind)
+    from ministark_amd.distributed import RcclComm, lde_commit_sharded, owned_columns
+    if kind == "emu":
+        from tests.gloo_comm import GlooComm
+        pl = backends.planner("emu")
+        comm = GlooComm(pl)
+    else:                                               # one GPU per rank: the planner lives on LOCAL_RANK's device
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        pl = backends.planner("hip", local)
+        comm = RcclComm.from_torch_distributed(pl)
     results = []
     for field, V, total_cols, log_n, log_b in ((GOLDILOCKS_FP, 1, 5, 6, 2), (GOLDILOCKS_FQ3, 3, 3, 5, 3), (GOLDILOCKS_FP, 1, 1, 7, 1)):
         allc = [cref.random_elements((1 << log_n) * V, 1000 + c) for c in range(total_cols)]
         mine = [allc[c] for c in owned_columns(total_cols, rank, world)]
-        dev = torch.device("cpu") if kind == "emu" else torch.device("cuda", rank)
-        root, shard = lde_commit_sharded(pl, mine, total_cols, log_n, log_b, 7, field, device=dev)
+        root, shard = lde_commit_sharded(pl, comm, mine, total_cols, log_n, log_b, 7, field)
         results.append(root.hex())
     with open(outfile, "w") as f:
         f.write("\n".join(results))

@@ -4,7 +4,6 @@ import numpy as np
 import pytest
 
 from oracle import cref
-from oracle.pyref import evalexpr
 from oracle.pyref.fields import GL
 from tests import backends
 from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3, GpuVec, Matrix, MerkleTree
@@ -33,33 +32,16 @@ def test_c3_lde_2_20_x_32_blowup_8_and_commit():
     assert root == want_root
 
 
-def _sampled_eval(pl, expr, log_n, lde_step, base, ext, ch, fq_is_ext, npts=40):
+def _full_eval(pl, expr, log_n, lde_step, base, ext, ch, fq_is_ext):
+    """ALL 2^log_n outputs of the device evaluator against the C restatement of eval_cpu::eval
+    (oracle_eval_expr: 512-point chunks, batch inversion), Montgomery words, bit for bit."""
     n = 1 << log_n
     prog = E.compile_expr(expr, len(base), fq_is_ext)
-    out = E.eval(prog, pl, ch, ch[:1], lde_step, 7, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
+    got = E.eval(prog, pl, ch, ch[:1], lde_step, 7, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
                  [GpuVec.from_numpy(pl, c, FQ3) for c in ext]).to_numpy()
-    rng = np.random.default_rng(7)
-    pts = sorted(set([0, 1, n - 1] + [int(x) for x in rng.integers(0, n, size=npts)]))
-    canon = lambda col, V: _Lazy(col, V)
-    qc = (lambda r: tuple(GL.from_mont(int(x)) for x in r)) if fq_is_ext else (lambda r: GL.from_mont(int(r[0])))
-    want = evalexpr.eval_points(expr, pts, n, lde_step, 7, [canon(c, 1) for c in base], [canon(c, 3) for c in ext],
-                                [qc(r) for r in ch], [qc(r) for r in ch[:1]], fq_is_ext)
-    V = 3 if fq_is_ext else 1
-    for i, w in zip(pts, want):
-        got = tuple(GL.from_mont(int(x)) for x in out[V * i:V * i + V])
-        assert got == (w if fq_is_ext else (w,)), f"point {i}"
-
-
-class _Lazy:
-    """column view that converts out of Montgomery form on access (the oracle only touches a few rows)."""
-
-    def __init__(self, col, V):
-        self.col, self.V = col, V
-
-    def __getitem__(self, j):
-        if self.V == 1:
-            return GL.from_mont(int(self.col[j]))
-        return tuple(GL.from_mont(int(x)) for x in self.col[3 * j:3 * j + 3])
+    want = cref.eval_expr(expr, log_n, lde_step, 7, base, ext, ch, ch[:1], fq_is_ext)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} of {want.size} words differ, first at {bad[:4]}"
 
 
 @pytest.mark.gpu
@@ -78,14 +60,15 @@ def test_c4_fib_air_2_23():
         comp = term if comp is None else comp + term
     base = [cref.random_elements(1 << log_n, 100 + k) for k in range(8)]
     ch = cref.random_elements(16, 5).reshape(-1, 1)
-    _sampled_eval(pl, comp, log_n, lde_step, base, [], ch, False)
+    _full_eval(pl, comp, log_n, lde_step, base, [], ch, False)
+    _full_eval(pl, comp, log_n, 1, base, [], ch, False)        # lde_step = 1 is what src/prover.rs:103 passes for this AIR
 
 
 @pytest.mark.gpu
-def test_c4_mixed_17_fp_9_fq3_2_20():
-    # (ii): the brainfuck shape, 17 Fp + 9 Fq3 columns (examples/brainfuck/air.rs:26-27)
+def test_c4_mixed_17_fp_9_fq3_2_23():
+    # (ii): the brainfuck shape, 17 Fp + 9 Fq3 columns (examples/brainfuck/air.rs:26-27), at BASELINE's 2^23 points
     pl = backends.planner("hip")
-    log_n, lde_step = 20, 2
+    log_n, lde_step = 23, 2
     x = E.X()
     b = [lambda o=0, k=k: E.Trace(k, o) for k in range(17)]
     e = [lambda o=0, k=k: E.Trace(17 + k, o) for k in range(9)]
@@ -97,4 +80,31 @@ def test_c4_mixed_17_fp_9_fq3_2_20():
     base = [cref.random_elements(1 << log_n, 200 + k) for k in range(17)]
     ext = [cref.random_elements(3 << log_n, 300 + k) for k in range(9)]
     ch = cref.random_elements(12, 6).reshape(-1, 3)
-    _sampled_eval(pl, expr, log_n, lde_step, base, ext, ch, True, npts=24)
+    _full_eval(pl, expr, log_n, lde_step, base, ext, ch, True)
+
+
+@pytest.mark.gpu
+def test_c4_fib_air_on_the_256_bit_field_2_23():
+    # (iii): "256-bit Fq" = the reference's only 256-bit field, Fp252 with Fq = Fp (src/eval_gpu.rs:1054-1082), 8 columns
+    from ministark_amd import STARK252_FP
+    pl = backends.planner("hip")
+    log_n, lde_step = 23, 4
+    x = E.X()
+    c = [lambda o=0, k=k: E.Trace(k, o) for k in range(8)]
+    cons = [c[0](1) - (c[6]() + c[7]()), c[1](1) - (c[7]() + c[0](1))] + [c[k]() - (c[k - 2]() + c[k - 1]()) for k in range(2, 8)]
+    n_trace = 1 << (log_n - 2)
+    comp = None
+    for k, cn in enumerate(cons):
+        term = cn * (x - E.Constant(3)) / (x ** n_trace - 1) * (E.Challenge(2 * k) * x ** 3 + E.Challenge(2 * k + 1))
+        comp = term if comp is None else comp + term
+    rng = np.random.default_rng(252)
+    # uniformly random canonical residues below 2^251 (< p) as the stored Montgomery words
+    cols = [rng.integers(0, 1 << 63, size=4 << log_n, dtype=np.uint64) for _ in range(8)]
+    for col in cols:
+        col[3::4] >>= np.uint64(4)
+    ch = rng.integers(0, 1 << 59, size=(16, 4), dtype=np.uint64)
+    prog = E.compile_expr(comp, 8, False, STARK252_FP)
+    got = E.eval(prog, pl, ch, ch[:1], lde_step, 3, 1 << log_n, [GpuVec.from_numpy(pl, col, STARK252_FP) for col in cols]).to_numpy()
+    want = cref.eval_expr(comp, log_n, lde_step, 3, cols, [], ch, ch[:1], False, field="f252")
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} of {want.size} words differ, first at {bad[:4]}"

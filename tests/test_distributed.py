@@ -35,3 +35,40 @@ def test_sharded_commit_matches_single_device_gloo(tmp_path, world):
     want = _expected()
     for f in files:
         assert open(f).read().split("\n") == want
+
+
+@pytest.mark.gpu
+def test_rccl_entry_points_world1_hip():
+    """The RCCL leg on the single-GPU lease, through the C ABI without torch: ncclGetUniqueId / ncclCommInitRank,
+    the send/recv group (degenerate: the own block is a device copy) and ncclAllGather really execute."""
+    from tests import backends
+    from ministark_amd import GOLDILOCKS_FQ3, GpuVec, Matrix, MerkleTree
+    from ministark_amd.distributed import RcclComm, lde_commit_sharded
+    pl = backends.planner("hip")
+    comm = RcclComm(pl, 0, 1, RcclComm.unique_id(pl.lib))
+    try:
+        cols = [cref.random_elements((1 << 10) * 3, 70 + c) for c in range(3)]
+        vecs = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FQ3) for c in cols]
+        shard = comm.cols_to_rows(vecs, 3)
+        assert all(np.array_equal(s.to_numpy(), c) for s, c in zip(shard, cols))
+        tree = MerkleTree.from_matrix(Matrix(shard))
+        assert comm.allgather_digests(tree.nodes.ptr + 32).to_numpy().tobytes() == tree.root()
+        root, _ = lde_commit_sharded(pl, comm, cols, 3, 10, 3, 7, GOLDILOCKS_FQ3)
+        want = cref.sha256_merkle(cref.sha256_rows([cref.lde(c, 10, 3, 3, 7, True) for c in cols], 3))[1].tobytes()
+        assert root == want
+        with pytest.raises(Exception):
+            comm.cols_to_rows(vecs[:2], 3)          # a rank of a 1-rank world owns all 3 columns
+    finally:
+        comm.close()
+
+
+@pytest.mark.gpu
+def test_sharded_commit_world1_nccl_hip(tmp_path):
+    """The same worker the gloo tests run, with backend "nccl" (= RCCL) and the product library on GPU 0."""
+    port = str(29900 + (os.getpid() % 90))
+    f = str(tmp_path / "r0.txt")
+    env = dict(os.environ, LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "0", "1", port, "hip", f],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    assert open(f).read().split("\n") == _expected()

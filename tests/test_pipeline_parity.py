@@ -137,3 +137,103 @@ def test_prover_pipeline_c1_shape(kind):
                                  (q.composition_trace_proof, o_comp_leaves, o_comp_nodes)):
         assert proof == omerkle.prove(leaves, nodes, positions)
         assert omerkle.verify(nodes[1], proof, positions)
+
+
+# ---- the C5 shape (fib-like trace, ProofOptions::new(32, 4, 8, 8, 64)) against the C oracle, at size on the GPU ------------
+def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr):
+    """The same transcript on the CPU: oracle/c for every transform, hash, evaluation and the DEEP composition."""
+    import hashlib
+    from oracle import cref
+    log_b = blowup.bit_length() - 1
+    log_l = log_t + log_b
+    n_t, n_l = 1 << log_t, 1 << log_l
+    R = lambda v: np.array([cref.lib().oracle_gl_to_mont(int(v) % cref.GL_P)], dtype=np.uint64)
+    out = {}
+    polys = [cref.ntt(c.copy(), log_t, 1, True, 1) for c in cols]
+    lde_nat = [cref.lde(c, log_t, log_b, 1, 7, False) for c in cols]
+    lde_br = [cref.bit_reverse(c.copy(), log_l) for c in lde_nat]
+    out["base_root"] = cref.sha256_merkle(cref.sha256_rows(lde_br, 1))[1].tobytes()
+    ch = np.array([R(c)[0] for c in draws.challenges], dtype=np.uint64).reshape(-1, 1)
+    comp_nat = cref.eval_expr(comp_expr, log_l, blowup, 7, lde_nat, [], ch, ch[:1], False)
+    out["comp_evals_br"] = cref.bit_reverse(comp_nat.copy(), log_l)
+    comp_poly = cref.ntt(comp_nat.copy(), log_l, 1, True, 7)
+    comp_polys = [np.ascontiguousarray(comp_poly[c::blowup]) for c in range(blowup)]          # prover.rs:113-121
+    out["comp_polys"] = comp_polys
+
+    def evaluate_br(coeffs):                                                                 # bit_reversed_evaluate on the LDE coset
+        a = np.zeros(n_l, dtype=np.uint64)
+        a[:len(coeffs)] = coeffs
+        return cref.bit_reverse(cref.ntt(a, log_l, 1, False, 7), log_l)
+    comp_lde = [evaluate_br(p) for p in comp_polys]
+    out["composition_root"] = cref.sha256_merkle(cref.sha256_rows(comp_lde, 1))[1].tobytes()
+    # DEEP (composer.rs:43-188), Fq = Fp
+    g = GL.root_of_unity(n_t)
+    z = draws.z
+    pt = lambda off: (z * pow(g, off, GL.p)) % GL.p
+    z_n = pow(z, blowup, GL.p)
+    exec_ood = [cref.horner_eval(polys[c], 1, R(pt(o))) for c, o in draws.trace_args]
+    comp_ood = [cref.horner_eval(p, 1, R(z_n)) for p in comp_polys]
+    out["ood"] = ([GL.from_mont(int(v[0])) for v in exec_ood], [GL.from_mont(int(v[0])) for v in comp_ood])
+    terms = []
+    for c in range(len(polys)):
+        zs = [R(pt(o))[0] for (cc, o) in draws.trace_args if cc == c]
+        al = [R(a)[0] for (cc, o), a in zip(draws.trace_args, draws.deep.execution_trace) if cc == c]
+        terms.append((np.array(zs, dtype=np.uint64), np.array(al, dtype=np.uint64)))
+    for c in range(blowup):
+        terms.append((R(z_n), R(draws.deep.composition_trace[c])))
+    deep_poly = cref.deep_compose(polys + comp_polys, [1] * (len(polys) + blowup), terms, n_t, 1,
+                                  (R(draws.deep.degree[0]), R(draws.deep.degree[1])))
+    out["deep_poly"] = deep_poly
+    layer = evaluate_br(deep_poly)
+    out["fri_roots"], n = [], n_l
+    for alpha in draws.fri_alphas:
+        rows = [np.ascontiguousarray(layer[k::folding]) for k in range(folding)]              # rows of `folding` consecutive evaluations
+        out["fri_roots"].append(cref.sha256_merkle(cref.sha256_rows(rows, 1))[1].tobytes())
+        layer = cref.fri_fold(layer, n.bit_length() - 1, 1, folding, R(alpha), 1)
+        n //= folding
+    out["remainder"] = layer
+    seed = out["fri_roots"][-1]
+    nonce = 1
+    while int.from_bytes(hashlib.sha256(seed + nonce.to_bytes(8, "big")).digest()[:8], "big") >> (64 - 8):
+        nonce += 1
+    out["nonce"] = nonce
+    out["lde_br"], out["comp_lde"] = lde_br, comp_lde
+    return out
+
+
+def _run_c5(kind, log_t, seed):
+    from oracle import cref
+    from ministark_amd import pipeline
+    pl = backends.planner(kind)
+    blowup, folding, ncols = 4, 8, 8
+    n_t = 1 << log_t
+    cols = [cref.random_elements(n_t, seed + c) for c in range(ncols)]
+    comp, nch = pipeline.fib_constraints(n_t, ncols)
+    nlayers = pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64)
+    draws = pipeline.Draws(seed, ncols, nch, blowup, 32, n_t * blowup, nlayers)
+    got = pipeline.prove_phases(pl, Matrix.from_numpy(pl, cols, FP), comp, draws, blowup, folding, 64, 8, keep=True)
+    want = _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp)
+    assert got["base_root"] == want["base_root"]
+    assert np.array_equal(got["comp_evals"].to_numpy(), want["comp_evals_br"])
+    assert all(np.array_equal(g.to_numpy(), w) for g, w in zip(got["comp_polys"].columns, want["comp_polys"]))
+    assert got["composition_root"] == want["composition_root"]
+    assert ([int(v) for v in got["ood"][0]], [int(v) for v in got["ood"][1]]) == want["ood"]
+    assert np.array_equal(got["deep_poly"].to_numpy(), want["deep_poly"])
+    assert len(got["fri_roots"]) == nlayers and got["fri_roots"] == want["fri_roots"]
+    assert np.array_equal(got["remainder"].to_numpy(), want["remainder"])
+    assert got["nonce"] == want["nonce"]
+    q = got["queries"]
+    pos = draws.positions
+    assert np.array_equal(q.base_trace_values, np.stack([c[pos] for c in want["lde_br"]], axis=1))
+    assert np.array_equal(q.composition_trace_values, np.stack([c[pos] for c in want["comp_lde"]], axis=1))
+
+
+def test_prover_pipeline_c5_shape_emu():
+    _run_c5("emu", 7, 4242)
+
+
+@pytest.mark.gpu
+def test_prover_pipeline_c5_at_size_hip():
+    """BASELINE configs[4] on one GPU: 2^22 rows x 8 columns, blow-up 4 -- every commitment, evaluation, polynomial,
+    FRI layer root, the remainder, the nonce and the queried rows against the CPU chain."""
+    _run_c5("hip", 22, 0xC5)
