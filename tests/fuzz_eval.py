@@ -80,20 +80,23 @@ while time.time() - t0 < budget:
         if not np.array_equal(br, cref.bit_reverse(out, log_n, V3)):
             print(f"MISMATCH (bit-reversed layout) case {count} (seed {seed}): log_n={log_n} fq_is_ext={fq_is_ext} lde_step={lde_step} offset={offset}")
             sys.exit(1)
-    pts = sorted(set([0, 1, n - 1, n // 2] + [int(x) for x in rng.integers(0, n, size=6)]))
+    # every output against the C restatement of eval_cpu::eval (chunks of 512, batch inversion) ...
+    want_all = cref.eval_expr(expr, log_n, lde_step, offset, base, ext, ch, ch[:1], fq_is_ext)
+    if not np.array_equal(out, want_all):
+        bad = np.nonzero(out != want_all)[0]
+        print(f"MISMATCH case {count} (seed {seed}): log_n={log_n} fq_is_ext={fq_is_ext} lde_step={lde_step} offset={offset}: {bad.size} words differ, first at {bad[:4]}; {len(prog.instrs)} instructions")
+        sys.exit(1)
+    # ... and a few points against the independent per-point big-integer evaluator
+    pts = sorted(set([0, n - 1] + [int(x) for x in rng.integers(0, n, size=3)]))
     qc = (lambda r: tuple(GL.from_mont(int(x)) for x in r)) if fq_is_ext else (lambda r: GL.from_mont(int(r[0])))
-    cb = [canon(c, 1) for c in base] if log_n <= 13 else None
-    if cb is None:                              # large domain: convert only the rows the oracle will touch
-        need = sorted({(i + lde_step * o) % n for i in pts for o in range(-2, 3)})
-        cb = [{j: GL.from_mont(int(c[j])) for j in need} for c in base]
-        ce = [{j: tuple(GL.from_mont(int(x)) for x in c[3 * j:3 * j + 3]) for j in need} for c in ext]
-    else:
-        ce = [canon(c, 3) for c in ext]
+    need = sorted({(i + lde_step * o) % n for i in pts for o in range(-2, 3)})
+    cb = [{j: GL.from_mont(int(c[j])) for j in need} for c in base]
+    ce = [{j: tuple(GL.from_mont(int(x)) for x in c[3 * j:3 * j + 3]) for j in need} for c in ext]
     want = evalexpr.eval_points(expr, pts, n, lde_step, offset, cb, ce, [qc(r) for r in ch], [qc(r) for r in ch[:1]], fq_is_ext)
     for i, w in zip(pts, want):
         got = tuple(GL.from_mont(int(x)) for x in out[qw * i:qw * i + qw])
         if got != (w if fq_is_ext else (w,)):
-            print(f"MISMATCH case {count} (seed {seed}): log_n={log_n} fq_is_ext={fq_is_ext} lde_step={lde_step} offset={offset} point {i}; {len(prog.instrs)} instructions")
+            print(f"MISMATCH (python oracle) case {count} (seed {seed}): log_n={log_n} fq_is_ext={fq_is_ext} lde_step={lde_step} offset={offset} point {i}")
             sys.exit(1)
     count += 1
     jit += log_n >= 16

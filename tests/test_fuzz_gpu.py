@@ -1,0 +1,36 @@
+"""The two randomised differential runs (tests/fuzz_parity.py: transforms, LDE, FRI, commitments, stages against the C
+oracle; tests/fuzz_eval.py: random constraint programs against the C and the Python evaluators) as GPU tests with
+fixed seeds and a fixed time budget.  Their output is appended to gpurun_out/r02_fuzz.log when that directory exists
+(the summary kept under profiles/ is copied from there)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUDGET = os.environ.get("MS_FUZZ_SECONDS", "20")
+
+
+def _run(script, seed):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), BUDGET, str(seed)], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = p.stdout.decode()
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "r02_fuzz.log"), "a") as f:
+            f.write(f"$ python tests/{script} {BUDGET} {seed}\n{text.strip().splitlines()[-1] if text.strip() else '(no output)'}\n")
+    assert p.returncode == 0, text[-3000:]
+    assert "ok:" in text, text[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_parity_hip(seed):
+    _run("fuzz_parity.py", seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_eval_hip(seed):
+    _run("fuzz_eval.py", seed)
