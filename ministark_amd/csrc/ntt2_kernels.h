@@ -159,20 +159,38 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
         #pragma unroll
         for (int b = 0; b < 16; b++) y[b] = xch[(b * 8 + w) * TW + lane];
         const unsigned ap = w + 8 * r;                        // a'
+        glimb::W4 wn[4];                                      // twiddles one group ahead of their use (scalar loads from a 2 MiB table)
+        if constexpr (!LAST) {
+            #pragma unroll
+            for (int j = 0; j < 4; j++) wn[j] = w4_at(P.twu4, U * 256 + ap + 16 * j);
+        }
         glimb::L4 v[16];
         #pragma unroll
         for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(y[b]);
         glimb::dft<16, INV>(v);
         size_t pos = base + (size_t)ap * sw;
         #pragma unroll
-        for (int d = 0; d < 16; d++, pos += step) {
-            const unsigned k = ap + 16 * d;
-            uint64_t val;
-            if constexpr (!LAST) val = glimb::mul_fold<true>(v[d], w4_at(P.twu4, U * 256 + k));
-            else if constexpr (SCALE == 1) val = glimb::mul_fold<true>(v[d], w4_at(P.sc4, 0));
-            else val = glimb::to_canon(v[d]);
-            dst[pos] = val;
-            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < 4; g++) {
+            glimb::W4 wc[4];
+            if constexpr (!LAST) {
+                #pragma unroll
+                for (int j = 0; j < 4; j++) wc[j] = wn[j];
+                if (g < 3) {
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) wn[j] = w4_at(P.twu4, U * 256 + ap + 16 * (4 * (g + 1) + j));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            #pragma unroll
+            for (int j = 0; j < 4; j++, pos += step) {
+                const int d = 4 * g + j;
+                uint64_t val;
+                if constexpr (!LAST) val = glimb::mul_fold<true>(v[d], wc[j]);
+                else if constexpr (SCALE == 1) val = glimb::mul_fold<true>(v[d], w4_at(P.sc4, 0));
+                else val = glimb::to_canon(v[d]);
+                dst[pos] = val;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
