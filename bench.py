@@ -347,9 +347,12 @@ def main():
                         "bytes_moved_per_column": alg_bytes_col,
                         "GBps": round(alg_bytes_col / us_col / 1e3, 1)})
     achieved = alg_bytes_col / us_per_transform / 1e3 if us_per_transform else 0.0
-    traffic = None
+    # HBM bytes per transform are not measured in this run: they come from the separate rocprofv3 PMC passes
+    # (FETCH_SIZE / WRITE_SIZE, scripts/collect_profiles.sh) whose summary is the file named in `traffic_source`
+    traffic, traffic_source = None, None
     if args.traffic_json and os.path.exists(args.traffic_json):
         traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_transform")
+        traffic_source = os.path.relpath(args.traffic_json, ROOT)
     out = {
         "metric": "2^24-point Goldilocks NTT algorithmic bandwidth", "value": round(value, 2), "unit": "GB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -359,7 +362,7 @@ def main():
         "field_ops_per_s": round(field_ops * total_cols * args.steps / elapsed, 1),
         "us_per_transform": round(elapsed / args.steps / args.cols * 1e6, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_transform": alg_bytes_col,
                      "us_per_transform_events": round(us_per_transform, 2), "kernels": kernels},
     }

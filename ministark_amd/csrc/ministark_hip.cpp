@@ -461,6 +461,10 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         p->npass = 1 + extra;
         p->lr[0] = 8;
         for (int i = 0; i < extra; i++) p->lr[1 + i] = rest / extra + ((unsigned)i < rest % extra ? 1 : 0);
+        // three passes: prefer (8, 8, rest - 8) to an even split whenever the last radix is still >= 16 -- two of the
+        // three passes are then limb-form radix-256 passes (ntt2_kernels.h), e.g. 2^20 = 256 * 256 * 16 instead of 256 * 64 * 64
+        static const bool even_split = getenv("MS_NTT_EVEN_SPLIT") != nullptr && atoi(getenv("MS_NTT_EVEN_SPLIT")) != 0;
+        if (!even_split && extra == 2 && rest >= 12 && rest <= 16) { p->lr[1] = 8; p->lr[2] = rest - 8; }
         unsigned acc = 0;
         for (int q = 0; q < p->npass; q++) { p->log_s[q] = acc; acc += p->lr[q]; }
         // digit fields.  pass 1 maps j' = (j2..jm) [jm least significant] to layout (jm..j2) [j2 least]

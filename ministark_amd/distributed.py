@@ -125,3 +125,26 @@ def lde_commit_sharded(planner, comm, local_cols, total_cols, log_n, log_blowup,
     roots = comm.allgather_digests(tree.nodes.ptr + 32)
     top = MerkleTree(planner, roots, world, hash)
     return top.root(), shard
+
+
+def eval_constraints_sharded(prog, planner, comm, challenges, hints, lde_step, domain_offset, n, base_shard, ext_shard=()):
+    """Constraint evaluation on this rank's ROW shard of the committed (bit-reversed) LDE, without communication,
+    for lde_step a multiple of the number of ranks G (blow-up >= G, e.g. 8 GPUs and blow-up 8 or 16).
+
+    After ms_cols_to_rows_alltoall rank r holds positions R = r N/G + R' of every column, i.e. the natural indices
+    i = bitrev(R) = G i' + rho with rho = bitrev_g(r), i' = bitrev(R').  Those are the points x_i = (h w^rho) (w^G)^i' -- a
+    coset of the subgroup of order N/G -- and a rotation by lde_step * offset rows moves i' by (lde_step / G) * offset
+    and leaves rho alone: the shard is a self-contained evaluation problem of size N/G with offset h w^rho and step
+    lde_step / G (`eval_cpu::eval`'s arguments, src/eval_cpu.rs:33-42), on which the ordinary evaluator runs.
+    Concatenating the ranks' results in rank order gives the bit-reversed evaluation vector of the whole domain.
+    (When G does not divide lde_step a rotated row lives on another rank; that exchange is not implemented.)"""
+    from . import expr as E
+    from .api import GL_P, Radix2EvaluationDomain
+    G, r = comm.world, comm.rank
+    if lde_step % G:
+        raise ValueError(f"row-sharded evaluation needs lde_step ({lde_step}) to be a multiple of the number of ranks ({G})")
+    g = G.bit_length() - 1
+    rho = int(format(r, f"0{g}b")[::-1], 2) if g else 0
+    w = Radix2EvaluationDomain(n).group_gen
+    shard_offset = (domain_offset * pow(w, rho, GL_P)) % GL_P
+    return E.eval(prog, planner, challenges, hints, lde_step // G, shard_offset, n // G, list(base_shard), list(ext_shard), bit_reversed=True)

@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 PROF = os.path.join(ROOT, "profiles")
 
 
@@ -27,7 +27,9 @@ def counters(path, per_column=False):
     (grid = 4096 tiles x 256 threads per 2^24 column)."""
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        cols = max(1.0, float(r["Grid_Size"]) / (4096 * 256)) if per_column and "msntt" in r["Kernel_Name"] else 1.0
+        # work-items per 2^24 column: 4096 tiles x 256 threads (ntt_kernels.h), 1024 tiles x 512 threads (ntt2_kernels.h)
+        per_col = (1024 * 512) if "msntt2" in r["Kernel_Name"] else (4096 * 256)
+        cols = max(1.0, float(r["Grid_Size"]) / per_col) if per_column and "msntt" in r["Kernel_Name"] else 1.0
         out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]) / cols)
     return out
 
@@ -46,8 +48,12 @@ fetch, write = one("pmc_fetch/**/*counter_collection.csv"), one("pmc_write/**/*c
 if fetch and write:
     fc, wc = counters(fetch, True), counters(write, True)
     total = 0.0
+    # the three launches of ONE forward coset transform (bench.py's other variants -- subgroup, inverse -- run in the
+    # same process and must not be added in)
+    trio = ("ntt2_first_pass<false, true, 16>", "ntt2_mid_pass<false, false, 0>", "ntt2_mid_pass<false, true, 0>",
+            "ntt_first_pass<false, true, 16>", "ntt_mid_pass<16, false, false, 0, false>", "ntt_mid_pass<16, false, true, 0, false>")
     for k in fc:
-        if "msntt" not in k:
+        if "msntt" not in k or not any(t in k for t in trio):
             continue
         fb = 2 * 1024 * sum(fc[k]["FETCH_SIZE"]) / len(fc[k]["FETCH_SIZE"])      # per 2^24 column
         wb = 1024 * sum(wc[k]["WRITE_SIZE"]) / len(wc[k]["WRITE_SIZE"])
@@ -70,7 +76,9 @@ for name, dst in (("pmc_sq", "ntt_sq_counters"), ("pmc_sha", "sha256_sq_counters
             if "msntt" in k or "mssha" in k:
                 for cn, vals in sorted(c[k].items()):
                     w.writerow([k, len(vals), cn, sum(vals) / len(vals)])
-for src, dst in (("bench.json", f"{tag}_bench_ntt_2_24.json"), ("bench_configs.jsonl", f"{tag}_bench_configs.jsonl"), ("bench_commit.json", f"{tag}_bench_commit.json")):
+for src, dst in (("ubench3.txt", f"{tag}_ubench3_field_primitives.txt"), ("ntt_pass_bench.txt", f"{tag}_ntt_pass_bench.txt"),
+                 ("bench_lde_commit_n1.json", f"{tag}_bench_lde_commit_n1.json"),
+                 ("bench.json", f"{tag}_bench_ntt_2_24.json"), ("bench_configs.jsonl", f"{tag}_bench_configs.jsonl"), ("bench_commit.json", f"{tag}_bench_commit.json")):
     p = os.path.join(RAW, src)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(PROF, dst))

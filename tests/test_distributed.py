@@ -32,7 +32,7 @@ def test_sharded_commit_matches_single_device_gloo(tmp_path, world):
     for p in procs:
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out.decode()[-2000:]
-    want = _expected()
+    want = _expected() + ["eval_ok"]                 # + the row-sharded constraint evaluation check of the worker
     for f in files:
         assert open(f).read().split("\n") == want
 
@@ -71,4 +71,4 @@ def test_sharded_commit_world1_nccl_hip(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "0", "1", port, "hip", f],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
-    assert open(f).read().split("\n") == _expected()
+    assert open(f).read().split("\n") == _expected() + ["eval_ok"]
