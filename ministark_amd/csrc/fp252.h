@@ -66,7 +66,12 @@ MS_HD E sub(const E& a, const E& b) { return add(a, neg(b)); }      // felt_u256
 // the same lazy columns (p = 1 mod 2^28: m = -c_k mod 2^28, and m*p = m + 17m*2^192 + m*2^251 is two more
 // multiply-adds into columns k+6 and k+8); eight rounds of 28 bits and one of 32 make R = 2^256 exactly, so
 // the value is the arkworks Montgomery product bit for bit.  ~250 instructions.
-MS_HD E mul(const E& a, const E& b) {
+//
+// mul_t<false> leaves out the final conditional subtraction (result < 2p) and accepts a LAZY first operand: any a < 2^256
+// with a canonical b keeps every column below 2^62 (a's top digit has 32 bits, so one term per column is < 2^60), and
+// (a b + m p) / R < a p / R + p < 2p because p / R < 1/31.9.  The NTT tiles (fp252_ntt_kernels.h) run on such values.
+template <bool CANON>
+MS_HD E mul_t(const E& a, const E& b) {
     constexpr uint32_t M = (1u << 28) - 1;
     uint32_t x[9], y[9];
     {
@@ -119,7 +124,47 @@ MS_HD E mul(const E& a, const E& b) {
     r.l[1] = (uint64_t)(d[11] >> 12) | ((uint64_t)d[12] << 16) | ((uint64_t)d[13] << 44);
     r.l[2] = (uint64_t)(d[13] >> 20) | ((uint64_t)d[14] << 8) | ((uint64_t)d[15] << 36);
     r.l[3] = (uint64_t)d[16] | ((uint64_t)d[17] << 28) | ((uint64_t)d[18] << 56);
+    if constexpr (!CANON) return r;
     return geq_p(r) ? sub_p(r) : r;
+}
+MS_HD E mul(const E& a, const E& b) { return mul_t<true>(a, b); }
+
+// ---- lazy forms for long butterfly chains: residues kept below 2^256 ~ 31.9 p, no conditional subtractions -------------
+MS_HD E add_lazy(const E& a, const E& b) {          // a + b, the caller guarantees a + b < 2^256
+    E r;
+    u128 s = (u128)a.l[0] + b.l[0]; r.l[0] = (uint64_t)s;
+    s = (u128)a.l[1] + b.l[1] + (uint64_t)(s >> 64); r.l[1] = (uint64_t)s;
+    s = (u128)a.l[2] + b.l[2] + (uint64_t)(s >> 64); r.l[2] = (uint64_t)s;
+    r.l[3] = a.l[3] + b.l[3] + (uint64_t)(s >> 64);
+    return r;
+}
+template <int K>
+MS_HD E kp_minus(const E& t) {                       // K p - t for t < K p  (K = 2, 4: K p = K + K P3 2^192)
+    E r;
+    u128 d = (u128)(uint64_t)K - t.l[0]; r.l[0] = (uint64_t)d; uint64_t b = (uint64_t)(d >> 64) & 1;
+    d = (u128)0 - t.l[1] - b; r.l[1] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1;
+    d = (u128)0 - t.l[2] - b; r.l[2] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1;
+    r.l[3] = (uint64_t)K * P3 - t.l[3] - b;
+    return r;
+}
+// canonical residue of any x < 2^256: q = floor(x / 2^251) is floor(x / p) or one more, so x - q p lies in [-p, p)
+MS_HD E reduce_lazy(const E& x) {
+    const uint64_t q = x.l[3] >> 59;
+    E r;
+    u128 d = (u128)x.l[0] - q; r.l[0] = (uint64_t)d; uint64_t b = (uint64_t)(d >> 64) & 1;
+    d = (u128)x.l[1] - b; r.l[1] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1;
+    d = (u128)x.l[2] - b; r.l[2] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1;
+    d = (u128)x.l[3] - q * P3 - b; r.l[3] = (uint64_t)d;
+    const bool negative = ((uint64_t)(d >> 64) & 1) != 0;
+    if (negative) {
+        E s;
+        u128 a = (u128)r.l[0] + P0; s.l[0] = (uint64_t)a;
+        a = (u128)r.l[1] + (uint64_t)(a >> 64); s.l[1] = (uint64_t)a;
+        a = (u128)r.l[2] + (uint64_t)(a >> 64); s.l[2] = (uint64_t)a;
+        s.l[3] = r.l[3] + P3 + (uint64_t)(a >> 64);
+        return s;
+    }
+    return r;
 }
 
 MS_HD E to_mont(const E& canon) { return mul(canon, E{{R2_L[0], R2_L[1], R2_L[2], R2_L[3]}}); }

@@ -27,6 +27,7 @@
 #include "eval_jit.h"
 #endif
 #include "fp252_kernels.h"
+#include "fp252_ntt_kernels.h"
 #include "rpo_kernels.h"
 #include "deep_kernels.h"
 
@@ -319,6 +320,11 @@ struct ms_ntt_plan {
     uint64_t *d252_tw_lo = nullptr, *d252_tw_hi = nullptr, *d252_sc_lo = nullptr, *d252_sc_hi = nullptr;
     int scale_in252 = 0, scale_out252 = 0;
     uint64_t off252[4] = {0, 0, 0, 0};  // the coset offset itself: cache lookups compare it, not just its hash
+    // tiled passes of fp252_ntt_kernels.h (2^11 <= n <= 2^30): number of passes (0 = radix-2 sequence only), digit sizes,
+    // per-pass tables w_R^e (e < R/2)
+    int np252 = 0;
+    unsigned lr252[3] = {0, 0, 0};
+    uint64_t* d252_twr[3] = {nullptr, nullptr, nullptr};
 };
 
 static void powers(std::vector<uint64_t>& out, size_t count, uint64_t base, uint64_t first = 1) {
@@ -389,9 +395,21 @@ static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* 
         powers252(t, std::max<size_t>(n >> p->lo_bits, 1), f252::pow_u64(g, (uint64_t)1 << p->lo_bits), f252::one()); o_shi = append(t);
         if (inverse) p->scale_out252 = 1; else p->scale_in252 = 1;
     }
+    size_t o_twr[3] = {0, 0, 0};
+    if (log_n >= (unsigned)ms252::TILE_LOG && log_n <= 30) {
+        p->np252 = log_n <= 20 ? 2 : 3;
+        // MS_NTT252_PASSES=3 forces the three-pass split from 2^17 points on (tests: the emulator cannot hold 2^21 points)
+        if (const char* e = getenv("MS_NTT252_PASSES")) if (atoi(e) == 3 && log_n >= 17) p->np252 = 3;
+        for (int q = 0; q < p->np252; q++) p->lr252[q] = log_n / p->np252 + ((unsigned)q < log_n % p->np252 ? 1 : 0);
+        for (int q = 0; q < p->np252; q++) {
+            powers252(t, (size_t)1 << (p->lr252[q] - 1), f252::pow_u64(w, (uint64_t)n >> p->lr252[q]), f252::one());
+            o_twr[q] = append(t);
+        }
+    }
     if (hipMalloc(&p->d_tables, host.size() * 8) != hipSuccess) { delete p; return fail(MS_ERR_NOMEM, "Fp252 plan tables"); }
     if (hipMemcpy(p->d_tables, host.data(), host.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->d_tables); delete p; return fail(MS_ERR_HIP, "Fp252 table upload"); }
     p->d252_tw_lo = p->d_tables + o_lo; p->d252_tw_hi = p->d_tables + o_hi;
+    for (int q = 0; q < p->np252; q++) p->d252_twr[q] = p->d_tables + o_twr[q];
     if (scale) { p->d252_sc_lo = p->d_tables + o_slo; p->d252_sc_hi = p->d_tables + o_shi; }
     *out = p;
     return MS_OK;
@@ -606,7 +624,57 @@ static void launch_mid(bool inv, bool last, int scale, bool bitrev, dim3 grid, h
 static int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* const* src, void* const* dst, unsigned ncols);
 static unsigned stream_grid(size_t n);
 
+// Tiled passes (fp252_ntt_kernels.h).  log_zero_ext: the source holds only the first n >> log_zero_ext elements, the rest
+// of the domain is implicit zeros (needs 2^log_zero_ext <= R_0); bitrev_out: bit-reversed order, fused into the last pass.
+static int plan_run252_tiled(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned log_zero_ext, bool bitrev_out) {
+    ms_ctx* ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << p->log_n, col_bytes = n * 32;
+    const int np = p->np252;
+    if (log_zero_ext > p->lr252[0]) return fail(MS_ERR_INVALID, "internal: zero extension 2^%u beyond the first radix", log_zero_ext);
+    unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(msntt::MAXC, ctx->group_bytes / col_bytes));
+    group = std::min(group, ncols);
+    void* scratch = nullptr;
+    MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes, &scratch));
+    static const char* const names[3] = {"ntt252_pass1", "ntt252_pass2", "ntt252_pass3"};
+    if (getenv("MS_NTT_DEBUG"))
+        fprintf(stderr, "[ms_ntt] Fp252 log_n=%u tiled: %d passes, radices 2^%u 2^%u 2^%u, zero extension 2^%u, bitrev %d\n", p->log_n, np,
+                p->lr252[0], p->lr252[1], p->lr252[2], log_zero_ext, (int)bitrev_out);
+    for (unsigned c0 = 0; c0 < ncols; c0 += group) {
+        const unsigned nc = std::min(group, ncols - c0);
+        unsigned done = 0;                                        // log2 of R_0 .. R_(q-1)
+        for (int q = 0; q < np; q++) {
+            ms252::PassParams P;
+            memset(&P, 0, sizeof P);
+            const bool last = q == np - 1;
+            for (unsigned c = 0; c < nc; c++) {
+                uint64_t* scr = (uint64_t*)((char*)scratch + (size_t)c * col_bytes);
+                P.src[c] = q == 0 ? (const uint64_t*)src[c0 + c] : scr;
+                P.dst[c] = last ? (uint64_t*)dst[c0 + c] : scr;
+            }
+            P.twr = p->d252_twr[q]; P.tw_lo = p->d252_tw_lo; P.tw_hi = p->d252_tw_hi; P.sc_lo = p->d252_sc_lo; P.sc_hi = p->d252_sc_hi;
+            P.log_n = p->log_n; P.lo_bits = p->lo_bits;
+            P.log_r = p->lr252[q]; P.log_c = ms252::TILE_LOG - P.log_r;
+            P.log_s = p->log_n - done - P.log_r; P.log_tw = done;
+            P.valid_rows = (1u << p->lr252[0]) >> log_zero_ext;
+            P.log_r0 = p->lr252[0]; P.log_r1 = np == 3 ? p->lr252[1] : 0;
+            P.scale_in = p->scale_in252; P.scale_out = p->scale_out252; P.bitrev_out = bitrev_out ? 1 : 0;
+            const dim3 grid((unsigned)(n >> ms252::TILE_LOG), nc), block(ms252::NT2);
+            ProfScope ps(ctx, names[q], 2.0 * col_bytes * nc);
+            if (q == 0) hipLaunchKernelGGL((ms252::ntt252_strided_pass<ms252::NT2, true>), grid, block, 0, st, P);
+            else if (!last) hipLaunchKernelGGL((ms252::ntt252_strided_pass<ms252::NT2, false>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((ms252::ntt252_last_pass<ms252::NT2>), grid, block, 0, st, P);
+            done += P.log_r;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
 static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols) {
+    static const bool radix2_only = getenv("MS_NTT252_RADIX2") != nullptr && atoi(getenv("MS_NTT252_RADIX2")) != 0;   // A/B measurements
+    if (p->np252 && !radix2_only) return plan_run252_tiled(p, src, dst, ncols, 0, false);
     ms_ctx* ctx = p->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -642,7 +710,7 @@ static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst,
 // source only holds the first valid_rows/256 of the domain, the rest is implicit zeros.
 static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows, bool bitrev_out = false) {
     if (p->is252) {
-        if (valid_rows != 256 || bitrev_out) return fail(MS_ERR_UNSUPPORTED, "zero-extended input / fused bit reversal are not implemented for Fp252");
+        if (valid_rows != 256 || bitrev_out) return fail(MS_ERR_INVALID, "internal: Fp252 zero extension / fused bit reversal go through plan_run252_tiled");
         return plan_run252(p, src, dst, ncols);
     }
     if (bitrev_out && p->small) return fail(MS_ERR_INVALID, "internal: fused bit reversal needs the multi-pass path");
@@ -863,6 +931,10 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         MSCHK(plan252_cached(ctx, log_n, true, f252::one(), &inv));
         MSCHK(plan252_cached(ctx, log_N, false, h252, &fwd));
         MSCHK(plan_run252(inv, d_in, d_out, ncols));
+        // tiled passes: the coefficients are read straight from the head of the output column (zeros implicit), the
+        // bit reversal is part of the last pass
+        if (fwd->np252 && log_blowup <= fwd->lr252[0] && !getenv("MS_NTT252_RADIX2"))
+            return plan_run252_tiled(fwd, (const void* const*)d_out, d_out, ncols, log_blowup, bit_reversed != 0);
         const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
         if (N > n)
             for (unsigned c = 0; c < ncols; c++) HIPCHK(hipMemsetAsync((char*)d_out[c] + n * 32, 0, (N - n) * 32, ctx->stream));
@@ -926,6 +998,8 @@ extern "C" int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_
         if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
         MSCHK(ctx_plan(ctx, V, log_domain, false, h, &fwd));
     }
+    if (V == 4 && fwd->np252 && log_blowup <= fwd->lr252[0] && !getenv("MS_NTT252_RADIX2"))
+        return plan_run252_tiled(fwd, d_in, d_out, ncols, log_blowup, bit_reversed != 0);
     if (V != 4 && !fwd->small && log_blowup >= 2 && log_blowup <= 4) {
         // pass 1 reads only the rows that hold coefficients (straight from d_in), zero padding is implicit,
         // the bit reversal is fused into the last pass

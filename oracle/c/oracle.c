@@ -696,3 +696,60 @@ void oracle_degree_adjust(const uint64_t* acc, size_t n, unsigned PW, const uint
         out[(size_t)PW * i] = r.c0; if (PW == 3) { out[(size_t)PW * i + 1] = r.c1; out[(size_t)PW * i + 2] = r.c2; }
     }
 }
+
+/* ---- Fp252 NTT / LDE -------------------------------------------------------------------------------------------------
+   What the reference computes for Fp252 columns: ark-poly 0.4's Radix2EvaluationDomain::{fft_in_place, ifft_in_place} on a
+   coset (third-party dependency, ark-poly = "0.4" in Cargo.toml; called from GpuFft / GpuIfft's contract gpu/src/plan.rs:236-325
+   and from Matrix::into_evaluations / interpolate, src/matrix.rs:142-251): forward  y_k = sum_j (h^j x_j) w^(jk), inverse
+   x_j = h^-j n^-1 sum_k y_k w^(-jk), w = 3^((p-1)/n) (gpu/src/fields.rs:241).  Restated as bit reversal + iterative radix-2
+   butterflies over a twiddle table; checked against the big-integer oracle/pyref/ntt.py in tests/test_fp252_parity.py. */
+static const f252 F252_R2 = {{18446741271209837569ULL, 5151653887ULL, 18446744073700081664ULL, 576413109808302096ULL}};   /* R^2 mod p (felt_u256.h.metal:103) */
+static f252 f252_from_u64(uint64_t v) { f252 x = {{v, 0, 0, 0}}; return f252_mul(x, F252_R2); }
+static f252 f252_root_of_unity(unsigned log_n) {
+    const uint64_t e[1] = {0x0800000000000011ULL};                     /* (p - 1) / 2^192 */
+    f252 r = f252_pow(f252_from_u64(3), e, 1);
+    for (unsigned i = log_n; i < 192; i++) r = f252_mul(r, r);
+    return r;
+}
+void oracle_f252_ntt(uint64_t* data, unsigned log_n, int inverse, const uint64_t* offset_mont) {
+    const size_t n = (size_t)1 << log_n;
+    f252* x = (f252*)data;
+    f252 h; memcpy(h.l, offset_mont, 32);
+    f252 w = f252_root_of_unity(log_n);
+    if (inverse) w = f252_inv(w);
+    if (!inverse) { f252 s = F252_ONE; for (size_t i = 0; i < n; i++) { x[i] = f252_mul(x[i], s); s = f252_mul(s, h); } }
+    for (size_t i = 0; i < n; i++) {
+        size_t r = 0;
+        for (unsigned b = 0; b < log_n; b++) r |= ((i >> b) & 1) << (log_n - 1 - b);
+        if (r > i) { f252 t = x[i]; x[i] = x[r]; x[r] = t; }
+    }
+    const size_t half_n = n > 1 ? n / 2 : 1;
+    f252* tw = (f252*)malloc(half_n * sizeof(f252));
+    tw[0] = F252_ONE;
+    for (size_t i = 1; i < half_n; i++) tw[i] = f252_mul(tw[i - 1], w);
+    for (unsigned s = 1; s <= log_n; s++) {
+        const size_t half = (size_t)1 << (s - 1);
+        #pragma omp parallel for schedule(static)
+        for (size_t b = 0; b < n / 2; b++) {
+            const size_t j = b & (half - 1), lo = ((b >> (s - 1)) << s) + j, hi = lo + half;
+            const f252 t = f252_mul(x[hi], tw[j << (log_n - s)]), u = x[lo];
+            x[lo] = f252_add(u, t);
+            x[hi] = f252_sub(u, t);
+        }
+    }
+    free(tw);
+    if (inverse) {
+        const f252 hinv = f252_inv(h);
+        f252 s = f252_inv(f252_from_u64((uint64_t)n));
+        for (size_t i = 0; i < n; i++) { x[i] = f252_mul(x[i], s); s = f252_mul(s, hinv); }
+    }
+}
+/* interpolate on the subgroup, zero-extend, evaluate on the coset h<w_N>, optionally bit-reversed (src/prover.rs:50-51) */
+void oracle_f252_lde(const uint64_t* in, uint64_t* out, unsigned log_n, unsigned log_blowup, const uint64_t* offset_mont, int bit_reversed) {
+    const size_t n = (size_t)1 << log_n, N = n << log_blowup;
+    memcpy(out, in, n * 32);
+    oracle_f252_ntt(out, log_n, 1, F252_ONE.l);
+    memset(out + 4 * n, 0, (N - n) * 32);
+    oracle_f252_ntt(out, log_n + log_blowup, 0, offset_mont);
+    if (bit_reversed) oracle_bit_reverse(out, log_n + log_blowup, 4);
+}

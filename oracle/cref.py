@@ -85,6 +85,8 @@ def lib():
                                        u64p, u64p, ctypes.POINTER(u64p), ctypes.POINTER(ctypes.c_uint32), u64p, u64p]
         L.oracle_f252_mul.argtypes = [u64p, u64p, u64p]
         L.oracle_f252_inv.argtypes = [u64p, u64p]
+        L.oracle_f252_ntt.argtypes = [u64p, ctypes.c_uint, ctypes.c_int, u64p]
+        L.oracle_f252_lde.argtypes = [u64p, u64p, ctypes.c_uint, ctypes.c_uint, u64p, ctypes.c_int]
         L.oracle_horner_eval.argtypes = [u64p, ctypes.c_size_t, ctypes.c_uint, u64p, ctypes.c_uint, u64p]
         L.oracle_divide_out_points_acc.argtypes = [u64p, ctypes.c_size_t, ctypes.c_uint, u64p, u64p, ctypes.c_uint, ctypes.c_uint, u64p]
         L.oracle_degree_adjust.argtypes = [u64p, ctypes.c_size_t, ctypes.c_uint, u64p, u64p, u64p]
@@ -128,6 +130,9 @@ def random_elements(n, seed, V=1):
     return out
 
 
+F252_ONE_MONT = np.array([18446744073709551585, 18446744073709551615, 18446744073709551615, 576460752303422960], dtype=np.uint64)
+
+
 def ntt(a, log_n, V=1, inverse=False, offset=1):
     out = np.ascontiguousarray(a, dtype=np.uint64).copy()
     lib().oracle_ntt(_p(out), log_n, V, 1 if inverse else 0, offset)
@@ -144,6 +149,22 @@ def lde(a, log_n, log_blowup, V=1, offset=7, bit_reversed=True):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     out = np.empty((a.size << log_blowup,), dtype=np.uint64)
     lib().oracle_lde(_p(a), _p(out), log_n, log_blowup, V, offset, 1 if bit_reversed else 0)
+    return out
+
+
+def ntt252(a, log_n, inverse=False, offset_mont=None):
+    """Fp252 column (4 Montgomery words per element); offset_mont: 4 words, default R mod p (the subgroup)."""
+    out = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    off = np.ascontiguousarray(F252_ONE_MONT if offset_mont is None else offset_mont, dtype=np.uint64)
+    lib().oracle_f252_ntt(_p(out), log_n, 1 if inverse else 0, _p(off))
+    return out
+
+
+def lde252(a, log_n, log_blowup, offset_mont, bit_reversed=True):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty((a.size << log_blowup,), dtype=np.uint64)
+    off = np.ascontiguousarray(offset_mont, dtype=np.uint64)
+    lib().oracle_f252_lde(_p(a), _p(out), log_n, log_blowup, _p(off), 1 if bit_reversed else 0)
     return out
 
 

@@ -1,0 +1,22 @@
+"""C3 LDE (2^20 x 32, blow-up 8) kernel-time probe: per-pass kernel time for the column-group size in MS_NTT_GROUP_BYTES."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ministark_amd import GOLDILOCKS_FP, Matrix, Planner
+
+pl = Planner(0)
+log_n, log_b, ncols = int(os.environ.get("LOGN", 20)), int(os.environ.get("LOGB", 3)), int(os.environ.get("NCOLS", 32))
+rng = np.random.default_rng(3)
+P = (1 << 64) - (1 << 32) + 1
+trace = Matrix.from_numpy(pl, [rng.integers(0, P, size=1 << log_n, dtype=np.uint64) for _ in range(ncols)], GOLDILOCKS_FP)
+for _ in range(3):
+    lde = trace.lde(1 << log_b, 7, True); del lde
+pl.sync()
+pl.profile(True)
+for _ in range(5):
+    lde = trace.lde(1 << log_b, 7, True); del lde
+pl.sync()
+prof = pl.profile_read()
+pl.profile(False)
+k = {name: round(v["total_us"] / 5, 1) for name, v in sorted(prof.items())}
+print(json.dumps({"group_bytes": os.environ.get("MS_NTT_GROUP_BYTES"), "kernel_us": k, "lde_ms": round(sum(k.values()) / 1e3, 3)}))

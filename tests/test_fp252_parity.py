@@ -99,6 +99,90 @@ def test_hash_rows_252(kind):
         assert leaves[r].tobytes() == hashlib.sha256(a[r].to_bytes(32, "little") + b[r].to_bytes(32, "little")).digest()
 
 
+def _mont_words(vals):
+    return np.concatenate([f252_to_mont_limbs(v) for v in vals])
+
+
+def test_c_oracle_ntt_252_matches_bigint():
+    """oracle/c's Fp252 NTT / LDE (the checker of the large sizes below) against the big-integer restatement."""
+    from oracle import cref
+    for log_n, offset, inverse in [(0, 1, False), (1, 3, False), (7, 1, False), (9, 3, False), (9, 3, True), (10, 5, True)]:
+        n = 1 << log_n
+        vals = _rand_canon(n, 40 + log_n)
+        d = pyntt.Domain(F.F252, n, offset)
+        want = pyntt.ifft(d, vals) if inverse else pyntt.fft(d, vals)
+        got = cref.ntt252(_mont_words(vals), log_n, inverse, f252_to_mont_limbs(offset)).reshape(-1, 4)
+        assert [f252_from_mont_limbs(r) for r in got] == want
+    vals = _rand_canon(64, 3)
+    for br in (True, False):
+        got = cref.lde252(_mont_words(vals), 6, 3, f252_to_mont_limbs(3), br).reshape(-1, 4)
+        want = pyntt.lde_bit_reversed(F.F252, vals, 8, 3)
+        assert [f252_from_mont_limbs(r) for r in got] == (want if br else F.bit_reverse(want))
+
+
+def _ntt_case(pl, log_n, offset, inverse, seed):
+    from oracle import cref
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 1 << 59, size=4 << log_n, dtype=np.uint64)      # limbs < 2^59 => canonical (< p)
+    x[:4] = [0, 0, 0, 0]
+    x[4:8] = f252_to_mont_limbs(P - 1)
+    v = GpuVec.from_numpy(pl, x, STARK252_FP)
+    plan = (GpuIfft if inverse else GpuFft)(Radix2EvaluationDomain(1 << log_n, offset, STARK252_FP), STARK252_FP, pl)
+    plan.encode(v)
+    plan.execute()
+    assert np.array_equal(v.to_numpy(), cref.ntt252(x, log_n, inverse, f252_to_mont_limbs(offset)))
+
+
+@pytest.mark.parametrize("log_n,offset,inverse", [(12, 3, False), (13, 1, True), (14, 3, True), (15, 5, False)])
+def test_tiled_ntt_252_emu(log_n, offset, inverse):
+    """Two tiled passes (fp252_ntt_kernels.h) with even and odd radices, against the C oracle."""
+    _ntt_case(backends.planner("emu"), log_n, offset, inverse, log_n)
+
+
+def test_tiled_ntt_252_three_passes_emu(monkeypatch):
+    monkeypatch.setenv("MS_NTT252_PASSES", "3")
+    pl = backends.planner("emu")
+    _ntt_case(pl, 17, 3, False, 1)
+    _ntt_case(pl, 17, 3, True, 2)
+
+
+def _lde_case(pl, log_n, log_b, offset, seed):
+    from oracle import cref
+    rng = np.random.default_rng(seed)
+    cols = [rng.integers(0, 1 << 59, size=4 << log_n, dtype=np.uint64) for _ in range(3)]
+    m = Matrix([GpuVec.from_numpy(pl, c, STARK252_FP) for c in cols])
+    off = f252_to_mont_limbs(offset)
+    out = m.lde(1 << log_b, offset, True)
+    for c in range(3):
+        assert np.array_equal(out.columns[c].to_numpy(), cref.lde252(cols[c], log_n, log_b, off, True))
+    nat = m.lde(1 << log_b, offset, False)
+    assert np.array_equal(nat.columns[1].to_numpy(), cref.lde252(cols[1], log_n, log_b, off, False))
+    # into_evaluations on a shorter coefficient column (src/matrix.rs:193-251)
+    ev = m.bit_reversed_evaluate(Radix2EvaluationDomain(1 << (log_n + log_b), offset, STARK252_FP))
+    padded = np.concatenate([cols[2], np.zeros((4 << (log_n + log_b)) - cols[2].size, dtype=np.uint64)])
+    want = cref.bit_reverse(cref.ntt252(padded, log_n + log_b, False, off), log_n + log_b, 4)
+    assert np.array_equal(ev.columns[2].to_numpy(), want)
+
+
+@pytest.mark.parametrize("log_n,log_b", [(9, 2), (10, 3), (8, 4), (11, 1)])
+def test_tiled_lde_252_emu(log_n, log_b):
+    """Zero-extended input read from the short column + bit-reversed store fused into the last pass."""
+    _lde_case(backends.planner("emu"), log_n, log_b, 3, log_n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,offset,inverse", [(11, 3, False), (16, 3, True), (19, 1, False), (20, 3, False), (20, 3, True), (21, 5, False), (22, 3, True)])
+def test_tiled_ntt_252_hip(log_n, offset, inverse):
+    """2^20 (two passes of radix 1024) and the three-pass sizes against the C oracle, every element."""
+    _ntt_case(backends.planner("hip"), log_n, offset, inverse, log_n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,log_b", [(16, 2), (18, 2), (17, 4), (20, 1)])
+def test_tiled_lde_252_hip(log_n, log_b):
+    _lde_case(backends.planner("hip"), log_n, log_b, 3, log_n)
+
+
 @pytest.mark.gpu
 def test_roundtrip_2_16_252_hip():
     pl = backends.planner("hip")
