@@ -111,15 +111,22 @@ class _stdout_to_stderr:
         os.close(self.saved)
 
 
-def _profiled(pl, fn, reps):
-    """-> (wall seconds per call, {kernel: microseconds per call}) with hipEvents around every launch."""
+def _profiled(pl, fn, reps, after_wall=None):
+    """-> (wall seconds per call, {kernel: microseconds per call}).  The wall clock is taken WITHOUT the per-launch
+    hipEvents (a pair per kernel, ~150 launches per prover run, costs 15-20 % of the wall time); the kernel times come
+    from a second set of runs with them."""
     fn(); pl.sync()                                            # plans, pool, specialised kernels
-    pl.profile(True)
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
     pl.sync()
     wall = (time.perf_counter() - t0) / reps
+    if after_wall:
+        after_wall()
+    pl.profile(True)
+    for _ in range(reps):
+        fn()
+    pl.sync()
     prof = pl.profile_read()
     pl.profile(False)
     return wall, {k: round(v["total_us"] / reps, 1) for k, v in sorted(prof.items())}
@@ -182,7 +189,8 @@ def bench_prove(pl, with_cpu):
     def run():
         res.clear()
         res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8))
-    wall, k = _profiled(pl, run, 2)
+    phases = {}
+    wall, k = _profiled(pl, run, 3, after_wall=lambda: phases.update(res["phases_ms"]))      # phases of a run without events
     n_lde = n_t * blowup
     # algorithmic bytes per SURVEY.md 8(d): LDEs n s + beta n s per column, in-place transforms 2 n s, row hashing n cols s + 32 n,
     # trees 96 n, constraint evaluation sum of columns + result, FRI layers n s + n s / ff
@@ -191,7 +199,7 @@ def bench_prove(pl, with_cpu):
            + sum((n_lde >> (3 * i)) * 8 * (1 + 1 / 8) + 128 * (n_lde >> (3 * i + 3)) for i in range(len(draws.fri_alphas))))
     kernel_ms = sum(k.values()) / 1e3
     out = {"workload": "configs[4] on one GPU: 2^22 rows x 8 columns (Fp, Fq = Fp), ProofOptions::new(32, 4, 8, 8, 64): every data-parallel phase of default_prove, fixed challenges in place of the channel",
-           "prove_ms": round(wall * 1e3, 3), "kernel_ms": round(kernel_ms, 3), "phases_ms": res["phases_ms"], "kernel_us": k,
+           "prove_ms": round(wall * 1e3, 3), "kernel_ms": round(kernel_ms, 3), "phases_ms": phases, "kernel_us": k,
            "roofline": {"bound": "hbm (NTT / evaluation / FRI) + integer ALU (SHA-256)", "algorithmic_bytes": float(alg),
                         "achieved": round(alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},

@@ -1,0 +1,234 @@
+// Two-pass coset transforms for the LDE of columns of n = 256 L points, L = 256 T, T in {2, 4, 8, 16}
+// (2^17 <= n <= 2^20), Goldilocks Fp -- src/matrix.rs:142-251 / src/prover.rs:50-51 for blow-up beta:
+//
+//   the evaluations on the coset h<w_N>, N = beta n, are beta transforms of size n: E_j[k] = sum_i c_i (h w_N^j)^i w_n^(i k),
+//   j < beta, and in the committed bit-reversed order E_j is the CONTIGUOUS block rev(j) n .. rev(j) n + n, itself in
+//   bit-reversed order of k.  So instead of three passes over the N-point column (ntt2_kernels.h: 8 + 64 + 4 x 64 MiB per
+//   2^20-row column at beta = 8) each block is produced by two:
+//
+//   pass A (lde2_strided_pass)  i = i1 L + i0: radix 256 over i1 (rows at stride L, tile = 64 consecutive i0), input scaled by
+//                               (G^L)^i1 (wave-uniform), output k1 at row k1 (in place layout) times (G w_n^k1)^i0, G = h w_N^j;
+//   pass B (lde2_rows_pass)     radix L over i0 on whole contiguous rows: 256 x T with a 16 x 16 x T register / LDS
+//                               decomposition, output k = k1 + 256 k0 written to row rev8(k1) at rev(k0): whole rows of
+//                               L consecutive words again, no scattered store anywhere.
+//
+// Arithmetic is ntt2_kernels.h's (limb form, wave-uniform twiddles through scalar loads); the two per-lane twiddles are
+// pass A's inter-pass factor (running product, as in ntt2_first_pass) and pass B's w_L^(k t) between its radix-256 and
+// radix-T stages, which comes from a 32 KiB table read with coalesced loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ntt2_kernels.h"
+
+namespace mslde2 {
+
+using msntt::MAXC;
+using msntt2::NT;
+using msntt2::TW;
+using msntt2::cptr_t;
+using msntt2::pin;
+using msntt2::w4_at;
+
+struct Params {
+    const uint64_t* src[MAXC];
+    uint64_t* dst[MAXC];
+    const uint64_t* wr4;       // w_256^e, 4 plain copies each (the n-point plan's table)
+    const uint64_t* gpl;       // pass A: [j][i1] (G_j^L)^i1 plain, 256 per coset
+    const uint64_t* aux;       // pass A: [j][i0] G_j^i0 Montgomery, L per coset
+    const uint64_t* tw_lo;     // w_N^e two-level (Montgomery), lo_bits low bits
+    const uint64_t* tw_hi;
+    const uint64_t* t2;        // pass B: [k][t] w_L^(k t) Montgomery, 256 x T
+    unsigned log_n, log_b, lo_bits;   // n = 2^log_n points per coset, beta = 2^log_b cosets
+};
+
+__device__ __forceinline__ uint64_t twn_pow(const Params& P, uint64_t e) {      // w_n^e = w_N^(beta e), e < n
+    e <<= P.log_b;
+    const uint64_t lo = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+    const uint64_t hi_i = e >> P.lo_bits;
+    return hi_i ? gld::mmul(lo, P.tw_hi[hi_i]) : lo;
+}
+
+// first network of a pass on 16 loaded words (rows 16 a + b): optional uniform input scale, DFT16, times w_256^(a' b)
+template <bool SCALE>
+__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, const uint64_t* gpl_j) {
+    glimb::L4 v[16];
+    #pragma unroll
+    for (int a = 0; a < 16; a++) {
+        if constexpr (SCALE) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)gpl_j)[16 * a + b]);
+        else v[a] = glimb::from_u64(x[a]);
+    }
+    glimb::dft<16, false>(v);
+    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+    for (int c = 0; c < 16; c++) {
+        x[c] = pin(glimb::mul_fold(v[c], w4_at(P.wr4, (b * c) & 255)));
+        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- pass A ----------------------------------------------------------------------------------------------------------
+// grid = (L / 64, columns, beta): coefficients src[col][i1 L + i0] -> dst[col][j n + k1 L + i0]
+__global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
+    __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    const unsigned j = blockIdx.z;
+    const size_t n = (size_t)1 << P.log_n, L = n >> 8;
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y] + (size_t)j * n;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t i0 = (size_t)blockIdx.x * TW + lane;
+    const uint64_t* gpl_j = P.gpl + (size_t)j * 256;
+
+    const size_t step = 16 * L;
+    uint64_t x[2][16];
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint64_t* p = src + i0 + (size_t)(w + 8 * h) * L;
+        #pragma unroll
+        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
+        net1<true>(x[h], P, w + 8 * h, gpl_j);
+        #pragma unroll
+        for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    #pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r) {
+            __syncthreads();
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+                #pragma unroll
+                for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][8 + q];
+        }
+        __syncthreads();
+        const unsigned ap = w + 8 * r;                        // a' = low digit of k1
+        glimb::L4 v[16];
+        #pragma unroll
+        for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(xch[(b * 8 + w) * TW + lane]);
+        glimb::dft<16, false>(v);
+        uint64_t z[16];
+        #pragma unroll
+        for (int d = 0; d < 16; d++) {
+            z[d] = pin(glimb::to_weak(v[d]));
+            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // (G w_n^k1)^i0 for k1 = a' + 16 d: A B^d with A = G^i0 w_n^(i0 a'), B = w_n^(16 i0)   (i0 k1 < n: no wrap)
+        const uint64_t B = twn_pow(P, (uint64_t)i0 * 16);
+        uint64_t tw = gld::mmul(twn_pow(P, (uint64_t)i0 * ap), P.aux[(size_t)j * L + i0]);
+        uint64_t* q = dst + (size_t)ap * L + i0;
+        #pragma unroll
+        for (int d = 0; d < 16; d++, q += step) {
+            *q = gld::mmul(z[d], tw);
+            if (d < 15) tw = gld::mmul(tw, B);
+            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- pass B ----------------------------------------------------------------------------------------------------------
+// Rows of L = 256 T consecutive words, i0 = a (16 T) + b T + t.  A workgroup takes 64 / T rows: lane = (row select, t),
+// the radix-256 part over (a, b) is ntt2_mid_pass's (first network over a, uniform w_256^(a' b), exchange, second network
+// over b), then w_L^(k t) per lane, an exchange that gathers the T values t of a (row, k) pair into one lane, the radix-T
+// network, and a last trip through LDS so that the stores are runs of consecutive words.
+// grid = (256 T / 64, columns, beta)          [64 / T rows per workgroup, 256 rows per coset]
+static constexpr int X2P = 65;                               // pitch of the second exchange (words): conflict-free both ways
+template <int T>
+__global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
+    constexpr int LOGT = T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
+    constexpr int RSEL = 64 / T;                             // rows per workgroup
+    constexpr int X3WORDS = 8192 + 8192 / 16;               // third exchange: the 8192 words of a round, one pad word per 16
+    constexpr int XWORDS = X3WORDS > 128 * X2P ? X3WORDS : 128 * X2P;
+    __shared__ uint64_t xch[XWORDS];
+    const unsigned j = blockIdx.z;
+    const size_t n = (size_t)1 << P.log_n;
+    constexpr size_t L = 256 * T;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned rs = lane >> LOGT, t = lane & (T - 1);
+    const unsigned row0 = blockIdx.x * RSEL;
+    const uint64_t* __restrict__ src = P.src[blockIdx.y] + (size_t)j * n + (size_t)(row0 + rs) * L + t;
+    const unsigned jr = P.log_b ? __brev(j) >> (32 - P.log_b) : 0;     // block of coset j in the bit-reversed order
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y] + (size_t)jr * n;
+
+    uint64_t x[2][16];
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint64_t* p = src + (size_t)(w + 8 * h) * T;
+        #pragma unroll
+        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += 16 * T; }
+        net1<false>(x[h], P, w + 8 * h, nullptr);
+        #pragma unroll
+        for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    #pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r) {
+            __syncthreads();                                  // the stores of round 0 have read the buffer
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+                #pragma unroll
+                for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][8 + q];
+        }
+        __syncthreads();
+        const unsigned ap = w + 8 * r;                        // a' = low digit of k
+        {
+            glimb::L4 v[16];
+            #pragma unroll
+            for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(xch[(b * 8 + w) * TW + lane]);
+            glimb::dft<16, false>(v);
+            __syncthreads();                                  // everybody has read the first exchange
+            // k = a' + 16 b': times w_L^(k t), to slot kk = 16 w + b' of the second exchange
+            #pragma unroll
+            for (int d = 0; d < 16; d++) {
+                uint64_t z = glimb::to_weak(v[d]);
+                if constexpr (T > 1) z = gld::mmul(z, P.t2[(size_t)(ap + 16 * d) * T + t]);
+                xch[(w * 16 + d) * X2P + lane] = pin(z);
+                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        // the T words of (row, k) pairs: this lane owns pairs pr = threadIdx.x + 512 u, u < T / ... (128 k x RSEL rows = 8192 / T pairs)
+        constexpr int NPAIR = (128 * RSEL) / NT;             // pairs per lane and round: 16 / T
+        uint64_t out[NPAIR][T];
+        #pragma unroll
+        for (int u = 0; u < NPAIR; u++) {
+            const unsigned pr = threadIdx.x + NT * u;         // pair index: kk fastest (128), then the row
+            const unsigned kk = pr & 127, rsel = pr >> 7;
+            glimb::L4 v[T];
+            #pragma unroll
+            for (int tt = 0; tt < T; tt++) v[tt] = glimb::from_u64(xch[kk * X2P + rsel * T + tt]);
+            glimb::dft<T, false>(v);
+            #pragma unroll
+            for (int tt = 0; tt < T; tt++) out[u][tt] = pin(glimb::to_canon(v[tt]));
+        }
+        __syncthreads();                                      // the second exchange has been read
+        // third trip: chunk (row, x = bitrev3(w'), c = bitrev4(b')) holds the T outputs in bit-reversed order of t'; the slot
+        // of word ad is ad + ad / 16 (16 lanes that write 16 different chunks then hit 16 different banks for every T)
+        #pragma unroll
+        for (int u = 0; u < NPAIR; u++) {
+            const unsigned pr = threadIdx.x + NT * u;
+            const unsigned kk = pr & 127, rsel = pr >> 7;
+            const unsigned wq = kk >> 4, bq = kk & 15;
+            const unsigned chunk = (rsel * 8 + (__brev(wq) >> 29)) * 16 + (__brev(bq) >> 28);
+            #pragma unroll
+            for (int tt = 0; tt < T; tt++) {
+                unsigned rt = 0;
+                #pragma unroll
+                for (int bit = 0; bit < LOGT; bit++) rt |= ((tt >> bit) & 1u) << (LOGT - 1 - bit);
+                const unsigned ad = chunk * T + rt;
+                xch[ad + (ad >> 4)] = out[u][tt];
+            }
+        }
+        __syncthreads();
+        // stores: row rev8(k1); inside the row, run (r + 2 x) of 16 T words = chunks c = 0..15 of T words
+        #pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const unsigned idx = i * NT + threadIdx.x;        // < 8192 = RSEL * 8 * 16 * T
+            const unsigned tt = idx & (T - 1), c = (idx >> LOGT) & 15, xq = (idx >> (LOGT + 4)) & 7, rsel = idx >> (LOGT + 7);
+            const unsigned k1 = row0 + rsel;
+            dst[(size_t)(__brev(k1) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + c * T + tt] = xch[idx + (idx >> 4)];
+        }
+    }
+}
+
+}  // namespace mslde2

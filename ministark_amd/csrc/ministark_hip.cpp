@@ -28,6 +28,7 @@
 #endif
 #include "fp252_kernels.h"
 #include "fp252_ntt_kernels.h"
+#include "lde2_kernels.h"
 #include "rpo_kernels.h"
 #include "deep_kernels.h"
 
@@ -314,6 +315,11 @@ struct ms_ntt_plan {
     uint64_t* d_wr4[4] = {nullptr, nullptr, nullptr, nullptr};    // radix-256 passes: w_256^e
     uint64_t* d_twu4[4] = {nullptr, nullptr, nullptr, nullptr};   // middle passes: per-tile factor [U][k]
     uint64_t *d_sc4 = nullptr, *d_g_plain = nullptr;
+    // two-pass coset LDE (lde2_kernels.h), built on first use on the forward plan of the LDE domain: per blow-up
+    // [gpl | aux | t2] in one allocation
+    struct Lde2 { unsigned log_b = 0; uint64_t *d = nullptr, *gpl = nullptr, *aux = nullptr, *t2 = nullptr; };
+    std::vector<Lde2> lde2;
+    uint64_t offset_canon = 1;          // the coset offset h (canonical)
     std::vector<void*> queue;
     // Fp252 path (V == 4): plain radix-2 plan, see fp252_kernels.h
     bool is252 = false;
@@ -455,7 +461,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t gen = gl::root_of_unity(log_n);           // plain, arkworks get_root_of_unity
     ms_ntt_plan* p = new ms_ntt_plan();
-    p->ctx = ctx; p->V = V; p->log_n = log_n; p->inverse = inverse != 0; p->coset = (h != 1);
+    p->ctx = ctx; p->V = V; p->log_n = log_n; p->inverse = inverse != 0; p->coset = (h != 1); p->offset_canon = h;
     const size_t n = (size_t)1 << log_n;
     const uint64_t w = p->inverse ? gl::inv(gen) : gen;       // transform root
     const uint64_t hinv = gl::inv(h);
@@ -595,6 +601,7 @@ extern "C" int ms_ntt_plan_destroy(ms_ntt_plan* plan) {
     if (!plan) return MS_OK;
     (void)hipStreamSynchronize(plan->ctx->stream);
     if (plan->d_tables) (void)hipFree(plan->d_tables);
+    for (auto& l : plan->lde2) if (l.d) (void)hipFree(l.d);
     delete plan;
     return MS_OK;
 }
@@ -838,6 +845,82 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
     return MS_OK;
 }
 
+// ---- two-pass coset LDE (lde2_kernels.h) ------------------------------------------------------------------------------
+// fwd = the forward plan of the LDE domain (N = n << log_b points, offset h).  Applies to Fp columns of 2^17..2^20 rows.
+static bool lde2_applicable(const ms_ntt_plan* fwd, unsigned V, unsigned log_n, unsigned log_b) {
+    static const bool off = getenv("MS_LDE2") != nullptr && atoi(getenv("MS_LDE2")) == 0;       // A/B measurements
+    return !off && V == 1 && log_n >= 17 && log_n <= 20 && log_b >= 1 && log_b <= 6 && !fwd->small && fwd->d_wr4[0] != nullptr;
+}
+static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_plan::Lde2** out) {
+    for (auto& l : fwd->lde2) if (l.log_b == log_b) { *out = &l; return MS_OK; }
+    const size_t n = (size_t)1 << log_n, L = n >> 8, T = L >> 8, beta = (size_t)1 << log_b;
+    const uint64_t wN = gl::root_of_unity(log_n + log_b), wL = gl::root_of_unity(log_n - 8), h = fwd->offset_canon;
+    std::vector<uint64_t> host(beta * 256 + beta * L + 256 * T);
+    uint64_t* gpl = host.data();
+    uint64_t* aux = gpl + beta * 256;
+    uint64_t* t2 = aux + beta * L;
+    uint64_t G = h;                                               // G_j = h w_N^j
+    for (size_t j = 0; j < beta; j++, G = gl::mul(G, wN)) {
+        const uint64_t GL = gl::pow(G, (uint64_t)L);
+        uint64_t x = 1;
+        for (size_t i = 0; i < 256; i++) { gpl[j * 256 + i] = x; x = gl::mul(x, GL); }          // plain residues
+        x = 1;
+        for (size_t i = 0; i < L; i++) { aux[j * L + i] = gl::to_mont(x); x = gl::mul(x, G); }
+    }
+    for (size_t k = 0; k < 256; k++) {
+        const uint64_t wk = gl::pow(wL, (uint64_t)k);
+        uint64_t x = 1;
+        for (size_t t = 0; t < T; t++) { t2[k * T + t] = gl::to_mont(x); x = gl::mul(x, wk); }
+    }
+    ms_ntt_plan::Lde2 l;
+    l.log_b = log_b;
+    if (hipMalloc(&l.d, host.size() * 8) != hipSuccess) return fail(MS_ERR_NOMEM, "LDE tables (%zu bytes)", host.size() * 8);
+    if (hipMemcpy(l.d, host.data(), host.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(l.d); return fail(MS_ERR_HIP, "LDE table upload"); }
+    l.gpl = l.d; l.aux = l.d + beta * 256; l.t2 = l.aux + beta * L;
+    fwd->lde2.push_back(l);
+    *out = &fwd->lde2.back();
+    return MS_OK;
+}
+// coefficients (2^log_n words per column, src) -> bit-reversed evaluations on the coset of N points (dst, N words per column)
+static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols) {
+    ms_ctx* ctx = fwd->ctx;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    ms_ntt_plan::Lde2* tb = nullptr;
+    MSCHK(lde2_tables(fwd, log_n, log_b, &tb));
+    const size_t n = (size_t)1 << log_n, N = n << log_b, col_bytes = N * 8;
+    const unsigned T = (unsigned)(n >> 16);
+    unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
+    group = std::min(group, ncols);
+    void* scratch = nullptr;
+    MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes, &scratch));
+    for (unsigned c0 = 0; c0 < ncols; c0 += group) {
+        const unsigned nc = std::min(group, ncols - c0);
+        mslde2::Params P;
+        memset(&P, 0, sizeof P);
+        P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2;
+        P.tw_lo = fwd->d_tw_lo; P.tw_hi = fwd->d_tw_hi; P.lo_bits = fwd->lo_bits; P.log_n = log_n; P.log_b = log_b;
+        for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)src[c0 + c]; P.dst[c] = (uint64_t*)((char*)scratch + (size_t)c * col_bytes); }
+        {
+            ProfScope ps(ctx, "lde2_pass_a", (double)(n * 8 + col_bytes) * nc);
+            hipLaunchKernelGGL(mslde2::lde2_strided_pass, dim3((unsigned)(n >> 14), nc, 1u << log_b), dim3(msntt2::NT), 0, st, P);
+        }
+        for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)((char*)scratch + (size_t)c * col_bytes); P.dst[c] = (uint64_t*)dst[c0 + c]; }
+        {
+            ProfScope ps(ctx, "lde2_pass_b", 2.0 * col_bytes * nc);
+            const dim3 g(4 * T, nc, 1u << log_b), b(msntt2::NT);
+            switch (T) {
+            case 16: hipLaunchKernelGGL(mslde2::lde2_rows_pass<16>, g, b, 0, st, P); break;
+            case 8: hipLaunchKernelGGL(mslde2::lde2_rows_pass<8>, g, b, 0, st, P); break;
+            case 4: hipLaunchKernelGGL(mslde2::lde2_rows_pass<4>, g, b, 0, st, P); break;
+            default: hipLaunchKernelGGL(mslde2::lde2_rows_pass<2>, g, b, 0, st, P); break;
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
 extern "C" int ms_ntt_encode(ms_ntt_plan* plan, void* d_column) {
     if (!plan || !d_column) return fail(MS_ERR_INVALID, "ms_ntt_encode: null argument");
     std::lock_guard<std::mutex> lk(plan->ctx->mu);
@@ -955,6 +1038,12 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         // coefficients land in the first 2^log_n elements of the output column
         rc = plan_run(inv, d_in, d_out, ncols, 256);
         const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
+        if (rc == MS_OK && lde2_applicable(fwd, V, log_n, log_blowup)) {
+            // beta coset transforms of size n in two passes each, blocks land in the bit-reversed order
+            rc = lde2_run(fwd, log_n, log_blowup, (const void* const*)d_out, d_out, ncols);
+            if (rc == MS_OK && !bit_reversed) rc = bit_reverse_run(ctx, V, log_N, (const void* const*)d_out, d_out, ncols);
+            return rc;
+        }
         if (rc == MS_OK) {
             if (!fwd->small && log_blowup <= 4) {
                 // zero padding is implicit in pass 1, the bit reversal is fused into the last pass
@@ -997,6 +1086,11 @@ extern "C" int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_
         if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
         if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
         MSCHK(ctx_plan(ctx, V, log_domain, false, h, &fwd));
+    }
+    if (V != 4 && lde2_applicable(fwd, V, log_n, log_blowup)) {
+        MSCHK(lde2_run(fwd, log_n, log_blowup, d_in, d_out, ncols));
+        if (!bit_reversed) MSCHK(bit_reverse_run(ctx, V, log_domain, (const void* const*)d_out, d_out, ncols));
+        return MS_OK;
     }
     if (V == 4 && fwd->np252 && log_blowup <= fwd->lr252[0] && !getenv("MS_NTT252_RADIX2"))
         return plan_run252_tiled(fwd, d_in, d_out, ncols, log_blowup, bit_reversed != 0);

@@ -279,6 +279,20 @@ def test_lde_fq3_emu():
     _lde("emu", GOLDILOCKS_FP, 10, 2, bit_reversed=False)
 
 
+@pytest.mark.parametrize("log_n,log_b,bit_reversed", [(17, 1, True), (17, 2, False)])
+def test_lde_two_pass_cosets_emu(log_n, log_b, bit_reversed):
+    """lde2_kernels.h (columns of 2^17..2^20 rows: beta coset transforms in two passes each), smallest size, T = 2."""
+    _lde("emu", GOLDILOCKS_FP, log_n, log_b, ncols=2, bit_reversed=bit_reversed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,log_b", [(17, 2), (18, 3), (19, 1), (19, 4), (20, 2), (18, 5)])
+def test_lde_two_pass_cosets_hip(log_n, log_b):
+    """every row-length instantiation of lde2_rows_pass (T = 2, 4, 8, 16) and blow-ups 2..32"""
+    _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=3)
+    _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=1, bit_reversed=False)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_n,log_b", [(9, 4), (11, 3), (16, 3), (20, 3), (18, 0), (15, 2), (14, 4), (17, 1), (13, 3)])
 def test_lde_hip(log_n, log_b):
