@@ -315,6 +315,10 @@ struct ms_ntt_plan {
     uint64_t* d_wr4[4] = {nullptr, nullptr, nullptr, nullptr};    // radix-256 passes: w_256^e
     uint64_t* d_twu4[4] = {nullptr, nullptr, nullptr, nullptr};   // middle passes: per-tile factor [U][k]
     uint64_t *d_sc4 = nullptr, *d_g_plain = nullptr;
+    // three-pass plans with a last radix >= 64: pass 1's inter-pass factor from wave-uniform tables, the per-lane
+    // remainder applied by pass 2 on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
+    bool uni = false;
+    uint64_t *d_tin4 = nullptr, *d_tout4 = nullptr;
     // two-pass coset LDE (lde2_kernels.h), built on first use on the forward plan of the LDE domain: per blow-up
     // [gpl | aux | t2] in one allocation
     struct Lde2 { unsigned log_b = 0; uint64_t *d = nullptr, *gpl = nullptr, *aux = nullptr, *t2 = nullptr; };
@@ -540,8 +544,12 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
     for (auto& v : host) v = gl::to_mont(v);
     // ... except the tables of the limb-form passes (ntt2_kernels.h): plain residues, four copies
     // {w, w 2^24, w 2^48, w 2^72} per twiddle, appended after the conversion
-    size_t off_wr4[4] = {0, 0, 0, 0}, off_twu4[4] = {0, 0, 0, 0}, off_sc4 = 0, off_gp = 0;
+    size_t off_wr4[4] = {0, 0, 0, 0}, off_twu4[4] = {0, 0, 0, 0}, off_sc4 = 0, off_gp = 0, off_tin4 = 0, off_tout4 = 0;
     bool has_wr4[4] = {false, false, false, false}, has_twu4[4] = {false, false, false, false}, has_gp = false;
+    // MS_NTT2_PERLANE=1 keeps pass 1's per-lane running product (A/B measurements); MS_NTT_V1=1 the round-1 kernels
+    static const bool no_uni = (getenv("MS_NTT2_PERLANE") != nullptr && atoi(getenv("MS_NTT2_PERLANE")) != 0) ||
+                               (getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0);
+    p->uni = !p->small && !no_uni && p->npass == 3 && p->lr[1] == 8 && p->lr[2] >= 6 && (n * V) % msntt2::TILE == 0;
     if (!p->small) {
         const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
         auto append4 = [&](const std::vector<uint64_t>& plain) {
@@ -563,13 +571,36 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
                     for (unsigned f = 0; f < p->nfields[q]; f++)
                         rU |= (((unsigned)U >> p->fields[q][f].in_shift) & p->fields[q][f].mask) << p->fields[q][f].out_shift;
                     const uint64_t wu = gl::pow(ws, rU);
-                    uint64_t x = 1;
+                    // UNI plans: pass 2 also carries h^j3 of the inter-pass factor (h w_n^k1)^(R3 j2 + j3), j3 = rev(U)
+                    uint64_t x = (p->uni && q == 1 && !p->inverse && p->coset) ? gl::pow(h, rU) : 1;
                     for (unsigned k = 0; k < 256; k++) { t[U * 256 + k] = x; x = gl::mul(x, wu); }
                 }
                 off_twu4[q] = append4(t); has_twu4[q] = true;
             }
         }
         t.assign(1, ninv); off_sc4 = append4(t);
+        if (p->uni) {
+            // pass 1: tin4[j2][b][a'] = w_256^(a' b) w_n^(a' R3 j2) = w_n^(a' (b n/256 + R3 j2));
+            //         tout4[j2][b'] = h^(R3 j2) w_n^(16 b' R3 j2)      (h = 1 unless this is a forward coset transform)
+            const unsigned r3 = p->lr[2];
+            const uint64_t hh = (!p->inverse && p->coset) ? h : 1;
+            t.resize((size_t)256 * 256);
+            for (unsigned j2 = 0; j2 < 256; j2++)
+                for (unsigned b = 0; b < 16; b++) {
+                    const uint64_t m = ((uint64_t)b * (n >> 8) + ((uint64_t)j2 << r3)) & (n - 1);
+                    const uint64_t wm = gl::pow(w, m);
+                    uint64_t x = 1;
+                    for (unsigned a = 0; a < 16; a++) { t[((size_t)j2 * 16 + b) * 16 + a] = x; x = gl::mul(x, wm); }
+                }
+            off_tin4 = append4(t);
+            t.resize((size_t)256 * 16);
+            for (unsigned j2 = 0; j2 < 256; j2++) {
+                const uint64_t wm = gl::pow(w, (((uint64_t)j2 << r3) * 16) & (n - 1));
+                uint64_t x = gl::pow(hh, (uint64_t)j2 << r3);
+                for (unsigned bp = 0; bp < 16; bp++) { t[(size_t)j2 * 16 + bp] = x; x = gl::mul(x, wm); }
+            }
+            off_tout4 = append4(t);
+        }
         if (!p->inverse && p->coset) { powers(t, 256, gl::pow(h, (uint64_t)(n >> 8))); off_gp = host.size(); host.insert(host.end(), t.begin(), t.end()); has_gp = true; }
     }
     p->scale_const = gl::to_mont(p->scale_const);
@@ -591,6 +622,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             if (has_twu4[q]) p->d_twu4[q] = p->d_tables + off_twu4[q];
         }
         p->d_sc4 = p->d_tables + off_sc4;
+        if (p->uni) { p->d_tin4 = p->d_tables + off_tin4; p->d_tout4 = p->d_tables + off_tout4; }
         if (has_gp) p->d_g_plain = p->d_tables + off_gp;
     }
     *out = p;
@@ -745,6 +777,11 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
     void* scratch = nullptr;
     MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes, &scratch));
     const unsigned tiles = (unsigned)(n * p->V / msntt::TILE);
+    // uniform-factor plans on Fp columns: pass 1 stores whole lines in a permuted row order, pass 2 un-permutes out of
+    // place (scratch -> dst) and pass 3 runs in place on dst.  Not with the fused bit-reversed store (its last pass
+    // cannot run in place); MS_NTT2_NOPERM=1 keeps the natural rows (A/B measurements).
+    static const bool no_perm = getenv("MS_NTT2_NOPERM") != nullptr && atoi(getenv("MS_NTT2_NOPERM")) != 0;
+    const bool perm = p->uni && p->V == 1 && !bitrev_out && !no_perm;
     for (unsigned c0 = 0; c0 < ncols; c0 += group) {
         const unsigned nc = std::min(group, ncols - c0);
         for (int q = 0; q < p->npass; q++) {
@@ -755,6 +792,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 uint64_t* scr = (uint64_t*)((char*)scratch + (size_t)c * col_bytes);
                 P.src[c] = (q == 0) ? (const uint64_t*)src[c0 + c] : scr;
                 P.dst[c] = last ? (uint64_t*)dst[c0 + c] : scr;
+                if (perm && q >= 1) { P.dst[c] = (uint64_t*)dst[c0 + c]; if (q == 2) P.src[c] = (const uint64_t*)dst[c0 + c]; }
             }
             P.tw_lo = p->d_tw_lo; P.tw_hi = p->d_tw_hi; P.wr = p->d_wr[q];
             P.aux_lo = p->d_aux_lo; P.aux_hi = p->d_aux_hi; P.gtab = p->d_gtab;
@@ -776,7 +814,8 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                                (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0
                                        : (pass_sw % msntt2::TW == 0 && !(last && (bitrev_out || p->scale_mode == 2))));
             static const bool dbg = getenv("MS_NTT_DEBUG") != nullptr;
-            if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? "limb-form (ntt2)" : "round-1");
+            if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? (p->uni && q < 2 ? "limb-form (ntt2), uniform inter-pass factor" : "limb-form (ntt2)") : "round-1");
+            if (p->uni && q < 2 && !v2_ok) return fail(MS_ERR_INVALID, "internal: uniform inter-pass plan without its limb-form passes");
             if (v2_ok) {
                 msntt2::Params Q;
                 memset(&Q, 0, sizeof Q);
@@ -784,26 +823,37 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 Q.wr4 = p->d_wr4[q]; Q.twu4 = p->d_twu4[q]; Q.sc4 = p->d_sc4; Q.g_plain = p->d_g_plain;
                 Q.tw_lo = p->d_tw_lo; Q.tw_hi = p->d_tw_hi; Q.aux_lo = p->d_aux_lo; Q.aux_hi = p->d_aux_hi;
                 Q.log_n = p->log_n; Q.V = p->V; Q.valid_rows = valid_rows; Q.lo_bits = p->lo_bits; Q.log_s = p->log_s[q];
+                Q.tin4 = p->d_tin4; Q.tout4 = p->d_tout4; Q.r3 = p->lr[2];
                 Q.nfields = P.nfields;
                 for (unsigned f = 0; f < P.nfields; f++) Q.fields[f] = P.fields[f];
                 const dim3 g2((unsigned)(n * p->V / msntt2::TILE), nc), b2(msntt2::NT);
                 if (q == 0) {
                     const bool cos = (!p->inverse && p->coset);
                     const int na = valid_rows == 64 ? 4 : valid_rows == 32 ? 2 : valid_rows == 16 ? 1 : 16;
-                    if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, 16>), g2, b2, 0, st, Q);
+#define MS_P1(INV, COS, NA) do { if (perm) hipLaunchKernelGGL((msntt2::ntt2_first_pass<INV, COS, NA, true, true>), g2, b2, 0, st, Q); \
+                                 else if (p->uni) hipLaunchKernelGGL((msntt2::ntt2_first_pass<INV, COS, NA, true>), g2, b2, 0, st, Q); \
+                                 else hipLaunchKernelGGL((msntt2::ntt2_first_pass<INV, COS, NA, false>), g2, b2, 0, st, Q); } while (0)
+                    if (p->inverse) MS_P1(true, false, 16);
                     else if (cos) {
-                        if (na == 4) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 4>), g2, b2, 0, st, Q);
-                        else if (na == 2) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 2>), g2, b2, 0, st, Q);
-                        else if (na == 1) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 1>), g2, b2, 0, st, Q);
-                        else hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16>), g2, b2, 0, st, Q);
+                        if (na == 4) MS_P1(false, true, 4);
+                        else if (na == 2) MS_P1(false, true, 2);
+                        else if (na == 1) MS_P1(false, true, 1);
+                        else MS_P1(false, true, 16);
                     } else {
-                        if (na == 4) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 4>), g2, b2, 0, st, Q);
-                        else if (na == 2) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 2>), g2, b2, 0, st, Q);
-                        else if (na == 1) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 1>), g2, b2, 0, st, Q);
-                        else hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 16>), g2, b2, 0, st, Q);
+                        if (na == 4) MS_P1(false, false, 4);
+                        else if (na == 2) MS_P1(false, false, 2);
+                        else if (na == 1) MS_P1(false, false, 1);
+                        else MS_P1(false, false, 16);
                     }
+#undef MS_P1
                 } else if (!last) {
-                    if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0>), g2, b2, 0, st, Q);
+                    if (perm) {             // ... and reads pass 1's permuted rows, writes the natural order to dst
+                        if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0, true, true>), g2, b2, 0, st, Q);
+                        else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g2, b2, 0, st, Q);
+                    } else if (p->uni) {    // q == 1 of three: applies the per-lane remainder of pass 1's factor on its loads
+                        if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0, true>), g2, b2, 0, st, Q);
+                        else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true>), g2, b2, 0, st, Q);
+                    } else if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0>), g2, b2, 0, st, Q);
                     else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0>), g2, b2, 0, st, Q);
                 } else {
                     const int scale = p->scale_mode;

@@ -33,6 +33,7 @@ using msntt::DigitField;
 static constexpr int NT = 512;          // threads per workgroup (8 waves)
 static constexpr int TW = 64;           // words per tile row (one per lane)
 static constexpr int TILE = 256 * TW;   // words per tile
+struct alignas(16) Pair { uint64_t x, y; };   // two adjacent words, one 16-byte store
 static constexpr int XPITCH = 68;       // pass 1 exchange: row pitch in words (conflict-free transposed reads)
 
 struct Params {
@@ -43,12 +44,15 @@ struct Params {
     const uint64_t* twu4;      // middle pass: [U][k], w_n^((rev(U) k) << log_s)   (after the second network)
     const uint64_t* sc4;       // last pass, SCALE 1: the constant n^-1 (4 copies)
     const uint64_t* g_plain;   // pass 1 coset: g^j1 plain, j1 < 256
+    // uniform inter-pass factor of a three-pass plan (UNI kernels, see ntt2_first_pass):
+    const uint64_t* tin4;      // pass 1: [j2][b][a'] w_256^(a' b) w_n^(a' R3 j2)            (between the two networks)
+    const uint64_t* tout4;     // pass 1: [j2][b'] h^(R3 j2) w_n^(16 b' R3 j2)                (after the second network)
     // Montgomery-form tables of the round-1 kernels (per-lane twiddles of pass 1, scale walk of the last pass)
     const uint64_t* tw_lo;
     const uint64_t* tw_hi;
     const uint64_t* aux_lo;
     const uint64_t* aux_hi;
-    unsigned log_n, V, valid_rows, lo_bits, log_s, nfields;
+    unsigned log_n, V, valid_rows, lo_bits, log_s, nfields, r3;   // r3 = log2 of the last radix (UNI kernels)
     DigitField fields[3];
 };
 
@@ -90,22 +94,24 @@ MS_HD uint64_t pin(uint64_t x) { return x; }
 #endif
 
 // first network of a pass: 16 loaded words (rows 16 a + b) -> w_256^(a' b) * DFT16, as weak 64-bit residues
-template <bool INV, int NA>
-__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, bool coset) {
+//   IN   0: words as they are; 1: times the wave-uniform g_plain[16 a + b] (coset, pass 1); 2: times the per-lane q
+//   UNI  the factor after the network comes from tin4 at slot tslot + a' (pass 1 of a three-pass plan) instead of wr4
+template <bool INV, int NA, int IN, bool UNI = false>
+__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, uint64_t q = 0, unsigned tslot = 0) {
     glimb::L4 v[16];
-    if (coset) {
-        #pragma unroll
-        for (int a = 0; a < NA; a++) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)P.g_plain)[16 * a + b]);   // uniform: scalar load
-    } else {
-        #pragma unroll
-        for (int a = 0; a < NA; a++) v[a] = glimb::from_u64(x[a]);
+    #pragma unroll
+    for (int a = 0; a < NA; a++) {
+        if constexpr (IN == 1) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)P.g_plain)[16 * a + b]);   // uniform: scalar load
+        else if constexpr (IN == 2) v[a] = glimb::mul_to_limbs(x[a], q);
+        else v[a] = glimb::from_u64(x[a]);
     }
     if constexpr (NA == 16) glimb::dft<16, INV>(v);
     else glimb::dft16_pruned<NA, INV>(v);
     __builtin_amdgcn_sched_barrier(0);          // no twiddle (scalar) loads hoisted above the network: they would only be spilled
     #pragma unroll
     for (int c = 0; c < 16; c++) {
-        x[c] = pin(glimb::mul_fold(v[c], w4_at(P.wr4, (b * c) & 255)));
+        if constexpr (UNI) x[c] = pin(glimb::mul_fold(v[c], w4_at(P.tin4, tslot + c)));
+        else x[c] = pin(glimb::mul_fold(v[c], w4_at(P.wr4, (b * c) & 255)));
         if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the accumulators of at most 4 elements live
     }
 }
@@ -113,7 +119,15 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, b
 // ---- middle / last pass, radix 256 ---------------------------------------------------------------------
 // grid = (n V / 16384, columns); rows at stride sw = 2^log_s V words (>= 64), tile = 64 consecutive words.
 // SCALE (last pass): 0 none, 1 the constant in sc4 (n^-1 of an inverse transform on the subgroup).
-template <bool INV, bool LAST, int SCALE>
+// LOADQ (pass 2 of a three-pass plan whose pass 1 is the UNI kernel): every word is multiplied on the way in by
+//   w_n^(k1 j3), k1 = the lane's position in the row, j3 = this tile's block -- the part of the inter-pass factor
+//   (h w_n^k1)^(R3 j2 + j3) that pass 1 cannot apply with wave-uniform operands.  It is one value per lane and tile,
+//   so the 128-bit product replaces the plain conversion to limbs (no running product; h^j3 sits in twu4).
+// PERM (with LOADQ, V = 1, src != dst): pass 1 left every 256-word row in the order its stores like best (see
+//   ntt2_first_pass<.., PERM>): k1 = a' + 16 d sits at (a' >> 3) 128 + (d >> 1) 16 + (a' & 7) 2 + (d & 1).  The 64 words
+//   k1 = 64 q + lane of this tile are then two runs of 32 words (whole 128-byte lines, read once); the stores go to the
+//   natural positions of dst, so the permutation ends here.
+template <bool INV, bool LAST, int SCALE, bool LOADQ = false, bool PERM = false>
 __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
@@ -124,40 +138,60 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     const unsigned tiles_per_u = (unsigned)(sw / TW);
     const unsigned U = blockIdx.x / tiles_per_u;
     const size_t base = (size_t)U * 256 * sw + (size_t)(blockIdx.x % tiles_per_u) * TW + lane;
+    size_t rbase = base;
+    if constexpr (PERM) {
+        const unsigned q = blockIdx.x % tiles_per_u, ap = lane & 15, dl = lane >> 4;
+        rbase = (size_t)U * 256 * sw + (ap >> 3) * 128 + 32 * q + (dl >> 1) * 16 + (ap & 7) * 2 + (dl & 1);
+    }
 
     // Register budget: 128 per lane at two workgroups per CU, and a network in limb form holds 64.
     // Addresses walk by the uniform stride 16 sw (one 64-bit add per access; 32 precomputed row offsets would
-    // sit in scalar registers for the whole kernel).  The second half of the lane's words is loaded only after
-    // the first network has run, and the first half of each network's results goes to LDS at once: what waits
-    // in registers beside a network in flight is then 16 words, not 32.
+    // sit in scalar registers for the whole kernel).  The first half of each network's results goes to LDS at once,
+    // the second half as soon as round 0 of the exchange has been read (before the second network runs).
     const size_t step = 16 * sw;
     uint64_t x[2][16];
-    #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint64_t* p = src + base + (size_t)(w + 8 * h) * sw;
+    auto load_half = [&](int h) {
+        const uint64_t* p = src + rbase + (size_t)(w + 8 * h) * sw;
         #pragma unroll
         for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
-        net1<INV, 16>(x[h], P, w + 8 * h, false);
+    };
+    // Both halves are requested up front when the registers allow it (they do since the second half of the first
+    // networks' results leaves for LDS before the second network runs: ~115 VGPRs); with the load factor the second
+    // half is requested after the first network (measured: 54.0 vs 55.7 us per 2^24 column).
+    constexpr bool EARLY = !LOADQ;
+    load_half(0);
+    if constexpr (EARLY) load_half(1);
+    uint64_t qpl = 0;
+    if constexpr (LOADQ) {
+        const unsigned k1 = ((blockIdx.x % tiles_per_u) * TW + lane) / P.V;
+        qpl = gld::mmul(tw_pow(P, (uint64_t)k1 * digit_rev(P, U)), 1);      // out of Montgomery form: the data keeps its own
+    }
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (!EARLY && h == 1) load_half(1);
+        net1<INV, 16, LOADQ ? 2 : 0>(x[h], P, w + 8 * h, qpl);
         #pragma unroll
         for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][j];
         __builtin_amdgcn_sched_barrier(0);
     }
 
     // exchange: (wave, h) = b, register a'  ->  (wave, h) = a', register b; the lane keeps its word.
-    // Round r moves the registers a' in [8r, 8r + 8) and is followed at once by the second network of h = r.
+    // Round r moves the registers a' in [8r, 8r + 8) and is followed by the second network of h = r.
     #pragma unroll
     for (int r = 0; r < 2; r++) {
-        if (r) {
+        __syncthreads();
+        uint64_t y[16];
+        #pragma unroll
+        for (int b = 0; b < 16; b++) y[b] = xch[(b * 8 + w) * TW + lane];
+        if (r == 0) {
+            // the second half of the first networks' results moves to LDS as soon as everybody has read round 0 -- BEFORE
+            // this round's network, so that the 32 registers it occupied are free while the network runs
             __syncthreads();
             #pragma unroll
             for (int h = 0; h < 2; h++)
                 #pragma unroll
                 for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][8 + j];
         }
-        __syncthreads();
-        uint64_t y[16];
-        #pragma unroll
-        for (int b = 0; b < 16; b++) y[b] = xch[(b * 8 + w) * TW + lane];
         const unsigned ap = w + 8 * r;                        // a'
         glimb::W4 wn[4];                                      // twiddles one group ahead of their use (scalar loads from a 2 MiB table)
         if constexpr (!LAST) {
@@ -201,7 +235,18 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
 // the low output digit a' = c3 + 8 r -- one second network per lane and round, every lane busy in both rounds.
 // A wave then stores 8 runs of 8 consecutive k1 at the digit-reversed position of its 8 words (the two rounds
 // fill the two halves of each 128-byte line), the layout ntt_first_pass writes.
-template <bool INV, bool COSET, int NA>
+// UNI (three-pass plans whose last radix R3 is >= 64, so that a tile of 64 words has one j2 = j' / R3): the inter-pass
+// factor (h w_n^k1)^j', j' = R3 j2 + j3, k1 = a' + 16 b', is split into
+//     w_n^(a' R3 j2)            merged into the factor between the two networks (a' is a register index there),
+//     h^(R3 j2) w_n^(16 b' R3 j2)  after the second network (b' is the register index),
+//     (h w_n^k1)^j3             left to pass 2 (ntt2_mid_pass<.., LOADQ>), where it is one value per lane and tile,
+// all three wave-uniform or per-lane constants: no running product, no Montgomery multiplications in this pass.
+// PERM (UNI, V = 1): the 64-byte pieces of the layout above (8 lanes x 8 B per store, the other half of each line a round
+// later) cost pass 1 about 9 us per 2^24 column against whole-line stores (profiles/r02_ubench6_*).  With PERM a row of
+// 256 k1 is stored in the order  (a' >> 3) 128 + (d >> 1) 16 + (a' & 7) 2 + (d & 1)  (k1 = a' + 16 d): a lane's outputs
+// d, d + 1 are adjacent (one 16-byte store) and the 8 lanes a' & 7 fill one 128-byte line per store; pass 2 reads the
+// rows back in this order (ntt2_mid_pass<.., PERM>) and writes the natural one.
+template <bool INV, bool COSET, int NA, bool UNI = false, bool PERM = false>
 __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * XPITCH];                // [b][a' - 8 round][word], pitch 68 words
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
@@ -211,6 +256,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row_words = ((size_t)1 << (P.log_n - 8)) * V;
     const size_t w0 = (size_t)blockIdx.x * TW;
+    const unsigned j2 = UNI ? (unsigned)((w0 / V) >> P.r3) : 0;       // uniform: the block of R3 V words this tile lies in
 
     uint64_t x[2][16];
     auto load_half = [&](int h) {
@@ -226,15 +272,10 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
             p += 16 * row_words;
         }
     };
-#ifdef MS_NTT2_EARLY
-    load_half(0); load_half(1);
-#endif
+    load_half(0); load_half(1);          // both halves in flight before the first network (no spills since round 2b)
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-#ifndef MS_NTT2_EARLY
-        load_half(h);
-#endif
-        net1<INV, NA>(x[h], P, w + 8 * h, COSET);
+        net1<INV, NA, COSET ? 1 : 0, UNI>(x[h], P, w + 8 * h, 0, (j2 * 16 + w + 8 * h) * 16);
         #pragma unroll
         for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * XPITCH + lane] = x[h][j];
         __builtin_amdgcn_sched_barrier(0);
@@ -243,38 +284,85 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     const unsigned c3 = lane & 7, tl = lane >> 3;
     #pragma unroll
     for (int r = 0; r < 2; r++) {
-        if (r) {
+        __syncthreads();
+        const unsigned ap = c3 + 8 * r;                       // a' = low digit of k1
+        uint64_t y[16];
+        #pragma unroll
+        for (int b = 0; b < 16; b++) y[b] = xch[(b * 8 + c3) * XPITCH + 8 * w + tl];
+        if (r == 0) {                                         // second half to LDS before the network (see ntt2_mid_pass)
             __syncthreads();
             #pragma unroll
             for (int h = 0; h < 2; h++)
                 #pragma unroll
                 for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * XPITCH + lane] = x[h][8 + j];
         }
-        __syncthreads();
-        const unsigned ap = c3 + 8 * r;                       // a' = low digit of k1
         glimb::L4 v[16];
         #pragma unroll
-        for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(xch[(b * 8 + c3) * XPITCH + 8 * w + tl]);
+        for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(y[b]);
         glimb::dft<16, INV>(v);
-        uint64_t z[16];
-        #pragma unroll
-        for (int d = 0; d < 16; d++) {
-            z[d] = pin(glimb::to_weak(v[d]));
-            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        // inter-pass twiddle (h w_n^k1)^j' for k1 = a' + 16 d:  A * B^d   (j' k1 < n: no wrap); everything that is
-        // per lane is derived here, after the network, so that it does not occupy registers during it
-        const size_t wd = w0 + 8 * w + tl;                    // this lane's word after the exchange
-        const unsigned jp = (unsigned)(wd / V), vv = (unsigned)(wd % V);
-        uint64_t* q = dst + ((size_t)digit_rev(P, jp) << 8) * V + vv + (size_t)ap * V;
-        const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
-        uint64_t tw = tw_pow(P, (uint64_t)jp * ap);
-        if constexpr (COSET) tw = gld::mmul(tw, aux_pow(P, jp));
-        #pragma unroll
-        for (int d = 0; d < 16; d++, q += 16 * V) {
-            *q = gld::mmul(z[d], tw);
-            if (d < 15) tw = gld::mmul(tw, B);
-            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PERM) {
+            const unsigned jp = (unsigned)(w0 + 8 * w + tl);   // this lane's word after the exchange (V = 1)
+            Pair* q2 = (Pair*)(dst + ((size_t)digit_rev(P, jp) << 8) + r * 128 + c3 * 2);
+            glimb::W4 wn[4];
+            #pragma unroll
+            for (int j = 0; j < 4; j++) wn[j] = w4_at(P.tout4, j2 * 16 + j);
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                glimb::W4 wc[4];
+                #pragma unroll
+                for (int j = 0; j < 4; j++) wc[j] = wn[j];
+                if (g < 3) {
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) wn[j] = w4_at(P.tout4, j2 * 16 + 4 * (g + 1) + j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                #pragma unroll
+                for (int j = 0; j < 4; j += 2, q2 += 8)
+                    *q2 = Pair{glimb::mul_fold(v[4 * g + j], wc[j]), glimb::mul_fold(v[4 * g + j + 1], wc[j + 1])};
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (UNI) {
+            const size_t wd = w0 + 8 * w + tl;                // this lane's word after the exchange
+            const unsigned jp = (unsigned)(wd / V), vv = (unsigned)(wd % V);
+            uint64_t* q = dst + ((size_t)digit_rev(P, jp) << 8) * V + vv + (size_t)ap * V;
+            glimb::W4 wn[4];                                  // scalar loads one group ahead of their use
+            #pragma unroll
+            for (int j = 0; j < 4; j++) wn[j] = w4_at(P.tout4, j2 * 16 + j);
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                glimb::W4 wc[4];
+                #pragma unroll
+                for (int j = 0; j < 4; j++) wc[j] = wn[j];
+                if (g < 3) {
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) wn[j] = w4_at(P.tout4, j2 * 16 + 4 * (g + 1) + j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                #pragma unroll
+                for (int j = 0; j < 4; j++, q += 16 * V) *q = glimb::mul_fold(v[4 * g + j], wc[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            uint64_t z[16];
+            #pragma unroll
+            for (int d = 0; d < 16; d++) {
+                z[d] = pin(glimb::to_weak(v[d]));
+                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // inter-pass twiddle (h w_n^k1)^j' for k1 = a' + 16 d:  A * B^d   (j' k1 < n: no wrap); everything that is
+            // per lane is derived here, after the network, so that it does not occupy registers during it
+            const size_t wd = w0 + 8 * w + tl;                // this lane's word after the exchange
+            const unsigned jp = (unsigned)(wd / V), vv = (unsigned)(wd % V);
+            uint64_t* q = dst + ((size_t)digit_rev(P, jp) << 8) * V + vv + (size_t)ap * V;
+            const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
+            uint64_t tw = tw_pow(P, (uint64_t)jp * ap);
+            if constexpr (COSET) tw = gld::mmul(tw, aux_pow(P, jp));
+            #pragma unroll
+            for (int d = 0; d < 16; d++, q += 16 * V) {
+                *q = gld::mmul(z[d], tw);
+                if (d < 15) tw = gld::mmul(tw, B);
+                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }

@@ -38,12 +38,13 @@ int main(int argc, char** argv) {
     for (unsigned c = 0; c < NC; c++) { cols[c] = dev_table(n, 17 + c); CK(hipMalloc(&scr[c], n * 8)); CK(hipMemset(scr[c], 1, n * 8)); }
     uint64_t* wr4 = dev_table(256 * 4, 1); uint64_t* twu4 = dev_table((size_t)256 * 256 * 4, 2); uint64_t* sc4 = dev_table(4, 3);
     uint64_t* gp = dev_table(256, 4); uint64_t* tw_lo = dev_table(4096, 5); uint64_t* tw_hi = dev_table(4096, 6);
+    uint64_t* tin4 = dev_table((size_t)256 * 256 * 4, 11); uint64_t* tout4 = dev_table((size_t)256 * 16 * 4, 12);
     uint64_t* aux_lo = dev_table(4096, 7); uint64_t* aux_hi = dev_table(4096, 8); uint64_t* wr = dev_table(256, 9); uint64_t* gtab = dev_table(256, 10);
 
     msntt2::Params Q; memset(&Q, 0, sizeof Q);
     msntt::PassParams P; memset(&P, 0, sizeof P);
     Q.wr4 = wr4; Q.twu4 = twu4; Q.sc4 = sc4; Q.g_plain = gp; Q.tw_lo = tw_lo; Q.tw_hi = tw_hi; Q.aux_lo = aux_lo; Q.aux_hi = aux_hi;
-    Q.log_n = log_n; Q.V = 1; Q.valid_rows = 256; Q.lo_bits = 12;
+    Q.log_n = log_n; Q.V = 1; Q.valid_rows = 256; Q.lo_bits = 12; Q.tin4 = tin4; Q.tout4 = tout4; Q.r3 = 8;
     P.tw_lo = tw_lo; P.tw_hi = tw_hi; P.wr = wr; P.aux_lo = aux_lo; P.aux_hi = aux_hi; P.gtab = gtab; P.log_n = log_n; P.V = 1; P.valid_rows = 256; P.lo_bits = 12;
     // pass 1 of an (8, 8, 8) plan: j' = (j2, j3) -> layout (j3, j2)
     msntt::DigitField f1[2] = {{0, 8, 255}, {8, 0, 255}};
@@ -68,7 +69,14 @@ int main(int argc, char** argv) {
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_first_pass<false, true>), g1, b1, 0, 0, P); });   printf("round-1 pass 1 (coset)   %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset)   %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 16>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (subgroup) %6.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset, uniform factor)    %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 16, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (subgroup, uniform factor) %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset, uniform, permuted rows)  %5.1f us/column\n", t / NC);
     set_pass(1);
+    for (unsigned c = 0; c < NC; c++) Q.dst[c] = cols[c];
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g2, b2, 0, 0, Q); });   printf("limb    pass 2 (load factor, permuted rows in)  %5.1f us/column\n", t / NC);
+    set_pass(1);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true>), g2, b2, 0, 0, Q); });   printf("limb    pass 2 (per-lane load factor)     %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, false, 0>), g1, b1, 0, 0, P); }); printf("round-1 pass 2           %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0>), g2, b2, 0, 0, Q); });   printf("limb    pass 2           %7.1f us/column\n", t / NC);
     set_pass(2);

@@ -58,6 +58,23 @@ def test_multipass_variants_emu(log_n, inverse, offset):
     _run("emu", GOLDILOCKS_FP, log_n, inverse, offset)
 
 
+# three-pass plans whose last radix is >= 64 (2^22 .. 2^24): pass 1's inter-pass factor comes from wave-uniform tables and
+# pass 2 applies the per-lane remainder on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
+@pytest.mark.parametrize("field,log_n,inverse,offset", [(GOLDILOCKS_FP, 22, False, 7), (GOLDILOCKS_FP, 22, True, 1),
+                                                        (GOLDILOCKS_FP, 22, False, 1), (GOLDILOCKS_FP, 22, True, 7),
+                                                        (GOLDILOCKS_FQ3, 22, False, 7)])
+def test_uniform_interpass_factor_emu(field, log_n, inverse, offset):
+    _run("emu", field, log_n, inverse, offset)
+
+
+@pytest.mark.parametrize("log_b", [2, 3])
+def test_uniform_interpass_factor_lde_emu(log_b):
+    # the LDE's forward transform on 2^22 points with the pruned first network (zero-padded input) and the fused bit reversal
+    _lde("emu", GOLDILOCKS_FP, 22 - log_b, log_b, ncols=1)
+    if log_b == 2:      # natural order: the permuted-row variant (pass 2 out of place) with the pruned network
+        _lde("emu", GOLDILOCKS_FP, 22 - log_b, log_b, ncols=2, bit_reversed=False)
+
+
 @pytest.mark.parametrize("log_n,inverse,offset", [(5, False, 7), (11, True, 7), (12, False, 1), (13, True, 7), (17, False, 7)])
 def test_fq3_emu(log_n, inverse, offset):
     _run("emu", GOLDILOCKS_FQ3, log_n, inverse, offset, ncols=2)
@@ -96,7 +113,7 @@ def test_inverse_sizes_hip(log_n, offset):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n,inverse,offset", [(13, False, 7), (17, True, 7), (20, False, 7), (22, True, 1)])
+@pytest.mark.parametrize("log_n,inverse,offset", [(13, False, 7), (17, True, 7), (20, False, 7), (22, True, 1), (22, False, 7), (23, False, 7), (23, True, 7)])
 def test_fq3_sizes_hip(log_n, inverse, offset):
     _run("hip", GOLDILOCKS_FQ3, log_n, inverse, offset, ncols=2)
 
