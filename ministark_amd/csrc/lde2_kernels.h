@@ -81,10 +81,13 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     const size_t step = 16 * L;
     uint64_t x[2][16];
     #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < 2; h++) {                            // both halves requested before the first network
         const uint64_t* p = src + i0 + (size_t)(w + 8 * h) * L;
         #pragma unroll
         for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
+    }
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
         net1<true>(x[h], P, w + 8 * h, gpl_j);
         #pragma unroll
         for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
@@ -92,18 +95,21 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     }
     #pragma unroll
     for (int r = 0; r < 2; r++) {
-        if (r) {
+        __syncthreads();
+        const unsigned ap = w + 8 * r;                        // a' = low digit of k1
+        uint64_t y[16];
+        #pragma unroll
+        for (int b = 0; b < 16; b++) y[b] = xch[(b * 8 + w) * TW + lane];
+        if (r == 0) {                                         // second half to LDS before the network (as ntt2_mid_pass)
             __syncthreads();
             #pragma unroll
             for (int h = 0; h < 2; h++)
                 #pragma unroll
                 for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][8 + q];
         }
-        __syncthreads();
-        const unsigned ap = w + 8 * r;                        // a' = low digit of k1
         glimb::L4 v[16];
         #pragma unroll
-        for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(xch[(b * 8 + w) * TW + lane]);
+        for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(y[b]);
         glimb::dft<16, false>(v);
         uint64_t z[16];
         #pragma unroll

@@ -84,6 +84,8 @@ struct ms_ctx {
     int device = 0;
     std::vector<std::pair<PlanKey, ms_ntt_plan*>> plan_cache;   // plans used by the fused entry points
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // second half of a column group in plan_run (created on first use)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     // columns are processed in groups of about this size (= the scratch buffer).  Measured at 2^24: one column per
@@ -168,6 +170,7 @@ extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);
     for (auto m : ctx->jit_modules) (void)hipModuleUnload(m);
+    if (ctx->stream2) { (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MS_OK;
@@ -782,8 +785,29 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
     // cannot run in place); MS_NTT2_NOPERM=1 keeps the natural rows (A/B measurements).
     static const bool no_perm = getenv("MS_NTT2_NOPERM") != nullptr && atoi(getenv("MS_NTT2_NOPERM")) != 0;
     const bool perm = p->uni && p->V == 1 && !bitrev_out && !no_perm;
-    for (unsigned c0 = 0; c0 < ncols; c0 += group) {
-        const unsigned nc = std::min(group, ncols - c0);
+    // Two halves of a group on two streams: kernels of different passes then overlap (a pass alternates between a
+    // memory phase and an arithmetic phase per workgroup), measured 171 -> 165 us per 2^24 column over 8 columns
+    // (scripts/ntt_pass_bench.hip, launch orders).  Not while per-launch profiling is on (its events sit on one stream).
+    static const bool one_stream = getenv("MS_NTT_STREAMS") != nullptr && atoi(getenv("MS_NTT_STREAMS")) == 1;
+    const bool two = !one_stream && !ctx->profiling && ncols >= 2 && group >= 2 && p->log_n >= 20;
+    if (two) {
+        if (!ctx->stream2) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
+    void* const scratch_all = scratch;
+    const hipStream_t st_main = st;
+    for (unsigned g0 = 0; g0 < ncols; g0 += group) {
+      const unsigned gnc = std::min(group, ncols - g0);
+      const unsigned half = (two && gnc >= 2) ? gnc / 2 : gnc;
+      for (unsigned s0 = 0; s0 < gnc; s0 = (s0 == 0) ? half : gnc) {     // at most two ranges: [0, half), [half, gnc)
+        const unsigned c0 = g0 + s0, nc = (s0 == 0) ? half : gnc - half;
+        const hipStream_t st = (s0 == 0) ? st_main : ctx->stream2;
+        void* const scratch = (char*)scratch_all + (size_t)s0 * col_bytes;
         for (int q = 0; q < p->npass; q++) {
             msntt::PassParams P;
             memset(&P, 0, sizeof P);
@@ -890,6 +914,11 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 }
             }
         }
+      }
+    }
+    if (two) {
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     HIPCHK(hipGetLastError());
     return MS_OK;

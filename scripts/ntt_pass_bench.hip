@@ -83,6 +83,51 @@ int main(int argc, char** argv) {
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, true, 0>), g1, b1, 0, 0, P); });  printf("round-1 pass 3           %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, 0, Q); });    printf("limb    pass 3           %7.1f us/column\n", t / NC);
   }
+    // whole transforms (uniform factor + permuted rows): launch orders
+    {
+        hipStream_t sts[4]; hipEvent_t evs[5];
+        for (int i = 0; i < 4; i++) CK(hipStreamCreateWithFlags(&sts[i], hipStreamNonBlocking));
+        for (int i = 0; i < 5; i++) CK(hipEventCreateWithFlags(&evs[i], hipEventDisableTiming));
+        auto passes = [&](hipStream_t st, unsigned c0, unsigned nc, unsigned scr0) {
+            msntt2::Params A = Q;
+            const dim3 g((unsigned)(n / msntt2::TILE), nc);
+            A.log_s = 0; A.nfields = 2; A.fields[0] = f1[0]; A.fields[1] = f1[1];
+            for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = scr[scr0 + c]; }
+            hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true, true>), g, b2, 0, st, A);
+            A.log_s = 8; A.nfields = 1; A.fields[0] = {0, 0, 255};
+            for (unsigned c = 0; c < nc; c++) { A.src[c] = scr[scr0 + c]; A.dst[c] = cols[c0 + c]; }
+            hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g, b2, 0, st, A);
+            A.log_s = 16; A.nfields = 0;
+            for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = cols[c0 + c]; }
+            hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g, b2, 0, st, A);
+        };
+        for (int round = 0; round < 2; round++) {
+            t = time_us([&] { passes(0, 0, NC, 0); });
+            printf("transform, batch order (3 launches x 8 columns)        %7.1f us/column\n", t / NC);
+            t = time_us([&] { for (unsigned c = 0; c < NC; c += 2) passes(0, c, 2, 0); });
+            printf("transform, 2 columns per launch                        %7.1f us/column\n", t / NC);
+            t = time_us([&] { for (unsigned c = 0; c < NC; c++) passes(0, c, 1, 0); });
+            printf("transform, chain per column, one stream                %7.1f us/column\n", t / NC);
+            for (int k : {2, 4}) {
+                t = time_us([&] {
+                    CK(hipEventRecord(evs[4], 0));
+                    for (int i = 0; i < k; i++) CK(hipStreamWaitEvent(sts[i], evs[4], 0));
+                    for (unsigned c = 0; c < NC; c++) passes(sts[c % k], c, 1, c % k);
+                    for (int i = 0; i < k; i++) { CK(hipEventRecord(evs[i], sts[i])); CK(hipStreamWaitEvent(0, evs[i], 0)); }
+                });
+                printf("transform, chain per column on %d streams               %7.1f us/column\n", k, t / NC);
+            }
+            for (int k : {2, 4}) {
+                t = time_us([&] {
+                    CK(hipEventRecord(evs[4], 0));
+                    for (int i = 0; i < k; i++) CK(hipStreamWaitEvent(sts[i], evs[4], 0));
+                    for (int i = 0; i < k; i++) passes(sts[i], i * (NC / k), NC / k, i * (NC / k));
+                    for (int i = 0; i < k; i++) { CK(hipEventRecord(evs[i], sts[i])); CK(hipStreamWaitEvent(0, evs[i], 0)); }
+                });
+                printf("transform, %d streams x %d columns per launch            %7.1f us/column\n", k, NC / k, t / NC);
+            }
+        }
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }

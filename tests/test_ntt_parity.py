@@ -67,6 +67,11 @@ def test_uniform_interpass_factor_emu(field, log_n, inverse, offset):
     _run("emu", field, log_n, inverse, offset)
 
 
+def test_column_group_on_two_streams_emu():
+    # >= 2 columns of >= 2^20 points are split over two streams, [0, n/2) and [n/2, n): an odd count exercises both ranges
+    _run("emu", GOLDILOCKS_FP, 20, False, 7, ncols=3)
+
+
 @pytest.mark.parametrize("log_b", [2, 3])
 def test_uniform_interpass_factor_lde_emu(log_b):
     # the LDE's forward transform on 2^22 points with the pruned first network (zero-padded input) and the fused bit reversal
