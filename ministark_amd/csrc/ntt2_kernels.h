@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
             for (int j = 0; j < 4; j++, pos += step) {
                 const int d = 4 * g + j;
                 uint64_t val;
-                if constexpr (!LAST) val = glimb::mul_fold<true>(v[d], wc[j]);
+                if constexpr (!LAST) val = glimb::mul_fold<false>(v[d], wc[j]);       // a weak residue: every pass accepts any 64-bit representative
                 else if constexpr (SCALE == 1) val = glimb::mul_fold<true>(v[d], w4_at(P.sc4, 0));
                 else val = glimb::to_canon(v[d]);
                 dst[pos] = val;
