@@ -852,13 +852,15 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             // limb-form radix-256 passes (ntt2_kernels.h) wherever a pass has radix 256 and rows of >= 64 words;
             // MS_NTT_V1=1 keeps the round-1 kernels (A/B measurements)
             static const bool force_v1 = getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0;
+            static const bool no_br2 = getenv("MS_NTT2_BITREV") != nullptr && atoi(getenv("MS_NTT2_BITREV")) == 0;   // A/B: round-1 fused bit reversal
             const size_t pass_sw = ((size_t)1 << p->log_s[q]) * p->V;
-            // (the fused bit-reversed store and the per-element scale walk of an inverse coset transform stay with the
-            // round-1 last pass: the walk is two table loads and a Montgomery product per word, which the 4-wave limb kernel
-            // hides worse -- 91 vs 75 us per 2^24 column)
+            // (the per-element scale walk of an inverse coset transform stays with the round-1 last pass: the walk is two table
+            // loads and a Montgomery product per word, which the 4-wave limb kernel hides worse -- 91 vs 75 us per 2^24
+            // column; so does the fused bit-reversed store of Fq3 columns, whose runs interleave three words)
             const bool v2_ok = !force_v1 && p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
                                (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0
-                                       : (pass_sw % msntt2::TW == 0 && !(last && (bitrev_out || p->scale_mode == 2))));
+                                       : (pass_sw % msntt2::TW == 0 && !(last && p->scale_mode == 2) &&
+                                          !(last && bitrev_out && (p->V != 1 || p->inverse || p->scale_mode != 0 || no_br2))));
             static const bool dbg = getenv("MS_NTT_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? (p->uni && q < 2 ? "limb-form (ntt2), uniform inter-pass factor" : "limb-form (ntt2)") : "round-1");
             if (p->uni && q < 2 && !v2_ok) return fail(MS_ERR_INVALID, "internal: uniform inter-pass plan without its limb-form passes");
@@ -901,6 +903,8 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                         else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true>), g2, b2, 0, st, Q);
                     } else if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0>), g2, b2, 0, st, Q);
                     else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0>), g2, b2, 0, st, Q);
+                } else if (bitrev_out) {
+                    hipLaunchKernelGGL(msntt2::ntt2_last_pass_bitrev, g2, b2, 0, st, Q);
                 } else {
                     const int scale = p->scale_mode;
                     if (p->inverse) {

@@ -229,6 +229,68 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     }
 }
 
+// ---- last pass with the bit-reversed store fused (the LDE's forward transform, Fp columns) -----------------------
+// Same tile and arithmetic as ntt2_mid_pass<false, true, 0>; the output X[k], k = k3 2^log_s + low, goes to position
+// rev(low) 256 + rev8(k3): for every word of the tile a run of 256 consecutive words.  A round of the exchange yields
+// the k3 = a' + 16 d with a' in [8r, 8r + 8), i.e. in the run the eight 16-word chunks (2 rev3(a' & 7) + r): the results
+// take a third trip through LDS ([word][chunk][rev4(d)], pitch 129: conflict-free both ways) so that 16 consecutive lanes
+// store one whole 128-byte line.  The buffer is shared with the exchange, so here the second half of the first networks'
+// results waits in registers until round 0 has stored (a few spilled registers, as before round 2b).
+static constexpr int BR_PITCH = 129;
+__global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) {
+    __shared__ uint64_t xch[64 * BR_PITCH];                  // >= 16 * 8 * TW words of the exchange
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t sw = (size_t)1 << P.log_s;                  // V = 1; the last pass has a single block U = 0
+    const size_t lo0 = (size_t)blockIdx.x * TW;
+    const size_t base = lo0 + lane;
+    const size_t step = 16 * sw;
+    uint64_t x[2][16];
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint64_t* p = src + base + (size_t)(w + 8 * h) * sw;
+        #pragma unroll
+        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
+        net1<false, 16, 0>(x[h], P, w + 8 * h);
+        #pragma unroll
+        for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned ch = __brev(w) >> 29;                     // rev3(a' & 7): this wave's chunk of every run
+    #pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r) {
+            __syncthreads();                                  // round 0's stores have read the buffer
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+                #pragma unroll
+                for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][8 + j];
+        }
+        __syncthreads();
+        glimb::L4 v[16];
+        #pragma unroll
+        for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(xch[(b * 8 + w) * TW + lane]);
+        glimb::dft<16, false>(v);
+        __syncthreads();                                      // everybody has read the exchange
+        #pragma unroll
+        for (int d = 0; d < 16; d++) {
+            constexpr int R4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+            xch[lane * BR_PITCH + ch * 16 + R4[d]] = pin(glimb::to_canon(v[d]));
+            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const unsigned idx = it * NT + threadIdx.x;       // (word t, chunk c, i): 16 lanes = one 128-byte line
+            const unsigned i = idx & 15, c = (idx >> 4) & 7, t = idx >> 7;
+            const size_t e_rev = P.log_s ? (size_t)(__brevll((unsigned long long)(lo0 + t)) >> (64 - P.log_s)) : 0;
+            dst[(e_rev << 8) + c * 32 + r * 16 + i] = xch[t * BR_PITCH + c * 16 + i];
+        }
+    }
+}
+
 // ---- pass 1 -----------------------------------------------------------------------------------------------
 // grid = (n V / 16384, columns): rows j1 = 16 a + b of n V / 256 words, tile = 64 consecutive words of j'.
 // The exchange re-maps the lanes: readers are lane = (c3, tl), wave = th with word t = 8 th + tl and, in round r,

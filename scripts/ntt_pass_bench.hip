@@ -82,6 +82,8 @@ int main(int argc, char** argv) {
     set_pass(2);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, true, 0>), g1, b1, 0, 0, P); });  printf("round-1 pass 3           %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, 0, Q); });    printf("limb    pass 3           %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, true, 0, true>), g1, b1, 0, 0, P); });  printf("round-1 pass 3, bit-reversed store  %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL(msntt2::ntt2_last_pass_bitrev, g2, b2, 0, 0, Q); });    printf("limb    pass 3, bit-reversed store  %7.1f us/column\n", t / NC);
   }
     // whole transforms (uniform factor + permuted rows): launch orders
     {

@@ -67,6 +67,11 @@ def test_uniform_interpass_factor_emu(field, log_n, inverse, offset):
     _run("emu", field, log_n, inverse, offset)
 
 
+def test_lde_bit_reversed_limb_last_pass_emu():
+    # a 2^24-point LDE domain = (8, 8, 8): pruned uniform-factor pass 1, load-factor pass 2, ntt2_last_pass_bitrev
+    _lde("emu", GOLDILOCKS_FP, 22, 2, ncols=1)
+
+
 def test_column_group_on_two_streams_emu():
     # >= 2 columns of >= 2^20 points are split over two streams, [0, n/2) and [n/2, n): an odd count exercises both ranges
     _run("emu", GOLDILOCKS_FP, 20, False, 7, ncols=3)
