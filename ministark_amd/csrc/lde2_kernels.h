@@ -56,12 +56,25 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
         if constexpr (SCALE) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)gpl_j)[16 * a + b]);
         else v[a] = glimb::from_u64(x[a]);
     }
+    glimb::W4 wn[4];                            // the first group's factors are requested before the network (as msntt2::net1)
+    #pragma unroll
+    for (int j = 0; j < 4; j++) wn[j] = w4_at(P.wr4, (b * j) & 255);
+    __builtin_amdgcn_sched_barrier(0);
     glimb::dft<16, false>(v);
     __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-    for (int c = 0; c < 16; c++) {
-        x[c] = pin(glimb::mul_fold(v[c], w4_at(P.wr4, (b * c) & 255)));
-        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < 4; g++) {
+        glimb::W4 wc[4];
+        #pragma unroll
+        for (int j = 0; j < 4; j++) wc[j] = wn[j];
+        if (g < 3) {
+            #pragma unroll
+            for (int j = 0; j < 4; j++) wn[j] = w4_at(P.wr4, (b * (4 * (g + 1) + j)) & 255);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+        for (int j = 0; j < 4; j++) x[4 * g + j] = pin(glimb::mul_fold(v[4 * g + j], wc[j]));
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

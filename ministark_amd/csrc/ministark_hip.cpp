@@ -799,14 +799,15 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
     }
     unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
     group = std::min(group, ncols);
-    void* scratch = nullptr;
-    MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes, &scratch));
-    const unsigned tiles = (unsigned)(n * p->V / msntt::TILE);
     // uniform-factor plans on Fp columns: pass 1 stores whole lines in a permuted row order, pass 2 un-permutes out of
-    // place (scratch -> dst) and pass 3 runs in place on dst.  Not with the fused bit-reversed store (its last pass
-    // cannot run in place); MS_NTT2_NOPERM=1 keeps the natural rows (A/B measurements).
+    // place (scratch -> dst) and pass 3 runs in place on dst.  With the fused bit-reversed store the last pass cannot run
+    // in place: pass 2 then writes a second scratch column.  MS_NTT2_NOPERM=1 keeps the natural rows (A/B measurements).
     static const bool no_perm = getenv("MS_NTT2_NOPERM") != nullptr && atoi(getenv("MS_NTT2_NOPERM")) != 0;
-    const bool perm = p->uni && p->V == 1 && !bitrev_out && !no_perm;
+    const bool perm = p->uni && p->V == 1 && !no_perm;
+    const bool perm2 = perm && bitrev_out;
+    void* scratch = nullptr;
+    MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes * (perm2 ? 2 : 1), &scratch));
+    const unsigned tiles = (unsigned)(n * p->V / msntt::TILE);
     // Two halves of a group on two streams: kernels of different passes then overlap (a pass alternates between a
     // memory phase and an arithmetic phase per workgroup), measured 171 -> 165 us per 2^24 column over 8 columns
     // (scripts/ntt_pass_bench.hip, launch orders).  Not while per-launch profiling is on (its events sit on one stream).
@@ -838,7 +839,10 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 uint64_t* scr = (uint64_t*)((char*)scratch + (size_t)c * col_bytes);
                 P.src[c] = (q == 0) ? (const uint64_t*)src[c0 + c] : scr;
                 P.dst[c] = last ? (uint64_t*)dst[c0 + c] : scr;
-                if (perm && q >= 1) { P.dst[c] = (uint64_t*)dst[c0 + c]; if (q == 2) P.src[c] = (const uint64_t*)dst[c0 + c]; }
+                if (perm2 && q >= 1) {                        // scratch A -> scratch B -> dst
+                    uint64_t* scr_b = (uint64_t*)((char*)scratch_all + (size_t)(group + s0 + c) * col_bytes);
+                    if (q == 1) P.dst[c] = scr_b; else P.src[c] = scr_b;
+                } else if (perm && q >= 1) { P.dst[c] = (uint64_t*)dst[c0 + c]; if (q == 2) P.src[c] = (const uint64_t*)dst[c0 + c]; }
             }
             P.tw_lo = p->d_tw_lo; P.tw_hi = p->d_tw_hi; P.wr = p->d_wr[q];
             P.aux_lo = p->d_aux_lo; P.aux_hi = p->d_aux_hi; P.gtab = p->d_gtab;
