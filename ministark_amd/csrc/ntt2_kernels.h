@@ -168,20 +168,20 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
         #pragma unroll
         for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
     };
-    // Both halves are requested up front when the registers allow it (they do since the second half of the first
-    // networks' results leaves for LDS before the second network runs: ~115 VGPRs); with the load factor the second
-    // half is requested after the first network (measured: 54.0 vs 55.7 us per 2^24 column).
-    constexpr bool EARLY = !LOADQ;
-    load_half(0);
-    if constexpr (EARLY) load_half(1);
-    uint64_t qpl = 0;
-    if constexpr (LOADQ) {
-        const unsigned k1 = ((blockIdx.x % tiles_per_u) * TW + lane) / P.V;
-        qpl = gld::mmul(tw_pow(P, (uint64_t)k1 * digit_rev(P, U)), 1);      // out of Montgomery form: the data keeps its own
+    // Both halves of the tile are requested up front (the registers allow it since the second half of the first networks'
+    // results leaves for LDS before the second network runs).
+    uint64_t qlo = 0, qhi = 0;
+    if constexpr (LOADQ) {                                   // the two table words of w_n^(k1 j3) first: they come back before the
+        const unsigned k1 = ((blockIdx.x % tiles_per_u) * TW + lane) / P.V;              // tile's words and are combined meanwhile
+        const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
+        qlo = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+        qhi = P.tw_hi[e >> P.lo_bits];
     }
+    load_half(0); load_half(1);
+    uint64_t qpl = 0;
+    if constexpr (LOADQ) qpl = gld::mmul(gld::mmul(qlo, qhi), 1);      // out of Montgomery form: the data keeps its own
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        if (!EARLY && h == 1) load_half(1);
         net1<INV, 16, LOADQ ? 2 : 0>(x[h], P, w + 8 * h, qpl);
         #pragma unroll
         for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][j];
