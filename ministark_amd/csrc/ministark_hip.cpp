@@ -808,11 +808,12 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
     void* scratch = nullptr;
     MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes * (perm2 ? 2 : 1), &scratch));
     const unsigned tiles = (unsigned)(n * p->V / msntt::TILE);
-    // Two halves of a group on two streams: kernels of different passes then overlap (a pass alternates between a
-    // memory phase and an arithmetic phase per workgroup), measured 171 -> 165 us per 2^24 column over 8 columns
-    // (scripts/ntt_pass_bench.hip, launch orders).  Not while per-launch profiling is on (its events sit on one stream).
-    static const bool one_stream = getenv("MS_NTT_STREAMS") != nullptr && atoi(getenv("MS_NTT_STREAMS")) == 1;
-    const bool two = !one_stream && !ctx->profiling && ncols >= 2 && group >= 2 && p->log_n >= 20;
+    // MS_NTT_STREAMS=2: the two halves of a group on two streams -- kernels of different passes then overlap (a pass
+    // alternates between a memory phase and an arithmetic phase per workgroup); measured 162 -> 159 us per 2^24 column
+    // over 8 columns.  Off by default: with concurrent kernels the per-kernel durations of a trace no longer add up to the
+    // wall time, and the gain is under 2 %.  Never while per-launch profiling is on (its events sit on one stream).
+    static const bool two_streams = getenv("MS_NTT_STREAMS") != nullptr && atoi(getenv("MS_NTT_STREAMS")) == 2;
+    const bool two = two_streams && !ctx->profiling && ncols >= 2 && group >= 2 && p->log_n >= 20;
     if (two) {
         if (!ctx->stream2) {
             HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));

@@ -50,7 +50,7 @@ if fetch and write:
     total = 0.0
     # the three launches of ONE forward coset transform (bench.py's other variants -- subgroup, inverse -- run in the
     # same process and must not be added in)
-    trio = ("ntt2_first_pass<false, true, 16>", "ntt2_mid_pass<false, false, 0>", "ntt2_mid_pass<false, true, 0>",
+    trio = ("ntt2_first_pass<false, true, 16", "ntt2_mid_pass<false, false, 0", "ntt2_mid_pass<false, true, 0",
             "ntt_first_pass<false, true, 16>", "ntt_mid_pass<16, false, false, 0, false>", "ntt_mid_pass<16, false, true, 0, false>")
     for k in fc:
         if "msntt" not in k or not any(t in k for t in trio):

@@ -73,8 +73,20 @@ def test_lde_bit_reversed_limb_last_pass_emu():
 
 
 def test_column_group_on_two_streams_emu():
-    # >= 2 columns of >= 2^20 points are split over two streams, [0, n/2) and [n/2, n): an odd count exercises both ranges
-    _run("emu", GOLDILOCKS_FP, 20, False, 7, ncols=3)
+    # MS_NTT_STREAMS=2 splits >= 2 columns of >= 2^20 points over two streams, [0, n/2) and [n/2, n): an odd count
+    # exercises both ranges.  The switch is read once per process, so this runs in a child interpreter.
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r); import tests.test_ntt_parity as t; "
+            "t._run('emu', t.GOLDILOCKS_FP, 20, False, 7, ncols=3)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, MS_NTT_STREAMS="2"))
+
+
+@pytest.mark.gpu
+def test_column_group_on_two_streams_hip():
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r); import tests.test_ntt_parity as t; "
+            "t._run('hip', t.GOLDILOCKS_FP, 22, False, 7, ncols=3); t._run('hip', t.GOLDILOCKS_FP, 24, True, 1, ncols=2)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, MS_NTT_STREAMS="2"))
 
 
 @pytest.mark.parametrize("log_b", [2, 3])
