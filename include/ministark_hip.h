@@ -83,6 +83,10 @@ int ms_download(ms_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* b
  *     h_group_gen domain.group_gen, Montgomery form, or NULL.  When given it must equal
  *                 arkworks' get_root_of_unity(n) (the only root the kernels' constants are
  *                 built for); otherwise MS_ERR_UNSUPPORTED.
+ *     The twiddle tables of a (field, size, direction, offset) are built once per context: the object returned
+ *     is a handle (own queue) on the context's cached plan, so constructing a GpuFft per call, as the reference's
+ *     callers do (src/matrix.rs:119-131), costs no table build or upload after the first.  Destroy handles before
+ *     the context.  (Goldilocks fields; an Fp252 plan owns its tables.)
  * ms_ntt_encode        = fft.encode(&mut column): queue one column (n elements, in place)
  * ms_ntt_execute       = fft.execute(): run every queued column, BLOCKS, clears the queue
  *                        (the plan stays usable; the reference consumes it)
