@@ -331,10 +331,34 @@ def main():
     prof = pl.profile_read()
     pl.profile(False)
 
+    # The column-sharded LDE + commitment runs on every rank (RCCL inside the library).  It is guarded: the headline
+    # measurement above is complete at this point, so if the exchange raises -- or hangs: N > 1 has never run on
+    # physical GPUs from this repository -- rank 0 still prints its line (with the error recorded) instead of the whole
+    # run being lost to the driver's timeout.
     sharded = None
-    if not args.no_extras:
-        sharded = run_sharded()                                  # every rank takes part
+    state = {"line": None}
+
+    def run_sharded_guarded():
+        import threading
+
+        def bail():
+            if rank == 0 and state["line"] is not None:
+                state["line"]["sharded_lde_commit"] = {"error": "timed out after 180 s (collective did not complete)", "n_gpus": world}
+                print(json.dumps(state["line"]), flush=True)
+            os._exit(0 if state["line"] is not None or rank != 0 else 1)
+        timer = threading.Timer(180.0, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            return run_sharded()
+        except Exception as e:                                   # noqa: BLE001 -- recorded on the line, the headline stands
+            return {"error": f"{type(e).__name__}: {e}", "n_gpus": world}
+        finally:
+            timer.cancel()
+
     if rank != 0:
+        if not args.no_extras:
+            run_sharded_guarded()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -391,6 +415,9 @@ def main():
             variants[name + "_us_per_transform"] = round((time.perf_counter() - t1) / 5 / args.cols * 1e6, 2)
             plan.close()
         out["variants"] = variants
+    if not args.no_extras:
+        state["line"] = dict(out)                                # what rank 0 prints if the exchange never returns
+        sharded = run_sharded_guarded()                          # every rank takes part
     if sharded is not None:
         out["sharded_lde_commit"] = sharded
     if world == 1 and not args.no_extras:
