@@ -37,6 +37,10 @@ struct Params {
     const uint64_t* tw_lo;     // w_N^e two-level (Montgomery), lo_bits low bits
     const uint64_t* tw_hi;
     const uint64_t* t2;        // pass B: [k][t] w_L^(k t) Montgomery, 256 x T
+    // UNI (T >= 4): pass A's inter-pass factor (G w_n^k1)^i0, i0 = 64 i0h + t, split as in ntt2_first_pass<.., UNI>:
+    const uint64_t* tin4;      // pass A: [i0h][b][a'] w_256^(a' b) w_n^(a' 64 i0h), 4 plain copies     (between the networks)
+    const uint64_t* tout4;     // pass A: [j][i0h][b'] G_j^(64 i0h) w_n^(16 b' 64 i0h), 4 plain copies   (after the second network)
+                               // pass B applies (G_j w_n^k1)^t, one value per lane and (wave, half), on its loads
     unsigned log_n, log_b, lo_bits;   // n = 2^log_n points per coset, beta = 2^log_b cosets
 };
 
@@ -47,18 +51,22 @@ __device__ __forceinline__ uint64_t twn_pow(const Params& P, uint64_t e) {      
     return hi_i ? gld::mmul(lo, P.tw_hi[hi_i]) : lo;
 }
 
-// first network of a pass on 16 loaded words (rows 16 a + b): optional uniform input scale, DFT16, times w_256^(a' b)
-template <bool SCALE>
-__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, const uint64_t* gpl_j) {
+// first network of a pass on 16 loaded words (rows 16 a + b): input scale, DFT16, times w_256^(a' b)
+//   IN 0: none; 1: the wave-uniform gpl_j[16 a + b] (pass A); 2: the per-lane q (pass B under UNI)
+//   UNI: the factor after the network comes from tin4 at slot tslot + a' instead of wr4
+template <int IN, bool UNI = false>
+__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, const uint64_t* gpl_j, uint64_t q = 0, unsigned tslot = 0) {
     glimb::L4 v[16];
     #pragma unroll
     for (int a = 0; a < 16; a++) {
-        if constexpr (SCALE) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)gpl_j)[16 * a + b]);
+        if constexpr (IN == 1) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)gpl_j)[16 * a + b]);
+        else if constexpr (IN == 2) v[a] = glimb::mul_to_limbs(x[a], q);
         else v[a] = glimb::from_u64(x[a]);
     }
+    auto tw = [&](int c) { return UNI ? w4_at(P.tin4, tslot + c) : w4_at(P.wr4, (b * c) & 255); };
     glimb::W4 wn[4];                            // the first group's factors are requested before the network (as msntt2::net1)
     #pragma unroll
-    for (int j = 0; j < 4; j++) wn[j] = w4_at(P.wr4, (b * j) & 255);
+    for (int j = 0; j < 4; j++) wn[j] = tw(j);
     __builtin_amdgcn_sched_barrier(0);
     glimb::dft<16, false>(v);
     __builtin_amdgcn_sched_barrier(0);
@@ -69,7 +77,7 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
         for (int j = 0; j < 4; j++) wc[j] = wn[j];
         if (g < 3) {
             #pragma unroll
-            for (int j = 0; j < 4; j++) wn[j] = w4_at(P.wr4, (b * (4 * (g + 1) + j)) & 255);
+            for (int j = 0; j < 4; j++) wn[j] = tw(4 * (g + 1) + j);
         }
         __builtin_amdgcn_sched_barrier(0);
         #pragma unroll
@@ -79,13 +87,15 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
 }
 
 // ---- pass A ----------------------------------------------------------------------------------------------------------
-// grid = (L / 64, columns, beta): coefficients src[col][i1 L + i0] -> dst[col][j n + k1 L + i0]
+// grid = (L / 64, beta, columns): coefficients src[col][i1 L + i0] -> dst[col][j n + k1 L + i0].  The cosets of a column are
+// adjacent in dispatch order, so its coefficients (read beta times) come from L2 / the Infinity Cache after the first read.
+template <bool UNI>
 __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
-    const uint64_t* __restrict__ src = P.src[blockIdx.y];
-    const unsigned j = blockIdx.z;
+    const uint64_t* __restrict__ src = P.src[blockIdx.z];
+    const unsigned j = blockIdx.y;
     const size_t n = (size_t)1 << P.log_n, L = n >> 8;
-    uint64_t* __restrict__ dst = P.dst[blockIdx.y] + (size_t)j * n;
+    uint64_t* __restrict__ dst = P.dst[blockIdx.z] + (size_t)j * n;
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t i0 = (size_t)blockIdx.x * TW + lane;
@@ -101,7 +111,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     }
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        net1<true>(x[h], P, w + 8 * h, gpl_j);
+        net1<1, UNI>(x[h], P, w + 8 * h, gpl_j, 0, (blockIdx.x * 16 + w + 8 * h) * 16);
         #pragma unroll
         for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
         __builtin_amdgcn_sched_barrier(0);
@@ -124,21 +134,42 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
         #pragma unroll
         for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(y[b]);
         glimb::dft<16, false>(v);
-        uint64_t z[16];
-        #pragma unroll
-        for (int d = 0; d < 16; d++) {
-            z[d] = pin(glimb::to_weak(v[d]));
-            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        // (G w_n^k1)^i0 for k1 = a' + 16 d: A B^d with A = G^i0 w_n^(i0 a'), B = w_n^(16 i0)   (i0 k1 < n: no wrap)
-        const uint64_t B = twn_pow(P, (uint64_t)i0 * 16);
-        uint64_t tw = gld::mmul(twn_pow(P, (uint64_t)i0 * ap), P.aux[(size_t)j * L + i0]);
         uint64_t* q = dst + (size_t)ap * L + i0;
-        #pragma unroll
-        for (int d = 0; d < 16; d++, q += step) {
-            *q = gld::mmul(z[d], tw);
-            if (d < 15) tw = gld::mmul(tw, B);
-            if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (UNI) {
+            const unsigned slot0 = ((j * (unsigned)(L >> 6)) + blockIdx.x) * 16;
+            glimb::W4 wn[4];
+            #pragma unroll
+            for (int e = 0; e < 4; e++) wn[e] = w4_at(P.tout4, slot0 + e);
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                glimb::W4 wc[4];
+                #pragma unroll
+                for (int e = 0; e < 4; e++) wc[e] = wn[e];
+                if (g < 3) {
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) wn[e] = w4_at(P.tout4, slot0 + 4 * (g + 1) + e);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                #pragma unroll
+                for (int e = 0; e < 4; e++, q += step) *q = glimb::mul_fold(v[4 * g + e], wc[e]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            uint64_t z[16];
+            #pragma unroll
+            for (int d = 0; d < 16; d++) {
+                z[d] = pin(glimb::to_weak(v[d]));
+                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // (G w_n^k1)^i0 for k1 = a' + 16 d: A B^d with A = G^i0 w_n^(i0 a'), B = w_n^(16 i0)   (i0 k1 < n: no wrap)
+            const uint64_t B = twn_pow(P, (uint64_t)i0 * 16);
+            uint64_t tw = gld::mmul(twn_pow(P, (uint64_t)i0 * ap), P.aux[(size_t)j * L + i0]);
+            #pragma unroll
+            for (int d = 0; d < 16; d++, q += step) {
+                *q = gld::mmul(z[d], tw);
+                if (d < 15) tw = gld::mmul(tw, B);
+                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
@@ -150,7 +181,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
 // network, and a last trip through LDS so that the stores are runs of consecutive words.
 // grid = (256 T / 64, columns, beta)          [64 / T rows per workgroup, 256 rows per coset]
 static constexpr int X2P = 65;                               // pitch of the second exchange (words): conflict-free both ways
-template <int T>
+template <int T, bool UNI>
 __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     constexpr int LOGT = T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
     constexpr int RSEL = 64 / T;                             // rows per workgroup
@@ -168,13 +199,24 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     const unsigned jr = P.log_b ? __brev(j) >> (32 - P.log_b) : 0;     // block of coset j in the bit-reversed order
     uint64_t* __restrict__ dst = P.dst[blockIdx.y] + (size_t)jr * n;
 
+    // UNI: the part of pass A's factor that is per lane there, (G_j w_n^k1)^(i0 & 63), is one value per lane and half here
+    // (k1 = this lane's row; i0 & 63 = ((b & (64 / T - 1)) T + t, b = w + 8 h): the 128-bit product replaces the conversion
+    uint64_t qh[2] = {0, 0};
+    if constexpr (UNI) {
+        static_assert(!UNI || T >= 4, "i0 & 63 must not reach the register digit a");
+        #pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned tl = ((w + 8 * h) & (64 / T - 1)) * T + t, k1 = row0 + rs;
+            qh[h] = gld::mmul(gld::mmul(twn_pow(P, (uint64_t)k1 * tl), P.aux[(size_t)j * L + tl]), 1);
+        }
+    }
     uint64_t x[2][16];
     #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint64_t* p = src + (size_t)(w + 8 * h) * T;
         #pragma unroll
         for (int a = 0; a < 16; a++) { x[h][a] = *p; p += 16 * T; }
-        net1<false>(x[h], P, w + 8 * h, nullptr);
+        net1<UNI ? 2 : 0>(x[h], P, w + 8 * h, nullptr, qh[h]);
         #pragma unroll
         for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
         __builtin_amdgcn_sched_barrier(0);

@@ -330,7 +330,7 @@ struct ms_ntt_plan {
     uint64_t *d_tin4 = nullptr, *d_tout4 = nullptr;
     // two-pass coset LDE (lde2_kernels.h), built on first use on the forward plan of the LDE domain: per blow-up
     // [gpl | aux | t2] in one allocation
-    struct Lde2 { unsigned log_b = 0; uint64_t *d = nullptr, *gpl = nullptr, *aux = nullptr, *t2 = nullptr; };
+    struct Lde2 { unsigned log_b = 0; uint64_t *d = nullptr, *gpl = nullptr, *aux = nullptr, *t2 = nullptr, *tin4 = nullptr, *tout4 = nullptr; };
     std::vector<Lde2> lde2;
     uint64_t offset_canon = 1;          // the coset offset h (canonical)
     std::vector<void*> queue;
@@ -965,10 +965,35 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
     for (auto& l : fwd->lde2) if (l.log_b == log_b) { *out = &l; return MS_OK; }
     const size_t n = (size_t)1 << log_n, L = n >> 8, T = L >> 8, beta = (size_t)1 << log_b;
     const uint64_t wN = gl::root_of_unity(log_n + log_b), wL = gl::root_of_unity(log_n - 8), h = fwd->offset_canon;
-    std::vector<uint64_t> host(beta * 256 + beta * L + 256 * T);
+    const bool uni = T >= 4;                                      // lde2_kernels.h: uniform split of pass A's factor
+    const size_t nt = L >> 6, n_tin = uni ? nt * 256 * 4 : 0, n_tout = uni ? beta * nt * 16 * 4 : 0;
+    std::vector<uint64_t> host(beta * 256 + beta * L + 256 * T + n_tin + n_tout);
     uint64_t* gpl = host.data();
     uint64_t* aux = gpl + beta * 256;
     uint64_t* t2 = aux + beta * L;
+    uint64_t* tin4 = t2 + 256 * T;
+    uint64_t* tout4 = tin4 + n_tin;
+    if (uni) {
+        const uint64_t wn = gl::root_of_unity(log_n);
+        const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
+        for (size_t i0h = 0; i0h < nt; i0h++) {
+            const uint64_t E = 64 * i0h;
+            for (size_t b = 0; b < 16; b++) {
+                const uint64_t wm = gl::pow(wn, (b * L + E) & (n - 1));          // w_256^b w_n^E
+                uint64_t x = 1;
+                for (size_t a = 0; a < 16; a++, x = gl::mul(x, wm))
+                    for (int c = 0; c < 4; c++) tin4[((i0h * 16 + b) * 16 + a) * 4 + c] = gl::mul(x, sh[c]);
+            }
+        }
+        uint64_t G = h;
+        for (size_t j = 0; j < beta; j++, G = gl::mul(G, wN))
+            for (size_t i0h = 0; i0h < nt; i0h++) {
+                const uint64_t E = 64 * i0h, wm = gl::pow(wn, (16 * E) & (n - 1));
+                uint64_t x = gl::pow(G, E);
+                for (size_t bp = 0; bp < 16; bp++, x = gl::mul(x, wm))
+                    for (int c = 0; c < 4; c++) tout4[((j * nt + i0h) * 16 + bp) * 4 + c] = gl::mul(x, sh[c]);
+            }
+    }
     uint64_t G = h;                                               // G_j = h w_N^j
     for (size_t j = 0; j < beta; j++, G = gl::mul(G, wN)) {
         const uint64_t GL = gl::pow(G, (uint64_t)L);
@@ -987,6 +1012,7 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
     if (hipMalloc(&l.d, host.size() * 8) != hipSuccess) return fail(MS_ERR_NOMEM, "LDE tables (%zu bytes)", host.size() * 8);
     if (hipMemcpy(l.d, host.data(), host.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(l.d); return fail(MS_ERR_HIP, "LDE table upload"); }
     l.gpl = l.d; l.aux = l.d + beta * 256; l.t2 = l.aux + beta * L;
+    if (uni) { l.tin4 = l.t2 + 256 * T; l.tout4 = l.tin4 + n_tin; }
     fwd->lde2.push_back(l);
     *out = &fwd->lde2.back();
     return MS_OK;
@@ -1008,22 +1034,26 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
         const unsigned nc = std::min(group, ncols - c0);
         mslde2::Params P;
         memset(&P, 0, sizeof P);
-        P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2;
+        P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2; P.tin4 = tb->tin4; P.tout4 = tb->tout4;
+        static const bool no_uni = getenv("MS_LDE2_PERLANE") != nullptr && atoi(getenv("MS_LDE2_PERLANE")) != 0;    // A/B measurements
+        const bool uni = tb->tin4 != nullptr && !no_uni;
         P.tw_lo = fwd->d_tw_lo; P.tw_hi = fwd->d_tw_hi; P.lo_bits = fwd->lo_bits; P.log_n = log_n; P.log_b = log_b;
         for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)src[c0 + c]; P.dst[c] = (uint64_t*)((char*)scratch + (size_t)c * col_bytes); }
         {
             ProfScope ps(ctx, "lde2_pass_a", (double)(n * 8 + col_bytes) * nc);
-            hipLaunchKernelGGL(mslde2::lde2_strided_pass, dim3((unsigned)(n >> 14), nc, 1u << log_b), dim3(msntt2::NT), 0, st, P);
+            const dim3 ga((unsigned)(n >> 14), 1u << log_b, nc);
+            if (uni) hipLaunchKernelGGL(mslde2::lde2_strided_pass<true>, ga, dim3(msntt2::NT), 0, st, P);
+            else hipLaunchKernelGGL(mslde2::lde2_strided_pass<false>, ga, dim3(msntt2::NT), 0, st, P);
         }
         for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)((char*)scratch + (size_t)c * col_bytes); P.dst[c] = (uint64_t*)dst[c0 + c]; }
         {
             ProfScope ps(ctx, "lde2_pass_b", 2.0 * col_bytes * nc);
             const dim3 g(4 * T, nc, 1u << log_b), b(msntt2::NT);
             switch (T) {
-            case 16: hipLaunchKernelGGL(mslde2::lde2_rows_pass<16>, g, b, 0, st, P); break;
-            case 8: hipLaunchKernelGGL(mslde2::lde2_rows_pass<8>, g, b, 0, st, P); break;
-            case 4: hipLaunchKernelGGL(mslde2::lde2_rows_pass<4>, g, b, 0, st, P); break;
-            default: hipLaunchKernelGGL(mslde2::lde2_rows_pass<2>, g, b, 0, st, P); break;
+            case 16: if (uni) hipLaunchKernelGGL((mslde2::lde2_rows_pass<16, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<16, false>), g, b, 0, st, P); break;
+            case 8: if (uni) hipLaunchKernelGGL((mslde2::lde2_rows_pass<8, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<8, false>), g, b, 0, st, P); break;
+            case 4: if (uni) hipLaunchKernelGGL((mslde2::lde2_rows_pass<4, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<4, false>), g, b, 0, st, P); break;
+            default: hipLaunchKernelGGL((mslde2::lde2_rows_pass<2, false>), g, b, 0, st, P); break;
             }
         }
     }

@@ -318,7 +318,9 @@ def test_lde_fq3_emu():
     _lde("emu", GOLDILOCKS_FP, 10, 2, bit_reversed=False)
 
 
-@pytest.mark.parametrize("log_n,log_b,bit_reversed", [(17, 1, True), (17, 2, False)])
+@pytest.mark.parametrize("log_n,log_b,bit_reversed", [(17, 1, True), (17, 2, False),
+                                                      # T = 4, 8, 16: the uniform split of pass A's factor (per-lane remainder in pass B)
+                                                      (18, 2, True), (19, 1, True), (20, 1, False)])
 def test_lde_two_pass_cosets_emu(log_n, log_b, bit_reversed):
     """lde2_kernels.h (columns of 2^17..2^20 rows: beta coset transforms in two passes each), smallest size, T = 2."""
     _lde("emu", GOLDILOCKS_FP, log_n, log_b, ncols=2, bit_reversed=bit_reversed)
