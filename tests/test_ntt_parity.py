@@ -67,6 +67,14 @@ def test_uniform_interpass_factor_emu(field, log_n, inverse, offset):
     _run("emu", field, log_n, inverse, offset)
 
 
+@pytest.mark.parametrize("field,log_n,log_b,bit_reversed", [(GOLDILOCKS_FQ3, 18, 4, True), (GOLDILOCKS_FQ3, 19, 3, False),
+                                                            (GOLDILOCKS_FP, 21, 1, True)])
+def test_uniform_interpass_factor_pruned_variants_emu(field, log_n, log_b, bit_reversed):
+    # 2^22-point LDE domains that do not take the two-pass coset form: Fq3 with one / two non-zero inputs per first
+    # network (blow-up 16 / 8), Fp with blow-up 2 (memset + full transform + bit reversal)
+    _lde("emu", field, log_n, log_b, ncols=1, bit_reversed=bit_reversed)
+
+
 def test_lde_bit_reversed_limb_last_pass_emu():
     # a 2^24-point LDE domain = (8, 8, 8): pruned uniform-factor pass 1, load-factor pass 2, ntt2_last_pass_bitrev
     _lde("emu", GOLDILOCKS_FP, 22, 2, ncols=1)
