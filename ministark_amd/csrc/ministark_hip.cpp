@@ -323,7 +323,7 @@ struct ms_ntt_plan {
     // limb-form passes (ntt2_kernels.h): plain tables of 4 pre-shifted copies per twiddle
     uint64_t* d_wr4[4] = {nullptr, nullptr, nullptr, nullptr};    // radix-256 passes: w_256^e
     uint64_t* d_twu4[4] = {nullptr, nullptr, nullptr, nullptr};   // middle passes: per-tile factor [U][k]
-    uint64_t *d_sc4 = nullptr, *d_g_plain = nullptr;
+    uint64_t *d_sc4 = nullptr, *d_g_plain = nullptr, *d_scu4 = nullptr;
     // three-pass plans with a last radix >= 64: pass 1's inter-pass factor from wave-uniform tables, the per-lane
     // remainder applied by pass 2 on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
     bool uni = false;
@@ -565,7 +565,8 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
     // ... except the tables of the limb-form passes (ntt2_kernels.h): plain residues, four copies
     // {w, w 2^24, w 2^48, w 2^72} per twiddle, appended after the conversion
     size_t off_wr4[4] = {0, 0, 0, 0}, off_twu4[4] = {0, 0, 0, 0}, off_sc4 = 0, off_gp = 0, off_tin4 = 0, off_tout4 = 0;
-    bool has_wr4[4] = {false, false, false, false}, has_twu4[4] = {false, false, false, false}, has_gp = false;
+    bool has_wr4[4] = {false, false, false, false}, has_twu4[4] = {false, false, false, false}, has_gp = false, has_scu4 = false;
+    size_t off_scu4 = 0;
     // MS_NTT2_PERLANE=1 keeps pass 1's per-lane running product (A/B measurements); MS_NTT_V1=1 the round-1 kernels
     static const bool no_uni = (getenv("MS_NTT2_PERLANE") != nullptr && atoi(getenv("MS_NTT2_PERLANE")) != 0) ||
                                (getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0);
@@ -599,6 +600,9 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             }
         }
         t.assign(1, ninv); off_sc4 = append4(t);
+        if (p->scale_mode == 2 && p->lr[p->npass - 1] == 8) {      // inverse coset, last radix 256: h^-(k 2^log_s) per output row
+            powers(t, 256, gl::pow(hinv, (uint64_t)1 << p->log_s[p->npass - 1])); off_scu4 = append4(t); has_scu4 = true;
+        }
         if (p->uni) {
             // pass 1: tin4[j2][b][a'] = w_256^(a' b) w_n^(a' R3 j2) = w_n^(a' (b n/256 + R3 j2));
             //         tout4[j2][b'] = h^(R3 j2) w_n^(16 b' R3 j2)      (h = 1 unless this is a forward coset transform)
@@ -642,6 +646,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             if (has_twu4[q]) p->d_twu4[q] = p->d_tables + off_twu4[q];
         }
         p->d_sc4 = p->d_tables + off_sc4;
+        if (has_scu4) p->d_scu4 = p->d_tables + off_scu4;
         if (p->uni) { p->d_tin4 = p->d_tables + off_tin4; p->d_tout4 = p->d_tables + off_tout4; }
         if (has_gp) p->d_g_plain = p->d_tables + off_gp;
     }
@@ -857,6 +862,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             // limb-form radix-256 passes (ntt2_kernels.h) wherever a pass has radix 256 and rows of >= 64 words;
             // MS_NTT_V1=1 keeps the round-1 kernels (A/B measurements)
             static const bool force_v1 = getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0;
+            static const bool no_sc2 = getenv("MS_NTT2_COSET_SCALE") != nullptr && atoi(getenv("MS_NTT2_COSET_SCALE")) == 0;   // A/B: round-1 scale walk
             static const bool no_br2 = getenv("MS_NTT2_BITREV") != nullptr && atoi(getenv("MS_NTT2_BITREV")) == 0;   // A/B: round-1 fused bit reversal
             const size_t pass_sw = ((size_t)1 << p->log_s[q]) * p->V;
             // (the per-element scale walk of an inverse coset transform stays with the round-1 last pass: the walk is two table
@@ -864,7 +870,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             // column; so does the fused bit-reversed store of Fq3 columns, whose runs interleave three words)
             const bool v2_ok = !force_v1 && p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
                                (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0
-                                       : (pass_sw % msntt2::TW == 0 && !(last && p->scale_mode == 2) &&
+                                       : (pass_sw % msntt2::TW == 0 && !(last && p->scale_mode == 2 && (p->d_scu4 == nullptr || no_sc2)) &&
                                           !(last && bitrev_out && (p->V != 1 || p->inverse || p->scale_mode != 0 || no_br2))));
             static const bool dbg = getenv("MS_NTT_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? (p->uni && q < 2 ? "limb-form (ntt2), uniform inter-pass factor" : "limb-form (ntt2)") : "round-1");
@@ -873,7 +879,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 msntt2::Params Q;
                 memset(&Q, 0, sizeof Q);
                 for (unsigned c = 0; c < nc; c++) { Q.src[c] = P.src[c]; Q.dst[c] = P.dst[c]; }
-                Q.wr4 = p->d_wr4[q]; Q.twu4 = p->d_twu4[q]; Q.sc4 = p->d_sc4; Q.g_plain = p->d_g_plain;
+                Q.wr4 = p->d_wr4[q]; Q.twu4 = p->d_twu4[q]; Q.sc4 = p->d_sc4; Q.scu4 = p->d_scu4; Q.g_plain = p->d_g_plain;
                 Q.tw_lo = p->d_tw_lo; Q.tw_hi = p->d_tw_hi; Q.aux_lo = p->d_aux_lo; Q.aux_hi = p->d_aux_hi;
                 Q.log_n = p->log_n; Q.V = p->V; Q.valid_rows = valid_rows; Q.lo_bits = p->lo_bits; Q.log_s = p->log_s[q];
                 Q.tin4 = p->d_tin4; Q.tout4 = p->d_tout4; Q.r3 = p->lr[2];
@@ -913,7 +919,8 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 } else {
                     const int scale = p->scale_mode;
                     if (p->inverse) {
-                        if (scale == 1) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 1>), g2, b2, 0, st, Q);
+                        if (scale == 2) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 2>), g2, b2, 0, st, Q);
+                        else if (scale == 1) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 1>), g2, b2, 0, st, Q);
                         else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 0>), g2, b2, 0, st, Q);
                     } else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, st, Q);
                 }

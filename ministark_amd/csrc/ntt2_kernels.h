@@ -43,6 +43,7 @@ struct Params {
     const uint64_t* wr4;       // w_256^e, e < 256                      (between the two networks)
     const uint64_t* twu4;      // middle pass: [U][k], w_n^((rev(U) k) << log_s)   (after the second network)
     const uint64_t* sc4;       // last pass, SCALE 1: the constant n^-1 (4 copies)
+    const uint64_t* scu4;      // last pass, SCALE 2: [k] h^-(k 2^log_s), k < 256 (4 copies): the row part of the coset scale
     const uint64_t* g_plain;   // pass 1 coset: g^j1 plain, j1 < 256
     // uniform inter-pass factor of a three-pass plan (UNI kernels, see ntt2_first_pass):
     const uint64_t* tin4;      // pass 1: [j2][b][a'] w_256^(a' b) w_n^(a' R3 j2)            (between the two networks)
@@ -131,7 +132,9 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, u
 
 // ---- middle / last pass, radix 256 ---------------------------------------------------------------------
 // grid = (n V / 16384, columns); rows at stride sw = 2^log_s V words (>= 64), tile = 64 consecutive words.
-// SCALE (last pass): 0 none, 1 the constant in sc4 (n^-1 of an inverse transform on the subgroup).
+// SCALE (last pass): 0 none, 1 the constant in sc4 (n^-1 of an inverse transform on the subgroup), 2 the inverse coset
+//   transform's n^-1 h^-pos, pos = k 2^log_s + low: n^-1 h^-low is one value per lane and tile (it does not depend on the
+//   row), applied on the loads like LOADQ's factor; h^-(k 2^log_s) is wave-uniform per output row (scu4).
 // LOADQ (pass 2 of a three-pass plan whose pass 1 is the UNI kernel): every word is multiplied on the way in by
 //   w_n^(k1 j3), k1 = the lane's position in the row, j3 = this tile's block -- the part of the inter-pass factor
 //   (h w_n^k1)^(R3 j2 + j3) that pass 1 cannot apply with wave-uniform operands.  It is one value per lane and tile,
@@ -171,6 +174,12 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     // Both halves of the tile are requested up front (the registers allow it since the second half of the first networks'
     // results leaves for LDS before the second network runs).
     uint64_t qlo = 0, qhi = 0;
+    if constexpr (SCALE == 2) {
+        static_assert(SCALE != 2 || (LAST && !LOADQ), "the coset scale belongs to the last pass");
+        const uint64_t e = (blockIdx.x * (uint64_t)TW + lane) / P.V;      // the element this lane's words belong to (U = 0)
+        qlo = P.aux_lo[e & ((1u << P.lo_bits) - 1)];
+        qhi = P.aux_hi[e >> P.lo_bits];
+    }
     if constexpr (LOADQ) {                                   // the two table words of w_n^(k1 j3) first: they come back before the
         const unsigned k1 = ((blockIdx.x % tiles_per_u) * TW + lane) / P.V;              // tile's words and are combined meanwhile
         const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
@@ -179,10 +188,10 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     }
     load_half(0); load_half(1);
     uint64_t qpl = 0;
-    if constexpr (LOADQ) qpl = gld::mmul(gld::mmul(qlo, qhi), 1);      // out of Montgomery form: the data keeps its own
+    if constexpr (LOADQ || SCALE == 2) qpl = gld::mmul(gld::mmul(qlo, qhi), 1);      // out of Montgomery form: the data keeps its own
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        net1<INV, 16, LOADQ ? 2 : 0>(x[h], P, w + 8 * h, qpl);
+        net1<INV, 16, (LOADQ || SCALE == 2) ? 2 : 0>(x[h], P, w + 8 * h, qpl);
         #pragma unroll
         for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][j];
         __builtin_amdgcn_sched_barrier(0);
@@ -234,6 +243,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
                 uint64_t val;
                 if constexpr (!LAST) val = glimb::mul_fold<false>(v[d], wc[j]);       // a weak residue: every pass accepts any 64-bit representative
                 else if constexpr (SCALE == 1) val = glimb::mul_fold<true>(v[d], w4_at(P.sc4, 0));
+                else if constexpr (SCALE == 2) val = glimb::mul_fold<true>(v[d], w4_at(P.scu4, ap + 16 * d));
                 else val = glimb::to_canon(v[d]);
                 dst[pos] = val;
             }

@@ -75,6 +75,12 @@ def test_uniform_interpass_factor_pruned_variants_emu(field, log_n, log_b, bit_r
     _lde("emu", field, log_n, log_b, ncols=1, bit_reversed=bit_reversed)
 
 
+def test_inverse_coset_scale_in_limb_last_pass_emu():
+    # last radix 256 (2^16, 2^24): n^-1 h^-pos as a per-lane constant on the loads and a wave-uniform row factor
+    _run("emu", GOLDILOCKS_FP, 16, True, 7, ncols=2)
+    _run("emu", GOLDILOCKS_FQ3, 16, True, 7, ncols=1)
+
+
 def test_lde_bit_reversed_limb_last_pass_emu():
     # a 2^24-point LDE domain = (8, 8, 8): pruned uniform-factor pass 1, load-factor pass 2, ntt2_last_pass_bitrev
     _lde("emu", GOLDILOCKS_FP, 22, 2, ncols=1)
