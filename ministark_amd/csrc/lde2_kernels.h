@@ -27,6 +27,7 @@ using msntt2::TW;
 using msntt2::cptr_t;
 using msntt2::pin;
 using msntt2::w4_at;
+using msntt2::w4x4_at;
 
 struct Params {
     const uint64_t* src[MAXC];
@@ -63,22 +64,27 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
         else if constexpr (IN == 2) v[a] = glimb::mul_to_limbs(x[a], q);
         else v[a] = glimb::from_u64(x[a]);
     }
-    auto tw = [&](int c) { return UNI ? w4_at(P.tin4, tslot + c) : w4_at(P.wr4, (b * c) & 255); };
+    auto tw4 = [&](int c0, glimb::W4* o) {      // four factors: consecutive slots under UNI (two wide scalar loads)
+        if constexpr (UNI) w4x4_at(P.tin4, tslot + c0, o);
+        else {
+            #pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = w4_at(P.wr4, (b * (c0 + j)) & 255);
+        }
+    };
     glimb::W4 wn[4];                            // the first group's factors are requested before the network (as msntt2::net1)
-    #pragma unroll
-    for (int j = 0; j < 4; j++) wn[j] = tw(j);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IN != 1) {                    // ... unless 16 input scales already sit in scalar registers (spills otherwise)
+        tw4(0, wn);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     glimb::dft<16, false>(v);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IN == 1) tw4(0, wn);
     #pragma unroll
     for (int g = 0; g < 4; g++) {
         glimb::W4 wc[4];
         #pragma unroll
         for (int j = 0; j < 4; j++) wc[j] = wn[j];
-        if (g < 3) {
-            #pragma unroll
-            for (int j = 0; j < 4; j++) wn[j] = tw(4 * (g + 1) + j);
-        }
+        if (g < 3) tw4(4 * (g + 1), wn);
         __builtin_amdgcn_sched_barrier(0);
         #pragma unroll
         for (int j = 0; j < 4; j++) x[4 * g + j] = pin(glimb::mul_fold(v[4 * g + j], wc[j]));
@@ -137,18 +143,10 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
         uint64_t* q = dst + (size_t)ap * L + i0;
         if constexpr (UNI) {
             const unsigned slot0 = ((j * (unsigned)(L >> 6)) + blockIdx.x) * 16;
-            glimb::W4 wn[4];
             #pragma unroll
-            for (int e = 0; e < 4; e++) wn[e] = w4_at(P.tout4, slot0 + e);
-            #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < 4; g++) {                     // four factors at a time (more of them in flight spill scalar registers)
                 glimb::W4 wc[4];
-                #pragma unroll
-                for (int e = 0; e < 4; e++) wc[e] = wn[e];
-                if (g < 3) {
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) wn[e] = w4_at(P.tout4, slot0 + 4 * (g + 1) + e);
-                }
+                w4x4_at(P.tout4, slot0 + 4 * g, wc);
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
                 for (int e = 0; e < 4; e++, q += step) *q = glimb::mul_fold(v[4 * g + e], wc[e]);

@@ -81,10 +81,43 @@ typedef const __attribute__((address_space(4))) uint64_t* cptr_t;
 #else
 typedef const uint64_t* cptr_t;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// One 32-byte scalar load (s_load_dwordx8).  Written as a vector load on purpose: from four 64-bit loads the compiler
+// sometimes builds four overlapping s_load_dwordx4 (16 scalar registers per factor), which spills scalar registers into
+// vector lanes -- 472 v_readlane / v_writelane per lane and tile in lde2_strided_pass before this.
 __device__ __forceinline__ glimb::W4 w4_at(const uint64_t* t, unsigned slot) {
-    cptr_t p = (cptr_t)(t + 4 * (size_t)slot);
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8), aligned(8)));
+    const u32x8 v = *(const __attribute__((address_space(4))) u32x8*)(t + 4 * (size_t)slot);
+    glimb::W4 r;
+    r.lo[0] = v[0]; r.hi[0] = v[1]; r.lo[1] = v[2]; r.hi[1] = v[3];
+    r.lo[2] = v[4]; r.hi[2] = v[5]; r.lo[3] = v[6]; r.hi[3] = v[7];
+    return r;
+}
+#else
+MS_HD glimb::W4 w4_at(const uint64_t* t, unsigned slot) {
+    const uint64_t* p = t + 4 * (size_t)slot;
     return glimb::w4_from(p[0], p[1], p[2], p[3]);
 }
+#endif
+
+// Four consecutive table slots (128 bytes) as two s_load_dwordx16.  Consecutive w4_at calls are not left alone by the
+// compiler: it widens EACH of them to a dwordx16 that also fetches its neighbour (16 scalar registers per factor).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void w4x4_at(const uint64_t* t, unsigned slot, glimb::W4* out) {
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16), aligned(8)));
+    const __attribute__((address_space(4))) u32x16* p = (const __attribute__((address_space(4))) u32x16*)(t + 4 * (size_t)slot);
+    const u32x16 a = p[0], b = p[1];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[0].lo[i] = a[2 * i]; out[0].hi[i] = a[2 * i + 1]; out[1].lo[i] = a[8 + 2 * i]; out[1].hi[i] = a[9 + 2 * i];
+        out[2].lo[i] = b[2 * i]; out[2].hi[i] = b[2 * i + 1]; out[3].lo[i] = b[8 + 2 * i]; out[3].hi[i] = b[9 + 2 * i];
+    }
+}
+#else
+MS_HD void w4x4_at(const uint64_t* t, unsigned slot, glimb::W4* out) {
+    for (int i = 0; i < 4; i++) out[i] = w4_at(t, slot + i);
+}
+#endif
 
 // Materialise a value here.  Without it LLVM sinks the products of the second half of a network (needed only
 // after the next barrier) below the other network, i.e. keeps 4 limbs + 8 twiddle words alive instead of 2 words.
