@@ -376,8 +376,9 @@ def main():
         us_col = r["avg_us"] / cols_per_call
         us_per_transform += us_col
         kernels.append({"name": name, "avg_us_per_column": round(us_col, 2), "calls": r["calls"],
-                        "bytes_moved_per_column": alg_bytes_col,
-                        "GBps": round(alg_bytes_col / us_col / 1e3, 1)})
+                        "bytes_moved_per_column": alg_bytes_col,               # one read + one write of the column per pass
+                        "GBps": round(alg_bytes_col / us_col / 1e3, 1),
+                        "frac_of_hbm_peak": round(alg_bytes_col / us_col / 1e3 / HBM_PEAK_GBS, 3)})
     achieved = alg_bytes_col / us_per_transform / 1e3 if us_per_transform else 0.0
     # HBM bytes per transform are not measured in this run: they come from the separate rocprofv3 PMC passes
     # (FETCH_SIZE / WRITE_SIZE, scripts/collect_profiles.sh) whose summary is the file named in `traffic_source`
