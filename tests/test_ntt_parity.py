@@ -96,6 +96,17 @@ def test_column_group_on_two_streams_emu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_large_sizes_random_hip(seed):
+    # 2^22 .. 2^24: random field, direction, offset and column count through the uniform-factor / permuted-row passes
+    rng = np.random.default_rng(1000 + seed)
+    log_n = int(rng.integers(22, 25))
+    field = GOLDILOCKS_FQ3 if (log_n < 24 and rng.integers(0, 3) == 0) else GOLDILOCKS_FP
+    offset = int([1, 7, int(rng.integers(2, cref.GL_P, dtype=np.uint64))][int(rng.integers(0, 3))])
+    _run("hip", field, log_n, bool(rng.integers(0, 2)), offset, ncols=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)))
+
+
+@pytest.mark.gpu
 def test_column_group_on_two_streams_hip():
     import subprocess, sys, os
     code = ("import sys; sys.path.insert(0, %r); import tests.test_ntt_parity as t; "
