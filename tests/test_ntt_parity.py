@@ -107,6 +107,17 @@ def test_large_sizes_random_hip(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_large_lde_random_hip(seed):
+    # LDE domains of 2^22 .. 2^24 points: random field, blow-up (pruned first networks), output order, column count
+    rng = np.random.default_rng(2000 + seed)
+    log_dom = int(rng.integers(22, 25))
+    log_b = int(rng.integers(1, 5))
+    field = GOLDILOCKS_FQ3 if (log_dom < 24 and rng.integers(0, 3) == 0) else GOLDILOCKS_FP
+    _lde("hip", field, log_dom - log_b, log_b, ncols=int(rng.integers(1, 3)), bit_reversed=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.gpu
 def test_column_group_on_two_streams_hip():
     import subprocess, sys, os
     code = ("import sys; sys.path.insert(0, %r); import tests.test_ntt_parity as t; "
