@@ -46,15 +46,18 @@ def emit(name, wall, kernels, **kw):
     print(json.dumps({"config": name, "wall_ms": round(wall * 1e3, 3), "kernel_us": kernels, **kw}), flush=True)
 
 
-# ---- C2 sweep: forward coset NTT, one column, 2^20 / 2^22 / 2^24, and inverse 2^24, Fq3 2^22
-for log_n, field, inv in ((20, FP, False), (22, FP, False), (24, FP, False), (24, FP, True), (22, FQ3, False)):
+# ---- C2 sweep: forward coset NTT 2^20 / 2^22 / 2^24, inverse 2^24, Fq3 2^22.  A 2^20 column is 64 tiles and the chip has 512
+# workgroup slots: 4 columns per launch leave it half empty, so the small sizes are also shown at the column counts a prover
+# has (32 at 2^20 = the C3 matrix, 16 at 2^22).
+for log_n, field, inv, ncol in ((20, FP, False, 4), (20, FP, False, 32), (22, FP, False, 4), (22, FP, False, 16), (24, FP, False, 4),
+                                (24, FP, False, 8), (24, FP, True, 4), (22, FQ3, False, 4)):
     V = 3 if field == FQ3 else 1
     n = 1 << log_n
-    cols = [GpuVec.from_numpy(pl, rand(n * V), field) for _ in range(4)]
+    cols = [GpuVec.from_numpy(pl, rand(n * V), field) for _ in range(ncol)]
     plan = (GpuIfft if inv else GpuFft)(Radix2EvaluationDomain(n, 7), field, pl)
     wall, k = timed(lambda: plan.enqueue(cols), reps=5)
     alg = 2.0 * n * V * 8 * len(cols)
-    emit(f"C2 {'iNTT' if inv else 'NTT'} 2^{log_n} {'Fq3' if V == 3 else 'Fp'} x4 columns, coset 7", wall, k,
+    emit(f"C2 {'iNTT' if inv else 'NTT'} 2^{log_n} {'Fq3' if V == 3 else 'Fp'} x{ncol} columns, coset 7", wall, k,
          us_per_column=round(wall / len(cols) * 1e6, 1), algorithmic_GBps=round(alg / wall / 1e9, 1), hbm_frac=round(alg / wall / 8e12, 4))
     del cols, plan
 
