@@ -244,6 +244,68 @@ MS_HD uint64_t mul_fold(const L4& x, const W4& w) {
     return fold_t<CANON>(alo, ahi);
 }
 
+// ---- round 3: the same product with the middle carry inside the multiply-adds --------------------------------------
+// The second accumulator starts from the high word of the first, so the product is  a0 + H 2^32  with H < 2^64 exact
+// (limbs < 2^30, halves < 2^32: both sums stay below 2^64) and only H's high word h1 (weight 2^64 = EPS) is left to fold:
+//      z = (h0 : a0) + h1 EPS          one v_mad_u64_u32 whose CARRY-OUT (VOP3B sdst) says whether 2^64 was lost,
+//      z += carry ? EPS : 0            a second one; it cannot wrap again: z < h1 EPS <= 2^64 - 2^33 + 1 after a wrap.
+// Against fold_t: no 32-bit add / compare / add-with-carry for the middle word, no 64-bit compare, no 64-bit add.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t fold_h(uint32_t a0, uint64_t H) {
+    const uint64_t base = ((uint64_t)(uint32_t)H << 32) | a0;
+    const uint32_t h1 = (uint32_t)(H >> 32);
+    uint64_t z, cm;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(cm) : "v"(h1), "v"(base));      // -1 = 0xFFFFFFFF = EPS
+    uint32_t c01;
+    asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(c01) : "s"(cm));
+    return (uint64_t)c01 * 0xFFFFFFFFull + z;
+}
+#else
+MS_HD uint64_t fold_h(uint32_t a0, uint64_t H) {
+    const uint64_t base = ((uint64_t)(uint32_t)H << 32) | a0;
+    const u128 t = (u128)(uint32_t)(H >> 32) * 0xFFFFFFFFull + base;
+    return (uint64_t)t + ((uint64_t)(t >> 64) ? gl::EPS : 0ull);
+}
+#endif
+template <bool CANON = false>
+MS_HD uint64_t mul_fold_co(const L4& x, const W4& w) {
+    uint64_t alo = (uint64_t)x.l[0] * w.lo[0];
+    #pragma unroll
+    for (int i = 1; i < 4; i++) alo += (uint64_t)x.l[i] * w.lo[i];
+    uint64_t H = (uint64_t)x.l[0] * w.hi[0] + (alo >> 32);
+    #pragma unroll
+    for (int i = 1; i < 4; i++) H += (uint64_t)x.l[i] * w.hi[i];
+    const uint64_t z = fold_h((uint32_t)alo, H);
+    return (CANON && z >= gl::P) ? z + gl::EPS : z;
+}
+
+// A factor on the way INTO a network: x (any 64-bit residue, cut into limbs of 24, 24, 16 bits) times q given as three
+// pre-shifted copies Q_i = q 2^(24 i) mod p.  The 90-bit result  a0 + H 2^32  is cut at the limb boundaries directly (no
+// reduction at all: limbs are a representation mod 2^96 + 1), 14 instructions against the 21 of mul_to_limbs.
+struct Q3 { uint32_t lo[3], hi[3]; };
+MS_HD Q3 q3_from(uint64_t q0, uint64_t q1, uint64_t q2) {
+    Q3 r;
+    r.lo[0] = (uint32_t)q0; r.hi[0] = (uint32_t)(q0 >> 32);
+    r.lo[1] = (uint32_t)q1; r.hi[1] = (uint32_t)(q1 >> 32);
+    r.lo[2] = (uint32_t)q2; r.hi[2] = (uint32_t)(q2 >> 32);
+    return r;
+}
+MS_HD L4 mul3_to_limbs(uint64_t x, const Q3& q) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t l0 = lo & M24, l1 = perm(hi, lo, SEL_345), l2 = hi >> 16;
+    const uint64_t alo = (uint64_t)l0 * q.lo[0] + (uint64_t)l1 * q.lo[1] + (uint64_t)l2 * q.lo[2];      // < 2^58
+    uint64_t H = (uint64_t)l0 * q.hi[0] + (alo >> 32);
+    H += (uint64_t)l1 * q.hi[1];
+    H += (uint64_t)l2 * q.hi[2];                                                                        // < 2^58
+    const uint32_t a0 = (uint32_t)alo, h0 = (uint32_t)H, h1 = (uint32_t)(H >> 32);
+    L4 r;
+    r.l[0] = a0 & M24;
+    r.l[1] = perm(h0, a0, SEL_345);
+    r.l[2] = perm(h1, h0, SEL_234);
+    r.l[3] = h1 >> 8;
+    return r;
+}
+
 // x as a weak residue (no twiddle): the W_i are the constants 2^(24 i) mod p
 //   1, 2^24, 2^48, 2^72 = 2^40 - 2^8.
 template <bool CANON = false>

@@ -323,7 +323,7 @@ struct ms_ntt_plan {
     // limb-form passes (ntt2_kernels.h): plain tables of 4 pre-shifted copies per twiddle
     uint64_t* d_wr4[4] = {nullptr, nullptr, nullptr, nullptr};    // radix-256 passes: w_256^e
     uint64_t* d_twu4[4] = {nullptr, nullptr, nullptr, nullptr};   // middle passes: per-tile factor [U][k]
-    uint64_t *d_sc4 = nullptr, *d_g_plain = nullptr, *d_scu4 = nullptr;
+    uint64_t *d_sc4 = nullptr, *d_g4 = nullptr, *d_scu4 = nullptr;
     // three-pass plans with a last radix >= 64: pass 1's inter-pass factor from wave-uniform tables, the per-lane
     // remainder applied by pass 2 on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
     bool uni = false;
@@ -511,8 +511,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         for (int i = 0; i < extra; i++) p->lr[1 + i] = rest / extra + ((unsigned)i < rest % extra ? 1 : 0);
         // three passes: prefer (8, 8, rest - 8) to an even split whenever the last radix is still >= 16 -- two of the
         // three passes are then limb-form radix-256 passes (ntt2_kernels.h), e.g. 2^20 = 256 * 256 * 16 instead of 256 * 64 * 64
-        static const bool even_split = getenv("MS_NTT_EVEN_SPLIT") != nullptr && atoi(getenv("MS_NTT_EVEN_SPLIT")) != 0;
-        if (!even_split && extra == 2 && rest >= 12 && rest <= 16) { p->lr[1] = 8; p->lr[2] = rest - 8; }
+        if (extra == 2 && rest >= 12 && rest <= 16) { p->lr[1] = 8; p->lr[2] = rest - 8; }
         unsigned acc = 0;
         for (int q = 0; q < p->npass; q++) { p->log_s[q] = acc; acc += p->lr[q]; }
         // digit fields.  pass 1 maps j' = (j2..jm) [jm least significant] to layout (jm..j2) [j2 least]
@@ -567,10 +566,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
     size_t off_wr4[4] = {0, 0, 0, 0}, off_twu4[4] = {0, 0, 0, 0}, off_sc4 = 0, off_gp = 0, off_tin4 = 0, off_tout4 = 0;
     bool has_wr4[4] = {false, false, false, false}, has_twu4[4] = {false, false, false, false}, has_gp = false, has_scu4 = false;
     size_t off_scu4 = 0;
-    // MS_NTT2_PERLANE=1 keeps pass 1's per-lane running product (A/B measurements); MS_NTT_V1=1 the round-1 kernels
-    static const bool no_uni = (getenv("MS_NTT2_PERLANE") != nullptr && atoi(getenv("MS_NTT2_PERLANE")) != 0) ||
-                               (getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0);
-    p->uni = !p->small && !no_uni && p->npass == 3 && p->lr[1] == 8 && p->lr[2] >= 6 && (n * V) % msntt2::TILE == 0;
+    p->uni = !p->small && p->npass == 3 && p->lr[1] == 8 && p->lr[2] >= 6 && (n * V) % msntt2::TILE == 0;
     if (!p->small) {
         const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
         auto append4 = [&](const std::vector<uint64_t>& plain) {
@@ -625,7 +621,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             }
             off_tout4 = append4(t);
         }
-        if (!p->inverse && p->coset) { powers(t, 256, gl::pow(h, (uint64_t)(n >> 8))); off_gp = host.size(); host.insert(host.end(), t.begin(), t.end()); has_gp = true; }
+        if (!p->inverse && p->coset) { powers(t, 256, gl::pow(h, (uint64_t)(n >> 8))); off_gp = append4(t); has_gp = true; }
     }
     p->scale_const = gl::to_mont(p->scale_const);
     hipError_t e = hipMalloc(&p->d_tables, host.size() * 8);
@@ -648,7 +644,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         p->d_sc4 = p->d_tables + off_sc4;
         if (has_scu4) p->d_scu4 = p->d_tables + off_scu4;
         if (p->uni) { p->d_tin4 = p->d_tables + off_tin4; p->d_tout4 = p->d_tables + off_tout4; }
-        if (has_gp) p->d_g_plain = p->d_tables + off_gp;
+        if (has_gp) p->d_g4 = p->d_tables + off_gp;
     }
     *out = p;
     return MS_OK;
@@ -804,14 +800,12 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
     }
     unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
     group = std::min(group, ncols);
-    // uniform-factor plans on Fp columns: pass 1 stores whole lines in a permuted row order, pass 2 un-permutes out of
-    // place (scratch -> dst) and pass 3 runs in place on dst.  With the fused bit-reversed store the last pass cannot run
-    // in place: pass 2 then writes a second scratch column.  MS_NTT2_NOPERM=1 keeps the natural rows (A/B measurements).
-    static const bool no_perm = getenv("MS_NTT2_NOPERM") != nullptr && atoi(getenv("MS_NTT2_NOPERM")) != 0;
-    const bool perm = p->uni && p->V == 1 && !no_perm;
-    const bool perm2 = perm && bitrev_out;
+    // uniform-factor plans on Fp columns: pass 1 stores whole lines in a row order that permutes the words inside every run of
+    // 64; pass 2 un-permutes while it reads, in place on the scratch column (its tile owns those 64 words), and the last pass
+    // goes scratch -> dst (natural order, or bit-reversed for the LDE).
+    const bool perm = p->uni && p->V == 1;
     void* scratch = nullptr;
-    MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes * (perm2 ? 2 : 1), &scratch));
+    MSCHK(ctx_scratch(ctx, (size_t)group * col_bytes, &scratch));
     const unsigned tiles = (unsigned)(n * p->V / msntt::TILE);
     // MS_NTT_STREAMS=2: the two halves of a group on two streams -- kernels of different passes then overlap (a pass
     // alternates between a memory phase and an arithmetic phase per workgroup); measured 162 -> 159 us per 2^24 column
@@ -845,10 +839,6 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 uint64_t* scr = (uint64_t*)((char*)scratch + (size_t)c * col_bytes);
                 P.src[c] = (q == 0) ? (const uint64_t*)src[c0 + c] : scr;
                 P.dst[c] = last ? (uint64_t*)dst[c0 + c] : scr;
-                if (perm2 && q >= 1) {                        // scratch A -> scratch B -> dst
-                    uint64_t* scr_b = (uint64_t*)((char*)scratch_all + (size_t)(group + s0 + c) * col_bytes);
-                    if (q == 1) P.dst[c] = scr_b; else P.src[c] = scr_b;
-                } else if (perm && q >= 1) { P.dst[c] = (uint64_t*)dst[c0 + c]; if (q == 2) P.src[c] = (const uint64_t*)dst[c0 + c]; }
             }
             P.tw_lo = p->d_tw_lo; P.tw_hi = p->d_tw_hi; P.wr = p->d_wr[q];
             P.aux_lo = p->d_aux_lo; P.aux_hi = p->d_aux_hi; P.gtab = p->d_gtab;
@@ -859,19 +849,15 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
             dim3 grid(tiles, nc);
             static const char* const pass_names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
             ProfScope ps(ctx, pass_names[q], 2.0 * col_bytes * nc);
-            // limb-form radix-256 passes (ntt2_kernels.h) wherever a pass has radix 256 and rows of >= 64 words;
-            // MS_NTT_V1=1 keeps the round-1 kernels (A/B measurements)
-            static const bool force_v1 = getenv("MS_NTT_V1") != nullptr && atoi(getenv("MS_NTT_V1")) != 0;
-            static const bool no_sc2 = getenv("MS_NTT2_COSET_SCALE") != nullptr && atoi(getenv("MS_NTT2_COSET_SCALE")) == 0;   // A/B: round-1 scale walk
-            static const bool no_br2 = getenv("MS_NTT2_BITREV") != nullptr && atoi(getenv("MS_NTT2_BITREV")) == 0;   // A/B: round-1 fused bit reversal
+            // limb-form radix-256 passes (ntt2_kernels.h) wherever a pass has radix 256 and rows of >= 64 words
             const size_t pass_sw = ((size_t)1 << p->log_s[q]) * p->V;
             // (the per-element scale walk of an inverse coset transform stays with the round-1 last pass: the walk is two table
             // loads and a Montgomery product per word, which the 4-wave limb kernel hides worse -- 91 vs 75 us per 2^24
             // column; so does the fused bit-reversed store of Fq3 columns, whose runs interleave three words)
-            const bool v2_ok = !force_v1 && p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
+            const bool v2_ok = p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
                                (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0
-                                       : (pass_sw % msntt2::TW == 0 && !(last && p->scale_mode == 2 && (p->d_scu4 == nullptr || no_sc2)) &&
-                                          !(last && bitrev_out && (p->V != 1 || p->inverse || p->scale_mode != 0 || no_br2))));
+                                       : (pass_sw % msntt2::TW == 0 && !(last && p->scale_mode == 2 && p->d_scu4 == nullptr) &&
+                                          !(last && bitrev_out && (p->V != 1 || p->inverse || p->scale_mode != 0))));
             static const bool dbg = getenv("MS_NTT_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? (p->uni && q < 2 ? "limb-form (ntt2), uniform inter-pass factor" : "limb-form (ntt2)") : "round-1");
             if (p->uni && q < 2 && !v2_ok) return fail(MS_ERR_INVALID, "internal: uniform inter-pass plan without its limb-form passes");
@@ -879,7 +865,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                 msntt2::Params Q;
                 memset(&Q, 0, sizeof Q);
                 for (unsigned c = 0; c < nc; c++) { Q.src[c] = P.src[c]; Q.dst[c] = P.dst[c]; }
-                Q.wr4 = p->d_wr4[q]; Q.twu4 = p->d_twu4[q]; Q.sc4 = p->d_sc4; Q.scu4 = p->d_scu4; Q.g_plain = p->d_g_plain;
+                Q.wr4 = p->d_wr4[q]; Q.twu4 = p->d_twu4[q]; Q.sc4 = p->d_sc4; Q.scu4 = p->d_scu4; Q.g4 = p->d_g4;
                 Q.tw_lo = p->d_tw_lo; Q.tw_hi = p->d_tw_hi; Q.aux_lo = p->d_aux_lo; Q.aux_hi = p->d_aux_hi;
                 Q.log_n = p->log_n; Q.V = p->V; Q.valid_rows = valid_rows; Q.lo_bits = p->lo_bits; Q.log_s = p->log_s[q];
                 Q.tin4 = p->d_tin4; Q.tout4 = p->d_tout4; Q.r3 = p->lr[2];
@@ -906,7 +892,7 @@ static int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, un
                     }
 #undef MS_P1
                 } else if (!last) {
-                    if (perm) {             // ... and reads pass 1's permuted rows, writes the natural order to dst
+                    if (perm) {             // ... and reads pass 1's permuted rows, writes the natural order (in place)
                         if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0, true, true>), g2, b2, 0, st, Q);
                         else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g2, b2, 0, st, Q);
                     } else if (p->uni) {    // q == 1 of three: applies the per-lane remainder of pass 1's factor on its loads

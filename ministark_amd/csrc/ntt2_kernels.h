@@ -44,7 +44,7 @@ struct Params {
     const uint64_t* twu4;      // middle pass: [U][k], w_n^((rev(U) k) << log_s)   (after the second network)
     const uint64_t* sc4;       // last pass, SCALE 1: the constant n^-1 (4 copies)
     const uint64_t* scu4;      // last pass, SCALE 2: [k] h^-(k 2^log_s), k < 256 (4 copies): the row part of the coset scale
-    const uint64_t* g_plain;   // pass 1 coset: g^j1 plain, j1 < 256
+    const uint64_t* g4;        // pass 1 coset: g^j1, j1 < 256 (4 copies; the product on the loads uses three)
     // uniform inter-pass factor of a three-pass plan (UNI kernels, see ntt2_first_pass):
     const uint64_t* tin4;      // pass 1: [j2][b][a'] w_256^(a' b) w_n^(a' R3 j2)            (between the two networks)
     const uint64_t* tout4;     // pass 1: [j2][b'] h^(R3 j2) w_n^(16 b' R3 j2)                (after the second network)
@@ -127,17 +127,39 @@ __device__ __forceinline__ uint64_t pin(uint64_t x) { asm volatile("" : "+v"(x))
 MS_HD uint64_t pin(uint64_t x) { return x; }
 #endif
 
+// three of the four copies of a table slot, for a product on the way into a network (wave-uniform: scalar registers)
+__device__ __forceinline__ glimb::Q3 q3_at(const uint64_t* t, unsigned slot) {
+    const glimb::W4 w = w4_at(t, slot);
+    glimb::Q3 r;
+    #pragma unroll
+    for (int i = 0; i < 3; i++) { r.lo[i] = w.lo[i]; r.hi[i] = w.hi[i]; }
+    return r;
+}
+
 // first network of a pass: 16 loaded words (rows 16 a + b) -> w_256^(a' b) * DFT16, as weak 64-bit residues
-//   IN   0: words as they are; 1: times the wave-uniform g_plain[16 a + b] (coset, pass 1); 2: times the per-lane q
+//   IN   0: words as they are; 1: times the wave-uniform g4[16 a + b] (coset, pass 1); 2: times the per-lane q
+//        (both as glimb::mul3_to_limbs: three pre-shifted copies of the factor, no reduction between product and network)
 //   UNI  the factor after the network comes from tin4 at slot tslot + a' (pass 1 of a three-pass plan) instead of wr4
 template <bool INV, int NA, int IN, bool UNI = false>
-__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, uint64_t q = 0, unsigned tslot = 0) {
+__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, const glimb::Q3& q = glimb::Q3{}, unsigned tslot = 0) {
     glimb::L4 v[16];
-    #pragma unroll
-    for (int a = 0; a < NA; a++) {
-        if constexpr (IN == 1) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)P.g_plain)[16 * a + b]);   // uniform: scalar load
-        else if constexpr (IN == 2) v[a] = glimb::mul_to_limbs(x[a], q);
-        else v[a] = glimb::from_u64(x[a]);
+    if constexpr (IN == 1) {
+        #pragma unroll
+        for (int a0 = 0; a0 < NA; a0 += 4) {           // four scales (24 scalar registers) at a time
+            glimb::Q3 g[4];
+            #pragma unroll
+            for (int j = 0; j < 4 && a0 + j < NA; j++) g[j] = q3_at(P.g4, 16 * (a0 + j) + b);
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int j = 0; j < 4 && a0 + j < NA; j++) v[a0 + j] = glimb::mul3_to_limbs(x[a0 + j], g[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        #pragma unroll
+        for (int a = 0; a < NA; a++) {
+            if constexpr (IN == 2) v[a] = glimb::mul3_to_limbs(x[a], q);
+            else v[a] = glimb::from_u64(x[a]);
+        }
     }
     auto tw = [&](int c) { return UNI ? w4_at(P.tin4, tslot + c) : w4_at(P.wr4, (b * c) & 255); };
     glimb::W4 wn[4];                            // the first group's factors are requested before the network (32 SGPRs: 60.8 -> 55.8 us in pass 1)
@@ -158,7 +180,7 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, u
         }
         __builtin_amdgcn_sched_barrier(0);
         #pragma unroll
-        for (int j = 0; j < 4; j++) x[4 * g + j] = pin(glimb::mul_fold(v[4 * g + j], wc[j]));     // the accumulators of at most 4 elements live
+        for (int j = 0; j < 4; j++) x[4 * g + j] = pin(glimb::mul_fold_co(v[4 * g + j], wc[j]));     // the accumulators of at most 4 elements live
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -172,10 +194,11 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, u
 //   w_n^(k1 j3), k1 = the lane's position in the row, j3 = this tile's block -- the part of the inter-pass factor
 //   (h w_n^k1)^(R3 j2 + j3) that pass 1 cannot apply with wave-uniform operands.  It is one value per lane and tile,
 //   so the 128-bit product replaces the plain conversion to limbs (no running product; h^j3 sits in twu4).
-// PERM (with LOADQ, V = 1, src != dst): pass 1 left every 256-word row in the order its stores like best (see
-//   ntt2_first_pass<.., PERM>): k1 = a' + 16 d sits at (a' >> 3) 128 + (d >> 1) 16 + (a' & 7) 2 + (d & 1).  The 64 words
-//   k1 = 64 q + lane of this tile are then two runs of 32 words (whole 128-byte lines, read once); the stores go to the
-//   natural positions of dst, so the permutation ends here.
+// PERM (with LOADQ, V = 1): pass 1 left every 256-word row in the order its stores like best (see
+//   ntt2_first_pass<.., PERM>): k1 = a' + 16 d sits at 64 (d >> 2) + 32 ((d >> 1) & 1) + 16 (a' >> 3) + 2 (a' & 7) + (d & 1),
+//   a permutation INSIDE each run of 64 words.  The 64 words k1 = 64 q + lane of this tile are therefore this tile's own four
+//   128-byte lines, read once in a permuted lane order; the stores go to the natural positions, so the permutation ends here
+//   and the pass may run in place (every word of the tile is read before the first one is stored).
 template <bool INV, bool LAST, int SCALE, bool LOADQ = false, bool PERM = false>
 __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
@@ -188,9 +211,9 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     const unsigned U = blockIdx.x / tiles_per_u;
     const size_t base = (size_t)U * 256 * sw + (size_t)(blockIdx.x % tiles_per_u) * TW + lane;
     size_t rbase = base;
-    if constexpr (PERM) {
-        const unsigned q = blockIdx.x % tiles_per_u, ap = lane & 15, dl = lane >> 4;
-        rbase = (size_t)U * 256 * sw + (ap >> 3) * 128 + 32 * q + (dl >> 1) * 16 + (ap & 7) * 2 + (dl & 1);
+    if constexpr (PERM) {       // natural k1 = 64 q + lane sits at 64 q + pi(lane): inside this tile's own 64 words, so dst may be src
+        const unsigned q = blockIdx.x % tiles_per_u;
+        rbase = (size_t)U * 256 * sw + 64 * q + ((lane >> 5) & 1) * 32 + ((lane >> 3) & 1) * 16 + (lane & 7) * 2 + ((lane >> 4) & 1);
     }
 
     // Register budget: 128 per lane at two workgroups per CU, and a network in limb form holds 64.
@@ -220,8 +243,11 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
         qhi = P.tw_hi[e >> P.lo_bits];
     }
     load_half(0); load_half(1);
-    uint64_t qpl = 0;
-    if constexpr (LOADQ || SCALE == 2) qpl = gld::mmul(gld::mmul(qlo, qhi), 1);      // out of Montgomery form: the data keeps its own
+    glimb::Q3 qpl{};
+    if constexpr (LOADQ || SCALE == 2) {                     // three plain copies q 2^(24 i): the data keeps its own Montgomery factor
+        const uint64_t qm = gld::mmul(qlo, qhi);
+        qpl = glimb::q3_from(gld::mmul(qm, 1), gld::mmul(qm, (uint64_t)1 << 24), gld::mmul(qm, (uint64_t)1 << 48));
+    }
     #pragma unroll
     for (int h = 0; h < 2; h++) {
         net1<INV, 16, (LOADQ || SCALE == 2) ? 2 : 0>(x[h], P, w + 8 * h, qpl);
@@ -274,9 +300,9 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
             for (int j = 0; j < 4; j++, pos += step) {
                 const int d = 4 * g + j;
                 uint64_t val;
-                if constexpr (!LAST) val = glimb::mul_fold<false>(v[d], wc[j]);       // a weak residue: every pass accepts any 64-bit representative
-                else if constexpr (SCALE == 1) val = glimb::mul_fold<true>(v[d], w4_at(P.sc4, 0));
-                else if constexpr (SCALE == 2) val = glimb::mul_fold<true>(v[d], w4_at(P.scu4, ap + 16 * d));
+                if constexpr (!LAST) val = glimb::mul_fold_co<false>(v[d], wc[j]);       // a weak residue: every pass accepts any 64-bit representative
+                else if constexpr (SCALE == 1) val = glimb::mul_fold_co<true>(v[d], w4_at(P.sc4, 0));
+                else if constexpr (SCALE == 2) val = glimb::mul_fold_co<true>(v[d], w4_at(P.scu4, ap + 16 * d));
                 else val = glimb::to_canon(v[d]);
                 dst[pos] = val;
             }
@@ -361,9 +387,12 @@ __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) {
 // all three wave-uniform or per-lane constants: no running product, no Montgomery multiplications in this pass.
 // PERM (UNI, V = 1): the 64-byte pieces of the layout above (8 lanes x 8 B per store, the other half of each line a round
 // later) cost pass 1 about 9 us per 2^24 column against whole-line stores (profiles/r02_ubench6_*).  With PERM a row of
-// 256 k1 is stored in the order  (a' >> 3) 128 + (d >> 1) 16 + (a' & 7) 2 + (d & 1)  (k1 = a' + 16 d): a lane's outputs
-// d, d + 1 are adjacent (one 16-byte store) and the 8 lanes a' & 7 fill one 128-byte line per store; pass 2 reads the
-// rows back in this order (ntt2_mid_pass<.., PERM>) and writes the natural one.
+// 256 k1 is stored in the order  64 (d >> 2) + 32 ((d >> 1) & 1) + 16 (a' >> 3) + 2 (a' & 7) + (d & 1)  (k1 = a' + 16 d):
+// a lane's outputs d, d + 1 are adjacent (one 16-byte store), the 8 lanes a' & 7 fill one 128-byte line per store, and
+// every run of 64 natural k1 stays inside its own 64 words; pass 2 reads the rows back in this order
+// (ntt2_mid_pass<.., PERM>) and writes the natural one -- in place, since the permutation never leaves a pass-2 tile.
+// (Pass 1 itself cannot run in place without a rendezvous of the four tiles that share a 512 KiB slab of the column; that was
+// built and measured in round 3 -- 72 against 56 us per column, profiles/r03_ntt3_inplace.txt -- and dropped.)
 template <bool INV, bool COSET, int NA, bool UNI = false, bool PERM = false>
 __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * XPITCH];                // [b][a' - 8 round][word], pitch 68 words
@@ -393,7 +422,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     load_half(0); load_half(1);          // both halves in flight before the first network (no spills since round 2b)
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        net1<INV, NA, COSET ? 1 : 0, UNI>(x[h], P, w + 8 * h, 0, (j2 * 16 + w + 8 * h) * 16);
+        net1<INV, NA, COSET ? 1 : 0, UNI>(x[h], P, w + 8 * h, glimb::Q3{}, (j2 * 16 + w + 8 * h) * 16);
         #pragma unroll
         for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * XPITCH + lane] = x[h][j];
         __builtin_amdgcn_sched_barrier(0);
@@ -420,7 +449,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
         glimb::dft<16, INV>(v);
         if constexpr (PERM) {
             const unsigned jp = (unsigned)(w0 + 8 * w + tl);   // this lane's word after the exchange (V = 1)
-            Pair* q2 = (Pair*)(dst + ((size_t)digit_rev(P, jp) << 8) + r * 128 + c3 * 2);
+            Pair* q2 = (Pair*)(dst + ((size_t)digit_rev(P, jp) << 8) + r * 16 + c3 * 2);
             glimb::W4 wn[4];
             #pragma unroll
             for (int j = 0; j < 4; j++) wn[j] = w4_at(P.tout4, j2 * 16 + j);
@@ -435,8 +464,8 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
-                for (int j = 0; j < 4; j += 2, q2 += 8)
-                    *q2 = Pair{glimb::mul_fold(v[4 * g + j], wc[j]), glimb::mul_fold(v[4 * g + j + 1], wc[j + 1])};
+                for (int j = 0; j < 4; j += 2, q2 += 16)     // d = 4 g + j: position 64 g + 32 (j >> 1) + 16 r + 2 c3 + (d & 1)
+                    *q2 = Pair{glimb::mul_fold_co(v[4 * g + j], wc[j]), glimb::mul_fold_co(v[4 * g + j + 1], wc[j + 1])};
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (UNI) {
@@ -457,7 +486,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
-                for (int j = 0; j < 4; j++, q += 16 * V) *q = glimb::mul_fold(v[4 * g + j], wc[j]);
+                for (int j = 0; j < 4; j++, q += 16 * V) *q = glimb::mul_fold_co(v[4 * g + j], wc[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
