@@ -23,10 +23,14 @@ Extra objects on the JSON line:
   lde_commit   : configs[2] (C3): 2^20 rows x 32 columns, blow-up 8, fused LDE + SHA-256 row hashing + Merkle tree,
                  with its own roofline (LDE kernels against HBM; algorithmic bytes n s + beta n s per column,
                  SURVEY.md 8(d)) and cpu_baseline (oracle/c on the same matrix).                       [N = 1 only]
+  constraint_eval : configs[3] (C4): one fused evaluation of the composition constraint over 2^23 points for (i) the reference's
+                 fib AIR on 8 Fp columns, (ii) 17 Fp + 9 Fq3 columns, (iii) the fib AIR over the 252-bit field: kernel time,
+                 algorithmic bytes (columns read once + result), fraction of the HBM roofline, and
+                 oracle_eval_expr (the restated eval_cpu::eval) timed on the host cores.                [N = 1 only]
   prove        : the second half of BASELINE's metric, "end-to-end prove time": every data-parallel phase of
                  default_prove on configs[4]'s shape (2^22 rows x 8 columns, ProofOptions::new(32, 4, 8, 8, 64)),
                  device-resident, fixed challenges in place of the channel (ministark_amd/pipeline.py); phases,
-                 per-kernel time, and the oracle chain timed on a bounded sample (2^18 rows).           [N = 1 only]
+                 per-kernel time, and the oracle chain timed once at the same size.                   [N = 1 only]
   sharded_lde_commit : configs[4]'s multi-GPU step for any N (also N = 1, where RCCL runs with one rank): a
                  2^22-row x 32-column trace, blow-up 4, columns sharded over the ranks -> LDE (no communication) ->
                  ms_cols_to_rows_alltoall -> row hashing + subtree -> ms_allgather_digests -> top levels.  The total
@@ -182,23 +186,24 @@ def bench_prove(pl, with_cpu):
     rng = np.random.default_rng(5)
     P = (1 << 64) - (1 << 32) + 1
     trace = Matrix.from_numpy(pl, [rng.integers(0, P, size=n_t, dtype=np.uint64) for _ in range(ncols)], GOLDILOCKS_FP)
-    comp, nch = pipeline.fib_constraints(n_t, ncols)
-    draws = pipeline.Draws(0xC5, ncols, nch, blowup, 32, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64))
+    comp, ce, nch = pipeline.fib_constraints(n_t, ncols)        # FibAirConfig::constraints (examples/fib/main.rs:73-140): ce_blowup_factor 1
+    draws = pipeline.Draws(0xC5, ncols, nch, ce, 32, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64))
     res = {}
 
     def run():
         res.clear()
-        res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8))
+        res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, ce_blowup=ce))
     phases = {}
     wall, k = _profiled(pl, run, 3, after_wall=lambda: phases.update(res["phases_ms"]))      # phases of a run without events
-    n_lde = n_t * blowup
+    n_lde, n_ce = n_t * blowup, n_t * ce
     # algorithmic bytes per SURVEY.md 8(d): LDEs n s + beta n s per column, in-place transforms 2 n s, row hashing n cols s + 32 n,
-    # trees 96 n, constraint evaluation sum of columns + result, FRI layers n s + n s / ff
-    alg = (ncols * (n_t * 8 + n_lde * 8) + (n_lde * ncols * 8 + 128 * n_lde) + (ncols + 1) * n_lde * 8 + 2 * n_lde * 8
-           + blowup * (n_t * 8 + n_lde * 8) + (n_lde * blowup * 8 + 128 * n_lde) + (ncols + blowup + 1) * n_t * 8 + (n_t * 8 + n_lde * 8)
+    # trees 96 n, constraint evaluation sum of columns + result (on the n ce points of the constraint-evaluation domain), FRI
+    # layers n s + n s / ff
+    alg = (ncols * (n_t * 8 + n_lde * 8) + (n_lde * ncols * 8 + 128 * n_lde) + (ncols + 1) * n_ce * 8 + 2 * n_ce * 8
+           + ce * (n_t * 8 + n_lde * 8) + (n_lde * ce * 8 + 128 * n_lde) + (ncols + ce + 1) * n_t * 8 + (n_t * 8 + n_lde * 8)
            + sum((n_lde >> (3 * i)) * 8 * (1 + 1 / 8) + 128 * (n_lde >> (3 * i + 3)) for i in range(len(draws.fri_alphas))))
     kernel_ms = sum(k.values()) / 1e3
-    out = {"workload": "configs[4] on one GPU: 2^22 rows x 8 columns (Fp, Fq = Fp), ProofOptions::new(32, 4, 8, 8, 64): every data-parallel phase of default_prove, fixed challenges in place of the channel",
+    out = {"workload": "configs[4] on one GPU: 2^22 rows x 8 columns (Fp, Fq = Fp), the reference's fib AIR (examples/fib/main.rs:73-140: 17 constraints, ce_blowup_factor 1), ProofOptions::new(32, 4, 8, 8, 64): every data-parallel phase of default_prove, fixed challenges in place of the channel",
            "prove_ms": round(wall * 1e3, 3), "kernel_ms": round(kernel_ms, 3), "phases_ms": phases, "kernel_us": k,
            "roofline": {"bound": "hbm (NTT / evaluation / FRI) + integer ALU (SHA-256)", "algorithmic_bytes": float(alg),
                         "achieved": round(alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -208,15 +213,76 @@ def bench_prove(pl, with_cpu):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import cref
         from tests.test_pipeline_parity import _c5_oracle_chain
-        lt = 18                                                    # bounded sample: the same chain on 2^18 rows (1/16 of the work)
-        cols = [cref.random_elements(1 << lt, 77 + c) for c in range(ncols)]
-        comp_s, nch_s = pipeline.fib_constraints(1 << lt, ncols)
-        draws_s = pipeline.Draws(0xC5, ncols, nch_s, blowup, 32, (1 << lt) * blowup, pipeline.fri_num_layers((1 << lt) * blowup, blowup, folding, 64))
+        cols = [cref.random_elements(n_t, 77 + c) for c in range(ncols)]                    # the same size: the whole chain once
         t0 = time.perf_counter()
-        _c5_oracle_chain(cols, lt, blowup, folding, draws_s, comp_s)
+        _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp, ce)
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(dt * 1e3, 1), "unit": "ms", "cores": cref.num_threads(), "kind": "port",
-                               "sample": f"the same chain on 2^{lt} rows x {ncols} columns (1/16 of the rows), oracle/c + numpy glue; not extrapolated"}
+                               "sample": f"the same chain once at the same size (2^{log_t} rows x {ncols} columns), oracle/c (C/OpenMP restatement, not the reference binary) + numpy glue"}
+    return out
+
+
+def bench_constraint_eval(pl, with_cpu):
+    """configs[3] (C4): constraint composition evaluation on 2^23 points, three AIRs:
+    (i) the reference's fib AIR, 8 Fp columns; (ii) 17 Fp + 9 Fq3 columns (the brainfuck shape); (iii) the fib AIR over the
+    252-bit field.  Algorithmic bytes = sum over columns of n s_col + n s_Fq for the result (x is generated on the fly)."""
+    import numpy as np
+    from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3, STARK252_FP, GpuVec, expr as E, pipeline
+    log_n = 23
+    n = 1 << log_n
+    rng = np.random.default_rng(23)
+    P = (1 << 64) - (1 << 32) + 1
+    out = {"workload": "configs[3]: one fused evaluation of the composition constraint over 2^23 points of the coset 7<w>"}
+
+    def gl_cols(k, V=1):
+        return [rng.integers(0, P, size=n * V, dtype=np.uint64) for _ in range(k)]
+
+    def f252_cols(k):
+        cols = [rng.integers(0, 1 << 63, size=4 * n, dtype=np.uint64) for _ in range(k)]
+        for c in cols:
+            c[3::4] >>= np.uint64(4)                       # canonical residues below 2^251 < p
+        return cols
+    cases = []
+    comp, _, nch = pipeline.fib_constraints(n)                                   # lde_step = ce_blowup_factor = 1 (src/prover.rs:103)
+    cases.append(("fib_air_fp", "(i) FibAirConfig::constraints (examples/fib/main.rs:73-140), 8 Fp columns, Fq = Fp, lde_step 1", comp, 1, 7, GOLDILOCKS_FP, False,
+                  gl_cols(8), [], rng.integers(1, P, size=(nch, 1), dtype=np.uint64), 8 * 8 + 8, "goldilocks", log_n))
+    comp, nch = pipeline.mixed_air_constraints()
+    cases.append(("mixed_17fp_9fq3", "(ii) 17 Fp + 9 Fq3 columns (examples/brainfuck/air.rs:26-27 shape), lde_step 2", comp, 2, 7, GOLDILOCKS_FP, True,
+                  gl_cols(17), gl_cols(9, 3), rng.integers(1, P, size=(nch, 3), dtype=np.uint64), 17 * 8 + 9 * 24 + 24, "goldilocks", log_n - 2))
+    comp, _, nch = pipeline.fib_constraints(n >> 2, 8, STARK252_FP)
+    cases.append(("fib_air_fp252", "(iii) the fib AIR over the 252-bit field (src/eval_gpu.rs:1054-1082), 8 columns, lde_step 4", comp, 4, 3, STARK252_FP, False,
+                  f252_cols(8), [], rng.integers(0, 1 << 59, size=(nch, 4), dtype=np.uint64), 8 * 32 + 32, "f252", log_n - 2))
+    for key, what, comp, lde_step, offset, field, fq_ext, base, ext, ch, bytes_per_point, oracle_field, cpu_log in cases:
+        prog = E.compile_expr(comp, len(base), fq_ext, field)
+        dbase = [GpuVec.from_numpy(pl, c, field) for c in base]
+        dext = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FQ3) for c in ext]
+        res = {}
+
+        def run():
+            res["out"] = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, dbase, dext)
+        wall, k = _profiled(pl, run, 5)
+        us = sum(k.values())
+        alg = float(bytes_per_point) * n
+        obj = {"workload": what, "instructions": len(prog.instrs), "wall_ms": round(wall * 1e3, 3), "kernel_us": k,
+               "roofline": {"bound": "hbm" if key == "fib_air_fp" else "integer ALU (extension-field / 252-bit products) over an HBM stream",
+                            "algorithmic_bytes": alg, "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}}
+        if with_cpu:
+            from oracle import cref
+            m = 1 << cpu_log                                   # bounded sample: the first 2^cpu_log points of the same columns
+            Vb = 4 if oracle_field == "f252" else 1
+            t0 = time.perf_counter()
+            want = cref.eval_expr(comp, cpu_log, lde_step, offset, [c[:m * Vb] for c in base], [c[:3 * m] for c in ext], ch, ch[:1], fq_ext,
+                                  **({"field": "f252"} if oracle_field == "f252" else {}))
+            dt = time.perf_counter() - t0
+            obj["cpu_baseline"] = {"value": round(dt * 1e3, 1), "unit": "ms", "cores": cref.num_threads(), "kind": "port",
+                                   "points": m, "us_per_point": round(dt * 1e6 / m, 4),
+                                   "sample": f"oracle_eval_expr (eval_cpu::eval restated: 512-point chunks, batch inversion) on 2^{cpu_log} points"
+                                             + (" = the whole domain" if cpu_log == log_n else f" (1/{1 << (log_n - cpu_log)} of the domain, same columns' prefix, trace_len scaled with it)")}
+            if cpu_log == log_n:
+                obj["cpu_baseline"]["matches_device"] = bool(np.array_equal(res["out"].to_numpy(), want))
+        out[key] = obj
+        del dbase, dext, res
     return out
 
 
@@ -426,6 +492,7 @@ def main():
         for c in cols:
             c.free()
         out["lde_commit"] = bench_lde_commit(pl, not args.no_cpu_baseline)
+        out["constraint_eval"] = bench_constraint_eval(pl, not args.no_cpu_baseline)
         out["prove"] = bench_prove(pl, not args.no_cpu_baseline)
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
         from oracle import cref

@@ -23,10 +23,92 @@ from .api import (GL_P, GOLDILOCKS_FP, Matrix, MerkleTree, Queries, Radix2Evalua
 from .composer import DeepCompositionCoeffs, DeepPolyComposer
 
 
-def fib_constraints(n_trace, ncols=8):
-    """The composition constraint of an `ncols`-column Fibonacci-style AIR in the shape of examples/fib/main.rs:73-140:
-    transition constraints c_k = c_(k-2) + c_(k-1) across and along rows, each divided by the transition zerofier
-    (X - 3) / (X^n - 1) and degree-adjusted by (alpha_k X^3 + beta_k)."""
+def _degree(e, trace_degree):
+    """`Constraint::degree` (src/constraints.rs:32-41, 152-158, 407-455): an upper bound (numerator, denominator) on the
+    degree in X, with the reference's own (loose) arithmetic."""
+    k, a = e.kind, e.args
+    if k in ("const", "challenge", "hint"):
+        return (0, 0)
+    if k == "trace":
+        return (trace_degree, 0)
+    if k == "x":
+        return (1, 0)
+    if k == "periodic":                                   # PeriodicColumn::degree (src/constraints.rs:135-141)
+        coeffs, interval = a[0], a[1]
+        return ((len(coeffs) - 1) * ((trace_degree + 1) // interval), 0)
+    if k == "neg":
+        return _degree(a[0], trace_degree)
+    if k == "pow":
+        n, d = _degree(a[0], trace_degree)
+        return (n * a[1], d * a[1])
+    (an, ad), (bn, bd) = _degree(a[0], trace_degree), _degree(a[1], trace_degree)
+    if k == "add":
+        return (max(an + bd, bn + ad), ad + bd)
+    if k == "mul":
+        return (an + bn, ad + bd)
+    if k == "div":
+        return (an + bd, ad + bn)
+    raise ValueError(k)
+
+
+def _ceil_power_of_two(v):                                # src/utils.rs:76-82
+    return v if v and (v & (v - 1)) == 0 else 1 << max(v, 1).bit_length() if v else 1
+
+
+def constraint_blowup_factor(c, trace_len):
+    """`Constraint::blowup_factor` (src/constraints.rs:162-166, 340-347) -- note the division by trace_len - 1."""
+    n, d = _degree(c, trace_len - 1)
+    return _ceil_power_of_two(max(n - d, 0)) // (trace_len - 1)
+
+
+def composition_constraint(trace_len, constraints):
+    """`AirConfig::composition_constraint` (src/air.rs:50-82): sum_i c_i (X^adj_i alpha_i + beta_i) with
+    adj_i = (trace_len ce_blowup - 1) - (deg num_i - deg den_i).  CompositionCoeff(i) is Challenge(i) here (the AIRs this
+    module drives have no other challenges; eval_constraint substitutes them as constants, src/air.rs:96-101).
+    Returns (expression, ce_blowup_factor, number of composition coefficients)."""
+    ce = max(constraint_blowup_factor(c, trace_len) for c in constraints)
+    composition_degree = trace_len * ce - 1
+    x = E.X()
+    comp = None
+    for i, c in enumerate(constraints):
+        n, d = _degree(c, trace_len - 1)
+        assert n - d <= composition_degree
+        adj = composition_degree - (n - d)
+        term = c * (x ** adj * E.Challenge(2 * i) + E.Challenge(2 * i + 1))
+        comp = term if comp is None else comp + term
+    return comp, ce, 2 * len(constraints)
+
+
+def fib_air_constraints(trace_len, field=GOLDILOCKS_FP):
+    """`FibAirConfig::constraints` (examples/fib/main.rs:73-140), in its order: 8 boundary constraints divided by (X - 1),
+    the terminal constraint divided by (X - g^-1), 8 multiplicative transition constraints times (X - g^-1) / (X^n - 1).
+    Hint(0) is the claimed n-th value.  field: the base field the trace domain lives in (the example's is Goldilocks;
+    src/eval_gpu.rs:1054-1082 runs its evaluator over the 252-bit field as well)."""
+    x = E.X()
+    dom = Radix2EvaluationDomain(trace_len, 1, field)
+    first_x, last_x = 1, pow(dom.group_gen, trace_len - 1, dom.p)
+    curr, nxt = (lambda k: E.Trace(k, 0)), (lambda k: E.Trace(k, 1))
+    v = [1, 2, 2]
+    for k in range(3, 8):
+        v.append(v[k - 2] * v[k - 1] % dom.p)                      # 4, 8, 32, 256, 8192
+    boundary = [(curr(k) - E.Constant(v[k])) / (x - E.Constant(first_x)) for k in range(8)]
+    terminal = [(curr(7) - E.Hint(0)) / (x - E.Constant(last_x))]
+    tr = [nxt(0) - curr(6) * curr(7), nxt(1) - curr(7) * nxt(0)] + [nxt(k) - nxt(k - 2) * nxt(k - 1) for k in range(2, 8)]
+    zer = (x - E.Constant(last_x)) / (x ** trace_len - E.Constant(1))
+    return boundary + terminal + [t * zer for t in tr]
+
+
+def fib_constraints(n_trace, ncols=8, field=GOLDILOCKS_FP):
+    """The reference's fib AIR as `default_prove` sees it: (composition constraint, ce_blowup_factor, number of composition
+    coefficients).  ce_blowup_factor is 1 for this AIR (every constraint has evaluation degree <= n - 1), i.e. the
+    composition polynomial has n coefficients and one column (src/prover.rs:111-124)."""
+    assert ncols == 8, "examples/fib has 8 columns"
+    return composition_constraint(n_trace, fib_air_constraints(n_trace, field))
+
+
+def additive_constraints(n_trace, ncols=8, ce_blowup=4):
+    """A second, cheaper shape (the round-1/2 stand-in, kept as an extra case): additive transitions c_k = c_(k-2) + c_(k-1),
+    each times (X - 3) / (X^n - 1) and (alpha_k X^3 + beta_k), evaluated on a constraint-evaluation domain of `ce_blowup` n points."""
     x = E.X()
     c = [lambda o=0, k=k: E.Trace(k, o) for k in range(ncols)]
     cons = [c[0](1) - (c[ncols - 2]() + c[ncols - 1]()), c[1](1) - (c[ncols - 1]() + c[0](1))]
@@ -36,19 +118,35 @@ def fib_constraints(n_trace, ncols=8):
     for k, cn in enumerate(cons):
         term = cn * zer * (E.Challenge(2 * k) * x ** 3 + E.Challenge(2 * k + 1))
         comp = term if comp is None else comp + term
-    return comp, 2 * len(cons)
+    return comp, ce_blowup, 2 * len(cons)
+
+
+def mixed_air_constraints():
+    """A 17 Fp + 9 Fq3-column composition in the shape of the brainfuck AIR (examples/brainfuck/air.rs:26-27, 68-125:
+    running-product style extension columns driven by base columns and challenges, transition zerofier (X - 1) / (X^64 - 1),
+    one boundary-style term divided by (X - 3)); 4 Fq3 challenges.  -> (expression, number of challenges)."""
+    x = E.X()
+    b = [lambda o=0, k=k: E.Trace(k, o) for k in range(17)]
+    e = [lambda o=0, k=k: E.Trace(17 + k, o) for k in range(9)]
+    expr = None
+    for k in range(9):
+        t = (e[k](1) - e[k]() * (E.Challenge(k % 4) - b[k]() * E.Challenge((k + 1) % 4) - b[k + 8](1))) * (x - 1) / (x ** 64 - 1)
+        expr = t if expr is None else expr + t * E.Challenge(k % 4)
+    expr = expr + (b[16]() ** 2 - b[16]()) * e[0]() / (x - E.Constant(3))
+    return expr, 4
 
 
 class Draws:
     """What the verifier's coin would supply, fixed up front (canonical integers of Fp)."""
 
-    def __init__(self, seed, ncols, nchallenges, blowup, nqueries, n_lde, nlayers):
+    def __init__(self, seed, ncols, nchallenges, ce_blowup, nqueries, n_lde, nlayers):
         rng = np.random.default_rng(seed)
         r = lambda k: [int(v) for v in rng.integers(1, GL_P, size=k, dtype=np.uint64)]
-        self.challenges = r(nchallenges)
+        self.challenges = r(nchallenges)                                        # the composition coefficients (alpha_i, beta_i)
+        self.hints = r(1)                                                       # FibHint::ClaimedNthFibNum
         self.z = r(1)[0]
         self.trace_args = [(c, o) for c in range(ncols) for o in (0, 1)]        # every column at the current and the next row
-        self.deep = DeepCompositionCoeffs(r(len(self.trace_args)), r(blowup), (r(1)[0], r(1)[0]))
+        self.deep = DeepCompositionCoeffs(r(len(self.trace_args)), r(ce_blowup), (r(1)[0], r(1)[0]))
         self.fri_alphas = r(nlayers)
         self.positions = [int(p) for p in rng.integers(0, n_lde, size=nqueries)]
 
@@ -63,15 +161,21 @@ def fri_num_layers(n_lde, blowup, folding, max_remainder_coeffs):
 
 
 def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_remainder_coeffs=64, grinding_bits=8, hash="sha256",
-                 keep=False):
-    """trace: Matrix of Fp columns (2^k rows).  Returns dict(roots=..., fri_roots=[...], remainder=GpuVec, nonce=int,
-    queries=Queries, phases_ms={...}); with keep=True also the intermediate device objects (for parity tests)."""
+                 keep=False, ce_blowup=None):
+    """trace: Matrix of Fp columns (2^k rows).  ce_blowup: the AIR's ce_blowup_factor (src/air.rs:55-59; the constraint
+    evaluation domain has trace_len * ce_blowup points, the composition trace ce_blowup columns); None = the LDE blow-up.
+    Returns dict(roots=..., fri_roots=[...], remainder=GpuVec, nonce=int, queries=Queries, phases_ms={...}); with keep=True
+    also the intermediate device objects (for parity tests)."""
     pl = planner
     n_t = trace.num_rows()
     n_lde = n_t * blowup
-    trace_dom, lde_dom = Radix2EvaluationDomain(n_t), Radix2EvaluationDomain(n_lde, 7)
+    ce_blowup = blowup if ce_blowup is None else ce_blowup
+    assert ce_blowup <= blowup                                                 # src/air.rs:149
+    n_ce = n_t * ce_blowup
+    trace_dom, lde_dom, ce_dom = Radix2EvaluationDomain(n_t), Radix2EvaluationDomain(n_lde, 7), Radix2EvaluationDomain(n_ce, 7)
     prog = E.compile_expr(comp_expr, trace.num_cols(), False)
     ch = np.array([gl_to_mont(c) for c in draws.challenges], dtype=np.uint64).reshape(-1, 1)
+    hints = np.array([gl_to_mont(c) for c in draws.hints], dtype=np.uint64).reshape(-1, 1)
     out, phase = {}, {}
     t = time.perf_counter()
 
@@ -87,11 +191,13 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
     tree_t = MerkleTree.from_matrix(lde_t, hash)                               # prover.rs:52-55
     out["base_root"] = tree_t.root()
     lap("base trace: interpolate + LDE + commit")
-    comp_evals = E.eval(prog, pl, ch, ch[:1], blowup, 7, n_lde, lde_t.columns, bit_reversed=True)       # prover.rs:88-107
+    # the first n_ce rows of the committed (bit-reversed) LDE are the constraint-evaluation coset in its own bit-reversed order:
+    # the evaluator works on them where they lie (the reference re-orders them, bit_reverse_ce_trace, prover.rs:88-91)
+    comp_evals = E.eval(prog, pl, ch, hints, ce_blowup, 7, n_ce, lde_t.columns, bit_reversed=True)      # prover.rs:97-107
     lap("constraint evaluation")
     kept_evals = comp_evals.clone() if keep else None                          # the next two steps work in place
-    comp_poly = Matrix([comp_evals]).bit_reverse_rows().into_polynomials(lde_dom).columns[0]            # prover.rs:111-112
-    comp_polys = Matrix.from_chunks(comp_poly, blowup)                         # prover.rs:113-121
+    comp_poly = Matrix([comp_evals]).bit_reverse_rows().into_polynomials(ce_dom).columns[0]             # prover.rs:111-112
+    comp_polys = Matrix.from_chunks(comp_poly, ce_blowup)                      # prover.rs:113-121
     comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)                       # prover.rs:122
     tree_c = MerkleTree.from_matrix(comp_lde, hash)                            # prover.rs:123-124
     out["composition_root"] = tree_c.root()

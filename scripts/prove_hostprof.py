@@ -10,9 +10,9 @@ n_t = 1 << log_t
 rng = np.random.default_rng(5)
 P = (1 << 64) - (1 << 32) + 1
 trace = Matrix.from_numpy(pl, [rng.integers(0, P, size=n_t, dtype=np.uint64) for _ in range(ncols)], GOLDILOCKS_FP)
-comp, nch = pipeline.fib_constraints(n_t, ncols)
-draws = pipeline.Draws(0xC5, ncols, nch, blowup, 32, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64))
-run = lambda: pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8)
+comp, ce, nch = pipeline.fib_constraints(n_t, ncols)
+draws = pipeline.Draws(0xC5, ncols, nch, ce, 32, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64))
+run = lambda: pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, ce_blowup=ce)
 for _ in range(2):
     r = run()
 pl.sync()

@@ -32,51 +32,54 @@ def test_c3_lde_2_20_x_32_blowup_8_and_commit():
     assert root == want_root
 
 
-def _full_eval(pl, expr, log_n, lde_step, base, ext, ch, fq_is_ext):
+def _full_eval(pl, expr, log_n, lde_step, base, ext, ch, fq_is_ext, hints=None):
     """ALL 2^log_n outputs of the device evaluator against the C restatement of eval_cpu::eval
     (oracle_eval_expr: 512-point chunks, batch inversion), Montgomery words, bit for bit."""
     n = 1 << log_n
+    hints = ch[:1] if hints is None else hints
     prog = E.compile_expr(expr, len(base), fq_is_ext)
-    got = E.eval(prog, pl, ch, ch[:1], lde_step, 7, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
+    got = E.eval(prog, pl, ch, hints, lde_step, 7, n, [GpuVec.from_numpy(pl, c, FP) for c in base],
                  [GpuVec.from_numpy(pl, c, FQ3) for c in ext]).to_numpy()
-    want = cref.eval_expr(expr, log_n, lde_step, 7, base, ext, ch, ch[:1], fq_is_ext)
+    want = cref.eval_expr(expr, log_n, lde_step, 7, base, ext, ch, hints, fq_is_ext)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, f"{bad.size} of {want.size} words differ, first at {bad[:4]}"
 
 
 @pytest.mark.gpu
 def test_c4_fib_air_2_23():
-    # "Constraint composition eval on 2^23-row synthetic AIR" (i): fib AIR, 8 Fp columns, Fq = Fp
+    # "Constraint composition eval on 2^23-row synthetic AIR" (i): the reference's fib AIR exactly -- FibAirConfig::constraints
+    # (examples/fib/main.rs:73-140: 8 boundary / (X - 1), 1 terminal / (X - g^-1), 8 multiplicative transitions
+    # (X - g^-1) / (X^n - 1)) under AirConfig::composition_constraint (src/air.rs:50-82) -- on 8 random Fp columns, Fq = Fp
+    from ministark_amd import pipeline
+    pl = backends.planner("hip")
+    log_n = 23
+    base = [cref.random_elements(1 << log_n, 100 + k) for k in range(8)]
+    for lde_step in (1, 4):       # 1 = its ce_blowup_factor, what src/prover.rs:103 passes for this AIR; 4 exercises strided rotations
+        comp, ce, nch = pipeline.fib_constraints((1 << log_n) // lde_step)
+        assert ce == 1 and nch == 34
+        ch = cref.random_elements(nch, 5).reshape(-1, 1)
+        _full_eval(pl, comp, log_n, lde_step, base, [], ch, False, hints=cref.random_elements(1, 6).reshape(-1, 1))
+
+
+@pytest.mark.gpu
+def test_c4_additive_air_2_23():
+    # a second, cheaper Fp shape (the stand-in of rounds 1-2): 8 additive transitions, one zerofier, degree adjustment X^3
+    from ministark_amd import pipeline
     pl = backends.planner("hip")
     log_n, lde_step = 23, 4
-    x = E.X()
-    c = [lambda o=0, k=k: E.Trace(k, o) for k in range(8)]
-    cons = [c[0](1) - (c[6]() + c[7]()), c[1](1) - (c[7]() + c[0](1))] + [c[k]() - (c[k - 2]() + c[k - 1]()) for k in range(2, 8)]
-    n_trace = 1 << (log_n - 2)
-    zer = (x - E.Constant(pow(GL.root_of_unity(n_trace), -1, P))) / (x ** n_trace - 1)
-    comp = None
-    for k, cn in enumerate(cons):
-        term = cn * zer * (E.Challenge(2 * k) * x ** 3 + E.Challenge(2 * k + 1))
-        comp = term if comp is None else comp + term
+    comp, _, nch = pipeline.additive_constraints((1 << log_n) // lde_step, 8, lde_step)
     base = [cref.random_elements(1 << log_n, 100 + k) for k in range(8)]
-    ch = cref.random_elements(16, 5).reshape(-1, 1)
+    ch = cref.random_elements(nch, 5).reshape(-1, 1)
     _full_eval(pl, comp, log_n, lde_step, base, [], ch, False)
-    _full_eval(pl, comp, log_n, 1, base, [], ch, False)        # lde_step = 1 is what src/prover.rs:103 passes for this AIR
 
 
 @pytest.mark.gpu
 def test_c4_mixed_17_fp_9_fq3_2_23():
     # (ii): the brainfuck shape, 17 Fp + 9 Fq3 columns (examples/brainfuck/air.rs:26-27), at BASELINE's 2^23 points
     pl = backends.planner("hip")
+    from ministark_amd import pipeline
     log_n, lde_step = 23, 2
-    x = E.X()
-    b = [lambda o=0, k=k: E.Trace(k, o) for k in range(17)]
-    e = [lambda o=0, k=k: E.Trace(17 + k, o) for k in range(9)]
-    expr = None
-    for k in range(9):
-        t = (e[k](1) - e[k]() * (E.Challenge(k % 4) - b[k]() * E.Challenge((k + 1) % 4) - b[k + 8](1))) * (x - 1) / (x ** 64 - 1)
-        expr = t if expr is None else expr + t * E.Challenge(k % 4)
-    expr = expr + (b[16]() ** 2 - b[16]()) * e[0]() / (x - E.Constant(3))
+    expr, _ = pipeline.mixed_air_constraints()
     base = [cref.random_elements(1 << log_n, 200 + k) for k in range(17)]
     ext = [cref.random_elements(3 << log_n, 300 + k) for k in range(9)]
     ch = cref.random_elements(12, 6).reshape(-1, 3)
@@ -88,21 +91,16 @@ def test_c4_fib_air_on_the_256_bit_field_2_23():
     # (iii): "256-bit Fq" = the reference's only 256-bit field, Fp252 with Fq = Fp (src/eval_gpu.rs:1054-1082), 8 columns
     from ministark_amd import STARK252_FP
     pl = backends.planner("hip")
+    from ministark_amd import pipeline
     log_n, lde_step = 23, 4
-    x = E.X()
-    c = [lambda o=0, k=k: E.Trace(k, o) for k in range(8)]
-    cons = [c[0](1) - (c[6]() + c[7]()), c[1](1) - (c[7]() + c[0](1))] + [c[k]() - (c[k - 2]() + c[k - 1]()) for k in range(2, 8)]
-    n_trace = 1 << (log_n - 2)
-    comp = None
-    for k, cn in enumerate(cons):
-        term = cn * (x - E.Constant(3)) / (x ** n_trace - 1) * (E.Challenge(2 * k) * x ** 3 + E.Challenge(2 * k + 1))
-        comp = term if comp is None else comp + term
+    comp, ce, nch = pipeline.fib_constraints(1 << (log_n - 2), 8, STARK252_FP)        # FibAirConfig::constraints over the 252-bit field
+    assert ce == 1 and nch == 34
     rng = np.random.default_rng(252)
     # uniformly random canonical residues below 2^251 (< p) as the stored Montgomery words
     cols = [rng.integers(0, 1 << 63, size=4 << log_n, dtype=np.uint64) for _ in range(8)]
     for col in cols:
         col[3::4] >>= np.uint64(4)
-    ch = rng.integers(0, 1 << 59, size=(16, 4), dtype=np.uint64)
+    ch = rng.integers(0, 1 << 59, size=(34, 4), dtype=np.uint64)
     prog = E.compile_expr(comp, 8, False, STARK252_FP)
     got = E.eval(prog, pl, ch, ch[:1], lde_step, 3, 1 << log_n, [GpuVec.from_numpy(pl, col, STARK252_FP) for col in cols]).to_numpy()
     want = cref.eval_expr(comp, log_n, lde_step, 3, cols, [], ch, ch[:1], False, field="f252")

@@ -140,12 +140,15 @@ def test_prover_pipeline_c1_shape(kind):
 
 
 # ---- the C5 shape (fib-like trace, ProofOptions::new(32, 4, 8, 8, 64)) against the C oracle, at size on the GPU ------------
-def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr):
-    """The same transcript on the CPU: oracle/c for every transform, hash, evaluation and the DEEP composition."""
+def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr, ce_blowup=None):
+    """The same transcript on the CPU: oracle/c for every transform, hash, evaluation and the DEEP composition.
+    ce_blowup: the AIR's ce_blowup_factor (constraint-evaluation domain = trace_len * ce_blowup points, src/air.rs:55-59)."""
     import hashlib
     from oracle import cref
+    ce_blowup = blowup if ce_blowup is None else ce_blowup
     log_b = blowup.bit_length() - 1
     log_l = log_t + log_b
+    log_ce = log_t + ce_blowup.bit_length() - 1
     n_t, n_l = 1 << log_t, 1 << log_l
     R = lambda v: np.array([cref.lib().oracle_gl_to_mont(int(v) % cref.GL_P)], dtype=np.uint64)
     out = {}
@@ -154,10 +157,13 @@ def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr):
     lde_br = [cref.bit_reverse(c.copy(), log_l) for c in lde_nat]
     out["base_root"] = cref.sha256_merkle(cref.sha256_rows(lde_br, 1))[1].tobytes()
     ch = np.array([R(c)[0] for c in draws.challenges], dtype=np.uint64).reshape(-1, 1)
-    comp_nat = cref.eval_expr(comp_expr, log_l, blowup, 7, lde_nat, [], ch, ch[:1], False)
-    out["comp_evals_br"] = cref.bit_reverse(comp_nat.copy(), log_l)
-    comp_poly = cref.ntt(comp_nat.copy(), log_l, 1, True, 7)
-    comp_polys = [np.ascontiguousarray(comp_poly[c::blowup]) for c in range(blowup)]          # prover.rs:113-121
+    hints = np.array([R(c)[0] for c in draws.hints], dtype=np.uint64).reshape(-1, 1)
+    # the constraint-evaluation coset h<w_(n ce)> in natural order: every (blowup / ce_blowup)-th point of the LDE coset
+    ce_nat = [np.ascontiguousarray(c[::blowup // ce_blowup]) for c in lde_nat]
+    comp_nat = cref.eval_expr(comp_expr, log_ce, ce_blowup, 7, ce_nat, [], ch, hints, False)     # prover.rs:97-107 (eval_cpu::eval)
+    out["comp_evals_br"] = cref.bit_reverse(comp_nat.copy(), log_ce)
+    comp_poly = cref.ntt(comp_nat.copy(), log_ce, 1, True, 7)                                  # prover.rs:111-112
+    comp_polys = [np.ascontiguousarray(comp_poly[c::ce_blowup]) for c in range(ce_blowup)]    # prover.rs:113-121
     out["comp_polys"] = comp_polys
 
     def evaluate_br(coeffs):                                                                 # bit_reversed_evaluate on the LDE coset
@@ -170,7 +176,7 @@ def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr):
     g = GL.root_of_unity(n_t)
     z = draws.z
     pt = lambda off: (z * pow(g, off, GL.p)) % GL.p
-    z_n = pow(z, blowup, GL.p)
+    z_n = pow(z, ce_blowup, GL.p)
     exec_ood = [cref.horner_eval(polys[c], 1, R(pt(o))) for c, o in draws.trace_args]
     comp_ood = [cref.horner_eval(p, 1, R(z_n)) for p in comp_polys]
     out["ood"] = ([GL.from_mont(int(v[0])) for v in exec_ood], [GL.from_mont(int(v[0])) for v in comp_ood])
@@ -179,9 +185,9 @@ def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr):
         zs = [R(pt(o))[0] for (cc, o) in draws.trace_args if cc == c]
         al = [R(a)[0] for (cc, o), a in zip(draws.trace_args, draws.deep.execution_trace) if cc == c]
         terms.append((np.array(zs, dtype=np.uint64), np.array(al, dtype=np.uint64)))
-    for c in range(blowup):
+    for c in range(ce_blowup):
         terms.append((R(z_n), R(draws.deep.composition_trace[c])))
-    deep_poly = cref.deep_compose(polys + comp_polys, [1] * (len(polys) + blowup), terms, n_t, 1,
+    deep_poly = cref.deep_compose(polys + comp_polys, [1] * (len(polys) + ce_blowup), terms, n_t, 1,
                                   (R(draws.deep.degree[0]), R(draws.deep.degree[1])))
     out["deep_poly"] = deep_poly
     layer = evaluate_br(deep_poly)
@@ -201,18 +207,20 @@ def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr):
     return out
 
 
-def _run_c5(kind, log_t, seed):
+def _run_c5(kind, log_t, seed, air="fib"):
+    """air = "fib": the reference's FibAirConfig (examples/fib/main.rs:73-140: 17 constraints, ce_blowup_factor 1);
+    "additive": the cheaper stand-in of rounds 1-2 on a constraint-evaluation domain as large as the LDE domain."""
     from oracle import cref
     from ministark_amd import pipeline
     pl = backends.planner(kind)
     blowup, folding, ncols = 4, 8, 8
     n_t = 1 << log_t
     cols = [cref.random_elements(n_t, seed + c) for c in range(ncols)]
-    comp, nch = pipeline.fib_constraints(n_t, ncols)
+    comp, ce, nch = pipeline.fib_constraints(n_t, ncols) if air == "fib" else pipeline.additive_constraints(n_t, ncols, blowup)
     nlayers = pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64)
-    draws = pipeline.Draws(seed, ncols, nch, blowup, 32, n_t * blowup, nlayers)
-    got = pipeline.prove_phases(pl, Matrix.from_numpy(pl, cols, FP), comp, draws, blowup, folding, 64, 8, keep=True)
-    want = _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp)
+    draws = pipeline.Draws(seed, ncols, nch, ce, 32, n_t * blowup, nlayers)
+    got = pipeline.prove_phases(pl, Matrix.from_numpy(pl, cols, FP), comp, draws, blowup, folding, 64, 8, keep=True, ce_blowup=ce)
+    want = _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp, ce)
     assert got["base_root"] == want["base_root"]
     assert np.array_equal(got["comp_evals"].to_numpy(), want["comp_evals_br"])
     assert all(np.array_equal(g.to_numpy(), w) for g, w in zip(got["comp_polys"].columns, want["comp_polys"]))
@@ -232,8 +240,18 @@ def test_prover_pipeline_c5_shape_emu():
     _run_c5("emu", 7, 4242)
 
 
+def test_prover_pipeline_additive_air_emu():
+    _run_c5("emu", 7, 4243, air="additive")
+
+
 @pytest.mark.gpu
 def test_prover_pipeline_c5_at_size_hip():
     """BASELINE configs[4] on one GPU: 2^22 rows x 8 columns, blow-up 4 -- every commitment, evaluation, polynomial,
     FRI layer root, the remainder, the nonce and the queried rows against the CPU chain."""
     _run_c5("hip", 22, 0xC5)
+
+
+@pytest.mark.gpu
+def test_prover_pipeline_additive_air_hip():
+    """The second shape: 8 additive transitions evaluated on the whole LDE domain (ce_blowup = 4, four composition columns)."""
+    _run_c5("hip", 20, 0xADD, air="additive")
