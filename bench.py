@@ -74,7 +74,7 @@ def sharded_lde_commit(pl, comm, steps, warmup, log_rows=22, total_cols=32, log_
         lde = trace.lde(1 << log_blowup, 7, True).columns
         pl.sync()
         t1 = time.perf_counter()
-        shard = comm.cols_to_rows(lde, total_cols)
+        shard = comm.cols_to_rows(lde, total_cols, N)
         pl.sync()
         barrier()
         t2 = time.perf_counter()

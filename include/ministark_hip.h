@@ -307,6 +307,18 @@ int ms_comm_rank(ms_ctx* ctx, int* rank, int* nranks);
 int ms_cols_to_rows_alltoall(ms_ctx* ctx, int field, size_t nrows, const void* const* d_my_cols, unsigned my_ncols,
                              unsigned total_cols, void* const* d_shard_cols);
 int ms_allgather_digests(ms_ctx* ctx, const void* d_my_digest32, void* d_all_digests);
+/* The point-to-point schedule ms_cols_to_rows_alltoall executes on rank `rank` of `nranks`, as data (a pure function of
+ * its arguments; no context, no GPU): ops[0 .. *count) in issue order.  MS_XCHG_SEND: blk_bytes bytes of my column
+ * `src_col` (index into d_my_cols) from byte `src_offset` to `peer`; MS_XCHG_RECV: blk_bytes bytes from `peer` into the start
+ * of shard column `dst_col` (index into d_shard_cols); MS_XCHG_COPY: the device-to-device copy of my own block.  Sends and
+ * receives between a pair of ranks match in issue order (RCCL / NCCL point-to-point semantics).  The entry point exists so
+ * that the offsets which run over xGMI can be executed and checked anywhere -- tests/test_exchange_schedule.py replays the
+ * schedules of all ranks on the host for 2, 4 and 8 ranks, and the gloo stand-in of the CPU tests (tests/gloo_comm.py)
+ * issues exactly these operations.  Returns MS_ERR_INVALID when cap is too small (*count = the number needed). */
+enum { MS_XCHG_SEND = 0, MS_XCHG_RECV = 1, MS_XCHG_COPY = 2 };
+typedef struct { uint32_t kind, peer, src_col, dst_col; uint64_t src_offset, bytes; } ms_xchg_op;
+int ms_cols_to_rows_schedule(unsigned nranks, unsigned rank, unsigned my_ncols, unsigned total_cols, size_t blk_bytes,
+                             ms_xchg_op* ops, size_t cap, size_t* count);
 
 #ifdef __cplusplus
 }

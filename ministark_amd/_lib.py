@@ -85,6 +85,7 @@ class Lib:
             "ms_comm_rank": (i, [vp, ctypes.POINTER(i), ctypes.POINTER(i)]),
             "ms_cols_to_rows_alltoall": (i, [vp, i, sz, c_void_pp, u, u, c_void_pp]),
             "ms_allgather_digests": (i, [vp, vp, vp]),
+            "ms_cols_to_rows_schedule": (i, [u, u, u, u, sz, vp, sz, ctypes.POINTER(sz)]),
             "ms_sha256_rows_row_major": (i, [vp, i, sz, u, vp, vp]),
         }
         self.optional = {}

@@ -2298,6 +2298,29 @@ extern "C" int ms_sha256_pow_grind(ms_ctx* ctx, const void* h_seed32, unsigned b
 // multi-GPU exchange over RCCL.  librccl is loaded on first use: a single-GPU user never
 // touches it, and a host that already carries an RCCL (torch does) gets that same copy by soname.
 // ---------------------------------------------------------------------------------------
+// The exchange schedule as data (both builds): ms_cols_to_rows_alltoall below issues exactly these operations.
+extern "C" int ms_cols_to_rows_schedule(unsigned nranks, unsigned rank, unsigned my_ncols, unsigned total_cols, size_t blk_bytes,
+                                        ms_xchg_op* ops, size_t cap, size_t* count) {
+    if (!count || !nranks || rank >= nranks) return fail(MS_ERR_INVALID, "ms_cols_to_rows_schedule: rank %u of %u", rank, nranks);
+    const unsigned G = nranks, me = rank;
+    const unsigned mine = total_cols > me ? (total_cols - me + G - 1) / G : 0;       // columns c = me, me + G, ...
+    if (my_ncols != mine) return fail(MS_ERR_INVALID, "rank %u of %u owns %u of %u columns, %u given", me, G, mine, total_cols, my_ncols);
+    size_t k = 0;
+    auto put = [&](uint32_t kind, uint32_t peer, uint32_t src_col, uint32_t dst_col, uint64_t off) {
+        if (ops && k < cap) ops[k] = ms_xchg_op{kind, peer, src_col, dst_col, off, (uint64_t)blk_bytes};
+        k++;
+    };
+    for (unsigned peer = 0; peer < G; peer++) {
+        if (peer == me) continue;
+        for (unsigned j = 0; j < my_ncols; j++) put(MS_XCHG_SEND, peer, j, 0, (uint64_t)peer * blk_bytes);      // my columns, the peer's rows
+        for (unsigned c = peer; c < total_cols; c += G) put(MS_XCHG_RECV, peer, 0, c, 0);                        // the peer's columns, my rows
+    }
+    for (unsigned j = 0; j < my_ncols; j++) put(MS_XCHG_COPY, me, j, me + j * G, (uint64_t)me * blk_bytes);    // my own block never leaves the device
+    *count = k;
+    if (ops && k > cap) return fail(MS_ERR_INVALID, "ms_cols_to_rows_schedule: %zu operations, room for %zu", k, cap);
+    return MS_OK;
+}
+
 #ifndef MS_EMU
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -2360,7 +2383,9 @@ extern "C" int ms_comm_init(ms_ctx* ctx, int nranks, int rank, const void* h_id1
     return MS_OK;
 }
 extern "C" int ms_comm_destroy(ms_ctx* ctx) {
-    if (!ctx || !ctx->comm) return MS_OK;
+    if (!ctx) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);                    // the other communicator entry points hold it too
+    if (!ctx->comm) return MS_OK;
     (void)hipStreamSynchronize(ctx->stream);
     (void)g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_size = 1;
@@ -2380,26 +2405,35 @@ extern "C" int ms_cols_to_rows_alltoall(ms_ctx* ctx, int field, size_t nrows, co
     if (!fb) return fail(MS_ERR_UNSUPPORTED, "unknown field %d", field);
     const unsigned G = (unsigned)ctx->comm_size, me = (unsigned)ctx->comm_rank;
     if (nrows % G) return fail(MS_ERR_INVALID, "%zu rows do not split over %u ranks", nrows, G);
-    const unsigned mine = total_cols > me ? (total_cols - me + G - 1) / G : 0;       // columns c = me, me + G, ...
-    if (my_ncols != mine) return fail(MS_ERR_INVALID, "rank %u of %u owns %u of %u columns, %u given", me, G, mine, total_cols, my_ncols);
     for (unsigned j = 0; j < my_ncols; j++) if (!d_my_cols[j]) return fail(MS_ERR_INVALID, "null column %u", j);
     for (unsigned c = 0; c < total_cols; c++) if (!d_shard_cols[c]) return fail(MS_ERR_INVALID, "null shard column %u", c);
     const size_t blk = nrows / G * fb;                                                // bytes of one rank's rows of one column
+    size_t nops = 0;
+    MSCHK(ms_cols_to_rows_schedule(G, me, my_ncols, total_cols, blk, nullptr, 0, &nops));      // also checks the ownership count
+    std::vector<ms_xchg_op> ops(nops);
+    MSCHK(ms_cols_to_rows_schedule(G, me, my_ncols, total_cols, blk, ops.data(), nops, &nops));
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     ProfScope ps(ctx, "cols_to_rows_alltoall", (double)blk * total_cols * 2.0);
+    // one group for all point-to-point operations; a failing call must not leave the group open (the communicator and this
+    // thread would stay in group mode): remember the first error, always close the group, then report
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
     NCCLCHK(g_rccl.GroupStart());
-    for (unsigned peer = 0; peer < G; peer++) {
-        if (peer == me) continue;
-        for (unsigned j = 0; j < my_ncols; j++)                                       // my columns, the peer's rows
-            NCCLCHK(g_rccl.Send((const char*)d_my_cols[j] + (size_t)peer * blk, blk, ncclUint8, (int)peer, comm, ctx->stream));
-        for (unsigned c = peer; c < total_cols; c += G)                               // the peer's columns, my rows
-            NCCLCHK(g_rccl.Recv(d_shard_cols[c], blk, ncclUint8, (int)peer, comm, ctx->stream));
+    for (const ms_xchg_op& op : ops) {
+        ncclResult_t r = ncclSuccess;
+        if (op.kind == MS_XCHG_SEND) r = g_rccl.Send((const char*)d_my_cols[op.src_col] + op.src_offset, op.bytes, ncclUint8, (int)op.peer, comm, ctx->stream);
+        else if (op.kind == MS_XCHG_RECV) r = g_rccl.Recv(d_shard_cols[op.dst_col], op.bytes, ncclUint8, (int)op.peer, comm, ctx->stream);
+        if (r != ncclSuccess && first == ncclSuccess) { first = r; what = op.kind == MS_XCHG_SEND ? "ncclSend" : "ncclRecv"; }
+        if (first != ncclSuccess) break;
     }
-    NCCLCHK(g_rccl.GroupEnd());
-    for (unsigned j = 0; j < my_ncols; j++)                                           // my own block never leaves the device
-        HIPCHK(hipMemcpyAsync(d_shard_cols[me + (size_t)j * G], (const char*)d_my_cols[j] + (size_t)me * blk, blk, hipMemcpyDeviceToDevice, ctx->stream));
+    const ncclResult_t rend = g_rccl.GroupEnd();
+    if (first != ncclSuccess) return fail(MS_ERR_HIP, "%s: %s", what, g_rccl.GetErrorString(first));
+    if (rend != ncclSuccess) return fail(MS_ERR_HIP, "ncclGroupEnd: %s", g_rccl.GetErrorString(rend));
+    for (const ms_xchg_op& op : ops)
+        if (op.kind == MS_XCHG_COPY)
+            HIPCHK(hipMemcpyAsync(d_shard_cols[op.dst_col], (const char*)d_my_cols[op.src_col] + op.src_offset, op.bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return MS_OK;
 }
 extern "C" int ms_allgather_digests(ms_ctx* ctx, const void* d_my_digest32, void* d_all_digests) {

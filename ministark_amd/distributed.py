@@ -37,6 +37,24 @@ def owned_columns(total_cols, rank, world):
     return list(range(rank, total_cols, world))
 
 
+class XchgOp(ctypes.Structure):                       # ms_xchg_op (include/ministark_hip.h)
+    _fields_ = [("kind", ctypes.c_uint32), ("peer", ctypes.c_uint32), ("src_col", ctypes.c_uint32), ("dst_col", ctypes.c_uint32),
+                ("src_offset", ctypes.c_uint64), ("bytes", ctypes.c_uint64)]
+
+
+XCHG_SEND, XCHG_RECV, XCHG_COPY = 0, 1, 2
+
+
+def exchange_schedule(lib, world, rank, total_cols, blk_bytes):
+    """ms_cols_to_rows_schedule: the point-to-point operations ms_cols_to_rows_alltoall issues on `rank`, in order."""
+    my_ncols = len(owned_columns(total_cols, rank, world))
+    count = ctypes.c_size_t(0)
+    lib.check(lib.ms_cols_to_rows_schedule(world, rank, my_ncols, total_cols, blk_bytes, None, 0, ctypes.byref(count)))
+    ops = (XchgOp * max(1, count.value))()
+    lib.check(lib.ms_cols_to_rows_schedule(world, rank, my_ncols, total_cols, blk_bytes, ops, count.value, ctypes.byref(count)))
+    return [ops[k] for k in range(count.value)]
+
+
 class RcclComm:
     """The exchange steps of the sharded commitment on one rank: ms_comm_init / ms_cols_to_rows_alltoall /
     ms_allgather_digests over RCCL.  `planner` must be this rank's own context (its own GPU)."""
@@ -67,14 +85,16 @@ class RcclComm:
             dist.broadcast_object_list(box, src=0, group=group)
         return cls(planner, rank, world, box[0])
 
-    def cols_to_rows(self, my_cols, total_cols):
-        """my_cols: this rank's columns of the whole domain (GpuVecs).  -> one GpuVec per column of the
-        matrix, holding this rank's rows."""
+    def cols_to_rows(self, my_cols, total_cols, nrows, field=GOLDILOCKS_FP):
+        """my_cols: this rank's columns of the whole domain (GpuVecs of `nrows` elements of `field`).  -> one GpuVec per
+        column of the matrix, holding this rank's rows.  The geometry is given by the caller, never inferred from my_cols:
+        a rank that owns no column (fewer columns than ranks) must post receives of the same size its peers send."""
         pl, L = self.planner, self.planner.lib
-        field = my_cols[0].field if my_cols else GOLDILOCKS_FP
-        nrows = len(my_cols[0]) if my_cols else 0
         if nrows % self.world:
             raise ValueError("rows do not split over the ranks")
+        for c in my_cols:
+            if len(c) != nrows or c.field != field:
+                raise ValueError("column of the wrong length or field")
         shard = [GpuVec(pl, nrows // self.world, field) for _ in range(total_cols)]
         L.check(L.ms_cols_to_rows_alltoall(pl.handle, field, nrows, _ptr_array(my_cols), len(my_cols), total_cols, _ptr_array(shard)))
         return shard
@@ -114,7 +134,7 @@ def lde_commit_sharded(planner, comm, local_cols, total_cols, log_n, log_blowup,
     lde = Matrix(vecs).lde(1 << log_blowup, offset, True).columns if vecs else []
 
     # 2. column shards -> row shards
-    shard = comm.cols_to_rows(lde, total_cols) if total_cols else []
+    shard = comm.cols_to_rows(lde, total_cols, N, field) if total_cols else []
 
     # 3. hash my rows, build my subtree
     tree = MerkleTree.from_matrix(Matrix(shard), hash)

@@ -44,7 +44,7 @@ def main():
         allc = [cref.random_elements(1 << log_n, 2000 + c) for c in range(ncols)]
         mine = [allc[c] for c in owned_columns(ncols, rank, world)]
         lde_local = Matrix([GpuVec.from_numpy(pl, c) for c in mine]).lde(step, 7, True).columns if mine else []
-        shard = comm.cols_to_rows(lde_local, ncols)
+        shard = comm.cols_to_rows(lde_local, ncols, n_lde)
         x = E.X()
         t = [lambda o=0, k=k: E.Trace(k, o) for k in range(ncols)]
         expr = ((t[0](1) - t[1]() * t[2](-1)) * (x - E.Constant(3)) / (x ** (1 << log_n) - 1) * (E.Challenge(0) * x ** 3 + E.Challenge(1))

@@ -22,31 +22,27 @@ class GlooComm:
         self.planner, self.group = planner, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
-    def cols_to_rows(self, my_cols, total_cols):
+    def cols_to_rows(self, my_cols, total_cols, nrows, field=GOLDILOCKS_FP):
+        """The same arguments as RcclComm.cols_to_rows, and the same operations: the schedule comes from the library's
+        ms_cols_to_rows_schedule (what ms_cols_to_rows_alltoall executes over RCCL), issued here over gloo."""
+        from ministark_amd.distributed import XCHG_COPY, XCHG_RECV, XCHG_SEND, exchange_schedule
         pl = self.planner
         pl.sync()
-        field = my_cols[0].field if my_cols else GOLDILOCKS_FP
         V = FIELD_WORDS[field]
-        nrows = len(my_cols[0]) if my_cols else 0
-        # every rank must agree on the geometry even if it owns no column
-        meta = torch.tensor([nrows, field], dtype=torch.int64)
-        dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self.group)
-        nrows, field = int(meta[0]), int(meta[1])
-        V = FIELD_WORDS[field]
-        blk = nrows // self.world * V
+        blk = nrows // self.world * V                                  # words of one rank's rows of one column
         shard = [GpuVec(pl, nrows // self.world, field) for _ in range(total_cols)]
         mine = [_host_view(c.ptr, nrows * V) for c in my_cols]
         dst = [_host_view(s.ptr, blk) for s in shard]
         ops = []
-        for peer in range(self.world):
-            if peer == self.rank:
-                for j, c in enumerate(range(self.rank, total_cols, self.world)):
-                    dst[c].copy_(mine[j][peer * blk:(peer + 1) * blk])
-                continue
-            for j in range(len(mine)):
-                ops.append(dist.P2POp(dist.isend, mine[j][peer * blk:(peer + 1) * blk], peer, self.group))
-            for c in range(peer, total_cols, self.world):
-                ops.append(dist.P2POp(dist.irecv, dst[c], peer, self.group))
+        for op in exchange_schedule(pl.lib, self.world, self.rank, total_cols, blk * 8):
+            assert op.bytes == blk * 8 and op.src_offset % 8 == 0
+            w0 = op.src_offset // 8
+            if op.kind == XCHG_SEND:
+                ops.append(dist.P2POp(dist.isend, mine[op.src_col][w0:w0 + blk], op.peer, self.group))
+            elif op.kind == XCHG_RECV:
+                ops.append(dist.P2POp(dist.irecv, dst[op.dst_col], op.peer, self.group))
+            elif op.kind == XCHG_COPY:
+                dst[op.dst_col].copy_(mine[op.src_col][w0:w0 + blk])
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()

@@ -49,7 +49,7 @@ def test_rccl_entry_points_world1_hip():
     try:
         cols = [cref.random_elements((1 << 10) * 3, 70 + c) for c in range(3)]
         vecs = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FQ3) for c in cols]
-        shard = comm.cols_to_rows(vecs, 3)
+        shard = comm.cols_to_rows(vecs, 3, 1 << 10, GOLDILOCKS_FQ3)
         assert all(np.array_equal(s.to_numpy(), c) for s, c in zip(shard, cols))
         tree = MerkleTree.from_matrix(Matrix(shard))
         assert comm.allgather_digests(tree.nodes.ptr + 32).to_numpy().tobytes() == tree.root()
@@ -57,7 +57,7 @@ def test_rccl_entry_points_world1_hip():
         want = cref.sha256_merkle(cref.sha256_rows([cref.lde(c, 10, 3, 3, 7, True) for c in cols], 3))[1].tobytes()
         assert root == want
         with pytest.raises(Exception):
-            comm.cols_to_rows(vecs[:2], 3)          # a rank of a 1-rank world owns all 3 columns
+            comm.cols_to_rows(vecs[:2], 3, 1 << 10, GOLDILOCKS_FQ3)          # a rank of a 1-rank world owns all 3 columns
     finally:
         comm.close()
 
