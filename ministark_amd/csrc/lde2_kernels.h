@@ -33,11 +33,11 @@ struct Params {
     const uint64_t* src[MAXC];
     uint64_t* dst[MAXC];
     const uint64_t* wr4;       // w_256^e, 4 plain copies each (the n-point plan's table)
-    const uint64_t* gpl;       // pass A: [j][i1] (G_j^L)^i1 plain, 256 per coset
+    const uint64_t* gpl;       // pass A: [j][i1] (G_j^L)^i1, 256 per coset, 4 plain copies each (the product on the loads uses three)
     const uint64_t* aux;       // pass A: [j][i0] G_j^i0 Montgomery, L per coset
     const uint64_t* tw_lo;     // w_N^e two-level (Montgomery), lo_bits low bits
     const uint64_t* tw_hi;
-    const uint64_t* t2;        // pass B: [k][t] w_L^(k t) Montgomery, 256 x T
+    const uint64_t* t2;        // pass B: [k][t] w_L^(k t), 256 x T, 4 plain copies each (per-lane factor of a limb-form product)
     // UNI (T >= 4): pass A's inter-pass factor (G w_n^k1)^i0, i0 = 64 i0h + t, split as in ntt2_first_pass<.., UNI>:
     const uint64_t* tin4;      // pass A: [i0h][b][a'] w_256^(a' b) w_n^(a' 64 i0h), 4 plain copies     (between the networks)
     const uint64_t* tout4;     // pass A: [j][i0h][b'] G_j^(64 i0h) w_n^(16 b' 64 i0h), 4 plain copies   (after the second network)
@@ -53,16 +53,28 @@ __device__ __forceinline__ uint64_t twn_pow(const Params& P, uint64_t e) {      
 }
 
 // first network of a pass on 16 loaded words (rows 16 a + b): input scale, DFT16, times w_256^(a' b)
-//   IN 0: none; 1: the wave-uniform gpl_j[16 a + b] (pass A); 2: the per-lane q (pass B under UNI)
+//   IN 0: none; 1: the wave-uniform gpl_j[16 a + b] (pass A); 2: the per-lane q (pass B under UNI)   [glimb::mul3_to_limbs]
 //   UNI: the factor after the network comes from tin4 at slot tslot + a' instead of wr4
 template <int IN, bool UNI = false>
-__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, const uint64_t* gpl_j, uint64_t q = 0, unsigned tslot = 0) {
+__device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, const uint64_t* gpl_j, const glimb::Q3& q = glimb::Q3{}, unsigned tslot = 0) {
     glimb::L4 v[16];
-    #pragma unroll
-    for (int a = 0; a < 16; a++) {
-        if constexpr (IN == 1) v[a] = glimb::mul_to_limbs(x[a], ((cptr_t)gpl_j)[16 * a + b]);
-        else if constexpr (IN == 2) v[a] = glimb::mul_to_limbs(x[a], q);
-        else v[a] = glimb::from_u64(x[a]);
+    if constexpr (IN == 1) {
+        #pragma unroll
+        for (int a0 = 0; a0 < 16; a0 += 4) {            // four input scales (24 scalar registers) at a time
+            glimb::Q3 g[4];
+            #pragma unroll
+            for (int e = 0; e < 4; e++) g[e] = msntt2::q3_at(gpl_j, 16 * (a0 + e) + b);
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int e = 0; e < 4; e++) v[a0 + e] = glimb::mul3_to_limbs(x[a0 + e], g[e]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        #pragma unroll
+        for (int a = 0; a < 16; a++) {
+            if constexpr (IN == 2) v[a] = glimb::mul3_to_limbs(x[a], q);
+            else v[a] = glimb::from_u64(x[a]);
+        }
     }
     auto tw4 = [&](int c0, glimb::W4* o) {      // four factors: consecutive slots under UNI (two wide scalar loads)
         if constexpr (UNI) w4x4_at(P.tin4, tslot + c0, o);
@@ -72,13 +84,10 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
         }
     };
     glimb::W4 wn[4];                            // the first group's factors are requested before the network (as msntt2::net1)
-    if constexpr (IN != 1) {                    // ... unless 16 input scales already sit in scalar registers (spills otherwise)
-        tw4(0, wn);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    tw4(0, wn);
+    __builtin_amdgcn_sched_barrier(0);
     glimb::dft<16, false>(v);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (IN == 1) tw4(0, wn);
     #pragma unroll
     for (int g = 0; g < 4; g++) {
         glimb::W4 wc[4];
@@ -87,7 +96,7 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
         if (g < 3) tw4(4 * (g + 1), wn);
         __builtin_amdgcn_sched_barrier(0);
         #pragma unroll
-        for (int j = 0; j < 4; j++) x[4 * g + j] = pin(glimb::mul_fold(v[4 * g + j], wc[j]));
+        for (int j = 0; j < 4; j++) x[4 * g + j] = pin(glimb::mul_fold_co(v[4 * g + j], wc[j]));
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -105,7 +114,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t i0 = (size_t)blockIdx.x * TW + lane;
-    const uint64_t* gpl_j = P.gpl + (size_t)j * 256;
+    const uint64_t* gpl_j = P.gpl + (size_t)j * 256 * 4;
 
     const size_t step = 16 * L;
     uint64_t x[2][16];
@@ -117,7 +126,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     }
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        net1<1, UNI>(x[h], P, w + 8 * h, gpl_j, 0, (blockIdx.x * 16 + w + 8 * h) * 16);
+        net1<1, UNI>(x[h], P, w + 8 * h, gpl_j, glimb::Q3{}, (blockIdx.x * 16 + w + 8 * h) * 16);
         #pragma unroll
         for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
         __builtin_amdgcn_sched_barrier(0);
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
                 w4x4_at(P.tout4, slot0 + 4 * g, wc);
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
-                for (int e = 0; e < 4; e++, q += step) *q = glimb::mul_fold(v[4 * g + e], wc[e]);
+                for (int e = 0; e < 4; e++, q += step) *q = glimb::mul_fold_co(v[4 * g + e], wc[e]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -199,13 +208,13 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
 
     // UNI: the part of pass A's factor that is per lane there, (G_j w_n^k1)^(i0 & 63), is one value per lane and half here
     // (k1 = this lane's row; i0 & 63 = ((b & (64 / T - 1)) T + t, b = w + 8 h): the 128-bit product replaces the conversion
-    uint64_t qh[2] = {0, 0};
+    uint64_t qm[2] = {0, 0};                                 // the factor in Montgomery form; its three plain copies are made per half
     if constexpr (UNI) {
         static_assert(!UNI || T >= 4, "i0 & 63 must not reach the register digit a");
         #pragma unroll
         for (int h = 0; h < 2; h++) {
             const unsigned tl = ((w + 8 * h) & (64 / T - 1)) * T + t, k1 = row0 + rs;
-            qh[h] = gld::mmul(gld::mmul(twn_pow(P, (uint64_t)k1 * tl), P.aux[(size_t)j * L + tl]), 1);
+            qm[h] = gld::mmul(twn_pow(P, (uint64_t)k1 * tl), P.aux[(size_t)j * L + tl]);
         }
     }
     uint64_t x[2][16];
@@ -214,7 +223,9 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
         const uint64_t* p = src + (size_t)(w + 8 * h) * T;
         #pragma unroll
         for (int a = 0; a < 16; a++) { x[h][a] = *p; p += 16 * T; }
-        net1<UNI ? 2 : 0>(x[h], P, w + 8 * h, nullptr, qh[h]);
+        glimb::Q3 qh{};
+        if constexpr (UNI) qh = glimb::q3_from(gld::mmul(qm[h], 1), gld::mmul(qm[h], (uint64_t)1 << 24), gld::mmul(qm[h], (uint64_t)1 << 48));
+        net1<UNI ? 2 : 0>(x[h], P, w + 8 * h, nullptr, qh);
         #pragma unroll
         for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
         __builtin_amdgcn_sched_barrier(0);
@@ -236,13 +247,21 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             for (int b = 0; b < 16; b++) v[b] = glimb::from_u64(xch[(b * 8 + w) * TW + lane]);
             glimb::dft<16, false>(v);
             __syncthreads();                                  // everybody has read the first exchange
-            // k = a' + 16 b': times w_L^(k t), to slot kk = 16 w + b' of the second exchange
+            // k = a' + 16 b': times w_L^(k t) (one factor per lane and output: four plain copies, 32 bytes, read coalesced
+            // along t from a table that lives in L2), to slot kk = 16 w + b' of the second exchange
             #pragma unroll
-            for (int d = 0; d < 16; d++) {
-                uint64_t z = glimb::to_weak(v[d]);
-                if constexpr (T > 1) z = gld::mmul(z, P.t2[(size_t)(ap + 16 * d) * T + t]);
-                xch[(w * 16 + d) * X2P + lane] = pin(z);
-                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < 8; g++) {                     // two factors (16 registers) in flight
+                glimb::W4 wt[2];
+                #pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                    const u64x2* tp = (const u64x2*)(P.t2 + ((size_t)(ap + 16 * (2 * g + e)) * T + t) * 4);
+                    const u64x2 lo = tp[0], hi = tp[1];
+                    wt[e] = glimb::w4_from(lo[0], lo[1], hi[0], hi[1]);
+                }
+                #pragma unroll
+                for (int e = 0; e < 2; e++) xch[(w * 16 + 2 * g + e) * X2P + lane] = pin(glimb::mul_fold_co(v[2 * g + e], wt[e]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();

@@ -960,15 +960,15 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
     const uint64_t wN = gl::root_of_unity(log_n + log_b), wL = gl::root_of_unity(log_n - 8), h = fwd->offset_canon;
     const bool uni = T >= 4;                                      // lde2_kernels.h: uniform split of pass A's factor
     const size_t nt = L >> 6, n_tin = uni ? nt * 256 * 4 : 0, n_tout = uni ? beta * nt * 16 * 4 : 0;
-    std::vector<uint64_t> host(beta * 256 + beta * L + 256 * T + n_tin + n_tout);
+    std::vector<uint64_t> host(beta * 256 * 4 + beta * L + 256 * T * 4 + n_tin + n_tout);
     uint64_t* gpl = host.data();
-    uint64_t* aux = gpl + beta * 256;
+    uint64_t* aux = gpl + beta * 256 * 4;
     uint64_t* t2 = aux + beta * L;
-    uint64_t* tin4 = t2 + 256 * T;
+    uint64_t* tin4 = t2 + 256 * T * 4;
     uint64_t* tout4 = tin4 + n_tin;
+    const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
     if (uni) {
         const uint64_t wn = gl::root_of_unity(log_n);
-        const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
         for (size_t i0h = 0; i0h < nt; i0h++) {
             const uint64_t E = 64 * i0h;
             for (size_t b = 0; b < 16; b++) {
@@ -991,21 +991,21 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
     for (size_t j = 0; j < beta; j++, G = gl::mul(G, wN)) {
         const uint64_t GL = gl::pow(G, (uint64_t)L);
         uint64_t x = 1;
-        for (size_t i = 0; i < 256; i++) { gpl[j * 256 + i] = x; x = gl::mul(x, GL); }          // plain residues
+        for (size_t i = 0; i < 256; i++) { for (int c = 0; c < 4; c++) gpl[(j * 256 + i) * 4 + c] = gl::mul(x, sh[c]); x = gl::mul(x, GL); }   // plain, 4 copies
         x = 1;
         for (size_t i = 0; i < L; i++) { aux[j * L + i] = gl::to_mont(x); x = gl::mul(x, G); }
     }
     for (size_t k = 0; k < 256; k++) {
         const uint64_t wk = gl::pow(wL, (uint64_t)k);
         uint64_t x = 1;
-        for (size_t t = 0; t < T; t++) { t2[k * T + t] = gl::to_mont(x); x = gl::mul(x, wk); }
+        for (size_t t = 0; t < T; t++) { for (int c = 0; c < 4; c++) t2[(k * T + t) * 4 + c] = gl::mul(x, sh[c]); x = gl::mul(x, wk); }          // plain, 4 copies
     }
     ms_ntt_plan::Lde2 l;
     l.log_b = log_b;
     if (hipMalloc(&l.d, host.size() * 8) != hipSuccess) return fail(MS_ERR_NOMEM, "LDE tables (%zu bytes)", host.size() * 8);
     if (hipMemcpy(l.d, host.data(), host.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(l.d); return fail(MS_ERR_HIP, "LDE table upload"); }
-    l.gpl = l.d; l.aux = l.d + beta * 256; l.t2 = l.aux + beta * L;
-    if (uni) { l.tin4 = l.t2 + 256 * T; l.tout4 = l.tin4 + n_tin; }
+    l.gpl = l.d; l.aux = l.d + beta * 256 * 4; l.t2 = l.aux + beta * L;
+    if (uni) { l.tin4 = l.t2 + 256 * T * 4; l.tout4 = l.tin4 + n_tin; }
     fwd->lde2.push_back(l);
     *out = &fwd->lde2.back();
     return MS_OK;
