@@ -31,6 +31,7 @@ enum Op : uint32_t {
     OP_NEG_P, OP_NEG_Q, OP_ADD_PP, OP_ADD_QQ, OP_ADD_QP, OP_MUL_PP, OP_MUL_QQ, OP_MUL_QP,
     OP_INV_P, OP_INV_Q, OP_POW_P, OP_POW_Q, OP_EMBED, OP_STORE_Q, OP_STORE_P,
     OP_XPOW_P,      // internal (eval_opt.h): dst = consts[a] * w_n^(b*i mod n)  ==  x^b with consts[a] = h^b
+    OP_TABLE_P, OP_TABLE_Q,   // internal (eval_opt.h, split_inversions): dst = table a of `periodic` at this launch position
     OP_COUNT
 };
 struct Instr { uint32_t op, dst, a, b; };
@@ -88,6 +89,12 @@ __device__ __forceinline__ gl::Fq3 ev_periodic_q(const EvalParams& P, size_t i, 
     const uint64_t* c = P.periodic[id] + 3 * (i % P.periodic_len[id]);
     return {c[0], c[1], c[2]};
 }
+// full-length tables (one entry per launch position R, whatever the layout): the batch-inverted denominators
+__device__ __forceinline__ uint64_t ev_table_p(const EvalParams& P, size_t R, uint32_t id) { return P.periodic[id][R]; }
+__device__ __forceinline__ gl::Fq3 ev_table_q(const EvalParams& P, size_t R, uint32_t id) {
+    const uint64_t* c = P.periodic[id] + 3 * R;
+    return {c[0], c[1], c[2]};
+}
 __device__ __forceinline__ gl::Fq3 ev_const_q(const EvalParams& P, uint32_t a) { return {P.consts[a], P.consts[a + 1], P.consts[a + 2]}; }
 __device__ __forceinline__ void ev_store_p(const EvalParams& P, size_t i, uint32_t slot, uint64_t v) { (slot ? (uint64_t*)P.periodic[slot - 1] : P.out)[i] = v; }
 __device__ __forceinline__ void ev_store_q(const EvalParams& P, size_t i, uint32_t slot, const gl::Fq3& v) {
@@ -111,6 +118,7 @@ __device__ __forceinline__ f252::E ev252_xpow(const EvalParams& P, size_t i, uin
 __device__ __forceinline__ f252::E ev252_const(const EvalParams& P, uint32_t a) { return f252::E{{P.consts[a], P.consts[a + 1], P.consts[a + 2], P.consts[a + 3]}}; }
 __device__ __forceinline__ f252::E ev252_trace(const EvalParams& P, size_t i, uint32_t col, uint32_t off) { return ev252_load(P.base_cols[col], ev_row(P, i, off)); }
 __device__ __forceinline__ f252::E ev252_periodic(const EvalParams& P, size_t i, uint32_t id) { return ev252_load(P.periodic[id], i % P.periodic_len[id]); }
+__device__ __forceinline__ f252::E ev252_table(const EvalParams& P, size_t R, uint32_t id) { return ev252_load(P.periodic[id], R); }
 __device__ __forceinline__ void ev252_store(const EvalParams& P, size_t i, uint32_t slot, const f252::E& v) {
     msstage::Fp252T::store(slot ? (uint64_t*)P.periodic[slot - 1] : P.out, i, v);
 }
@@ -150,6 +158,8 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
         case OP_STORE_Q: ev_store_q(P, R, I.b, rq[I.a]); break;
         case OP_STORE_P: ev_store_p(P, R, I.b, rp[I.a]); break;
         case OP_XPOW_P: rp[I.dst] = ev_xpow(P, i, I.a, I.b); break;
+        case OP_TABLE_P: rp[I.dst] = ev_table_p(P, R, I.a); break;
+        case OP_TABLE_Q: rq[I.dst] = ev_table_q(P, R, I.a); break;
         default: break;
         }
     }
@@ -178,7 +188,77 @@ __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
         case OP_POW_P: rp[I.dst] = msstage::powu<F>(rp[I.a], I.b); break;
         case OP_STORE_P: ev252_store(P, R, I.b, rp[I.a]); break;
         case OP_XPOW_P: rp[I.dst] = ev252_xpow(P, i, I.a, I.b); break;
+        case OP_TABLE_P: rp[I.dst] = ev252_table(P, R, I.a); break;
         default: break;
+        }
+    }
+}
+
+// ---- batch inversion of a full-length table, in place: t[i] <- t[i]^-1, zeros stay zero (ark_ff::batch_inversion, which
+// eval_cpu.rs:101-107 applies per 512-point chunk and division node).  Montgomery's trick over the K elements of a lane
+// (elements tid + j * stride: coalesced): K - 1 products forward, ONE Fermat inverse, 2 (K - 1) products backward -- 3
+// multiplications + 1/K of an inversion per element instead of 72 (Fp) / ~370 (Fp252) multiplications.  The inverse of a
+// field element is unique and every product is canonical, so the table holds exactly what the per-point inverse produces.
+__device__ __forceinline__ bool ev_is_zero(uint64_t v) { return v == 0; }
+__device__ __forceinline__ bool ev_is_zero(const gl::Fq3& v) { return (v.c0 | v.c1 | v.c2) == 0; }
+__device__ __forceinline__ bool ev_is_zero(const f252::E& v) { return (v.l[0] | v.l[1] | v.l[2] | v.l[3]) == 0; }
+template <class F, int K>
+__global__ void __launch_bounds__(NT) batch_inverse(uint64_t* t, size_t n) {
+    using T = typename F::T;
+    const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;
+    T pre[K];
+    T acc = F::one();
+    #pragma unroll
+    for (int j = 0; j < K; j++) {
+        const size_t i = tid + (size_t)j * stride;
+        pre[j] = acc;
+        if (i < n) { const T v = F::load(t, i); if (!ev_is_zero(v)) acc = F::mul(acc, v); }
+    }
+    T inv = F::inv(acc);
+    #pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        const size_t i = tid + (size_t)j * stride;
+        if (i < n) {
+            const T v = F::load(t, i);
+            if (!ev_is_zero(v)) { F::store(t, i, F::mul(inv, pre[j])); inv = F::mul(inv, v); }
+        }
+    }
+}
+
+// Two levels for fields whose inverse is very expensive (the 252-bit field: ~92 000 instructions): the products of the lanes'
+// K elements go to a scratch array of n / K entries, that array is inverted by batch_inverse (one Fermat inverse per K * K
+// elements), and a second sweep turns each lane's inverted product back into the K inverses.
+template <class F, int K>
+__global__ void __launch_bounds__(NT) batch_inverse_up(const uint64_t* t, size_t n, uint64_t* prod) {
+    using T = typename F::T;
+    const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;
+    T acc = F::one();
+    #pragma unroll
+    for (int j = 0; j < K; j++) {
+        const size_t i = tid + (size_t)j * stride;
+        if (i < n) { const T v = F::load(t, i); if (!ev_is_zero(v)) acc = F::mul(acc, v); }
+    }
+    F::store(prod, tid, acc);                                 // never zero
+}
+template <class F, int K>
+__global__ void __launch_bounds__(NT) batch_inverse_down(uint64_t* t, size_t n, const uint64_t* prod_inv) {
+    using T = typename F::T;
+    const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;
+    T pre[K];
+    T acc = F::one();
+    #pragma unroll
+    for (int j = 0; j < K; j++) {
+        const size_t i = tid + (size_t)j * stride;
+        pre[j] = acc;
+        if (i < n) { const T v = F::load(t, i); if (!ev_is_zero(v)) acc = F::mul(acc, v); }
+    }
+    T inv = F::load(prod_inv, tid);
+    #pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        const size_t i = tid + (size_t)j * stride;
+        if (i < n) {
+            const T v = F::load(t, i);
+            if (!ev_is_zero(v)) { F::store(t, i, F::mul(inv, pre[j])); inv = F::mul(inv, v); }
         }
     }
 }

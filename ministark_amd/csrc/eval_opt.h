@@ -33,7 +33,7 @@ struct SplitProgram {
 static inline bool op_is_q_dst(uint32_t op) {
     switch (op) {
     case OP_CONST_Q: case OP_TRACE_Q: case OP_PERIODIC_Q: case OP_NEG_Q: case OP_ADD_QQ: case OP_ADD_QP:
-    case OP_MUL_QQ: case OP_MUL_QP: case OP_INV_Q: case OP_POW_Q: case OP_EMBED: return true;
+    case OP_MUL_QQ: case OP_MUL_QP: case OP_INV_Q: case OP_POW_Q: case OP_EMBED: case OP_TABLE_Q: return true;
     default: return false;
     }
 }
@@ -216,6 +216,72 @@ static inline SplitProgram split_periodic(const Instr* prog, unsigned ninstr, un
     S.log_period = maxc;
     S.active = hoist || !S.xpows.empty();
     if (!hoist) { S.prologue.clear(); S.table_words.clear(); }
+    return S;
+}
+
+// 3. Batch inversion of x-only denominators.  A division by something built from x, constants and periodic values only --
+//    the (X - 1), (X - g^-1) of boundary / terminal constraints, a zerofier too long to hoist -- costs one Fermat inverse per
+//    point in a per-point program (72 multiplications over Goldilocks, ~370 over the 252-bit field; the reference's CPU
+//    evaluator batch-inverts per 512-point chunk instead, eval_cpu.rs:101-107).  Such denominators are computed for all
+//    points by a small program of their own into full-length tables, inverted there with Montgomery's trick
+//    (eval_kernels.h batch_inverse), and the per-point program reads the inverse back at its position (OP_TABLE_*).
+struct InvSplit {
+    bool active = false;
+    std::vector<Instr> denom, main;          // denom: stores denominator t into table slot first_table + t (STORE b = slot + 1)
+    std::vector<unsigned> table_words;
+};
+static inline InvSplit split_inversions(const Instr* prog, unsigned ninstr, unsigned first_table, unsigned max_tables, unsigned elem_words_p) {
+    InvSplit S;
+    std::vector<char> xo(ninstr, 0), in_den(ninstr, 0), hoisted(ninstr, 0);
+    std::vector<int> defp(256, -1), defq(128, -1);
+    std::vector<std::vector<int>> deps(ninstr);
+    unsigned ntab = 0;
+    for (unsigned k = 0; k < ninstr; k++) {
+        const Instr I = prog[k];
+        unsigned opnd[2][2];
+        const int nop = I.op == OP_XPOW_P ? 0 : op_operands(I, opnd);
+        bool x_only;
+        switch (I.op) {
+        case OP_TRACE_P: case OP_TRACE_Q: case OP_TABLE_P: case OP_TABLE_Q: x_only = false; break;
+        case OP_X_P: case OP_CONST_P: case OP_CONST_Q: case OP_PERIODIC_P: case OP_PERIODIC_Q: case OP_XPOW_P: x_only = true; break;
+        default:
+            x_only = nop > 0;
+            for (int o = 0; o < nop; o++) { const int d = opnd[o][0] ? defq[opnd[o][1]] : defp[opnd[o][1]]; deps[k].push_back(d); if (d < 0 || !xo[d]) x_only = false; }
+        }
+        if (op_is_store(I.op)) continue;
+        xo[k] = x_only;
+        if ((I.op == OP_INV_P || I.op == OP_INV_Q) && x_only && ntab < max_tables) { hoisted[k] = 1; ntab++; for (int d : deps[k]) in_den[d] = 1; }
+        if (op_is_q_dst(I.op)) defq[I.dst] = (int)k; else defp[I.dst] = (int)k;
+    }
+    if (!ntab) return S;
+    for (int k = (int)ninstr - 1; k >= 0; k--) if (in_den[k]) for (int d : deps[k]) if (d >= 0) in_den[d] = 1;
+    unsigned tab = 0;
+    std::vector<Instr> main;
+    for (unsigned k = 0; k < ninstr; k++) {
+        const Instr I = prog[k];
+        if (in_den[k]) S.denom.push_back(I);
+        if (hoisted[k]) {
+            const bool q = I.op == OP_INV_Q;
+            S.denom.push_back(Instr{q ? (uint32_t)OP_STORE_Q : (uint32_t)OP_STORE_P, 0, I.a, first_table + tab + 1});
+            main.push_back(Instr{q ? (uint32_t)OP_TABLE_Q : (uint32_t)OP_TABLE_P, I.dst, first_table + tab, 0});
+            S.table_words.push_back(q ? 3u : elem_words_p);
+            tab++;
+        } else main.push_back(I);
+    }
+    // dead-code elimination of the per-point program (the denominators' own sub-trees, x when nothing else needs it)
+    std::vector<char> lp(256, 0), lq(128, 0), keep(main.size(), 0);
+    for (int k = (int)main.size() - 1; k >= 0; k--) {
+        const Instr I = main[k];
+        unsigned opnd[2][2];
+        const int nop = I.op == OP_XPOW_P ? 0 : op_operands(I, opnd);
+        bool live = op_is_store(I.op);
+        if (!live) { char& l = op_is_q_dst(I.op) ? lq[I.dst] : lp[I.dst]; live = l; l = 0; }
+        if (!live) continue;
+        keep[k] = 1;
+        for (int o = 0; o < nop; o++) (opnd[o][0] ? lq[opnd[o][1]] : lp[opnd[o][1]]) = 1;
+    }
+    for (size_t k = 0; k < main.size(); k++) if (keep[k]) S.main.push_back(main[k]);
+    S.active = true;
     return S;
 }
 

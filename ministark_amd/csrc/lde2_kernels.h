@@ -254,10 +254,9 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
                 glimb::W4 wt[2];
                 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-                    const u64x2* tp = (const u64x2*)(P.t2 + ((size_t)(ap + 16 * (2 * g + e)) * T + t) * 4);
-                    const u64x2 lo = tp[0], hi = tp[1];
-                    wt[e] = glimb::w4_from(lo[0], lo[1], hi[0], hi[1]);
+                    const msntt2::Pair* tp = (const msntt2::Pair*)(P.t2 + ((size_t)(ap + 16 * (2 * g + e)) * T + t) * 4);      // two 16-byte loads
+                    const msntt2::Pair lo = tp[0], hi = tp[1];
+                    wt[e] = glimb::w4_from(lo.x, lo.y, hi.x, hi.y);
                 }
                 #pragma unroll
                 for (int e = 0; e < 2; e++) xch[(w * 16 + 2 * g + e) * X2P + lane] = pin(glimb::mul_fold_co(v[2 * g + e], wt[e]));

@@ -1668,11 +1668,17 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     const unsigned h252_slot = (unsigned)consts.size();       // the Fp252 domain offset travels as one more constant
     if (is252) consts.insert(consts.end(), h252.l, h252.l + 4);
     const Instr* main_prog = split.active ? split.main.data() : prog;
-    const unsigned main_n = split.active ? (unsigned)split.main.size() : ninstr;
+    unsigned main_n = split.active ? (unsigned)split.main.size() : ninstr;
     const unsigned pro_n = (unsigned)split.prologue.size();
+    // ---- rewrite 3: divisions by x-only denominators -> full-length tables, inverted in batches (eval_opt.h split_inversions)
+    const unsigned short_tables = (unsigned)split.table_words.size();
+    InvSplit isplit;
+    if (log_n >= 12) isplit = split_inversions(main_prog, main_n, nperiodic + short_tables, (unsigned)MAXPERIODIC - nperiodic - short_tables, PW);
+    if (isplit.active) { main_prog = isplit.main.data(); main_n = (unsigned)isplit.main.size(); }
+    const unsigned den_n = (unsigned)isplit.denom.size();
     // ---- program(s) + constants -> device
-    const size_t mbytes = (size_t)main_n * sizeof(Instr), pbytes = (size_t)pro_n * sizeof(Instr), cbytes = consts.size() * 8;
-    const size_t poff = (mbytes + 15) & ~(size_t)15, coff = (poff + pbytes + 15) & ~(size_t)15, total = coff + cbytes + 64;
+    const size_t mbytes = (size_t)main_n * sizeof(Instr), pbytes = (size_t)pro_n * sizeof(Instr), dbytes = (size_t)den_n * sizeof(Instr), cbytes = consts.size() * 8;
+    const size_t poff = (mbytes + 15) & ~(size_t)15, doff = (poff + pbytes + 15) & ~(size_t)15, coff = (doff + dbytes + 15) & ~(size_t)15, total = coff + cbytes + 64;
     HIPCHK(hipStreamSynchronize(ctx->stream));               // a previous evaluation may still read the buffer
     if (ctx->prog_bytes < total) {
         if (ctx->prog_buf) HIPCHK(hipFree(ctx->prog_buf));
@@ -1682,6 +1688,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     }
     HIPCHK(hipMemcpy(ctx->prog_buf, main_prog, mbytes, hipMemcpyHostToDevice));
     if (pbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + poff, split.prologue.data(), pbytes, hipMemcpyHostToDevice));
+    if (dbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + doff, isplit.denom.data(), dbytes, hipMemcpyHostToDevice));
     if (cbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + coff, consts.data(), cbytes, hipMemcpyHostToDevice));
     EvalParams E;
     memset(&E, 0, sizeof E);
@@ -1806,6 +1813,43 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     }
     E.prog = (const Instr*)ctx->prog_buf; E.ninstr = main_n; E.n = n; E.log_n = log_n; E.xshift = table_log - log_n;
     E.bitrev = (flags & MS_EVAL_BIT_REVERSED) ? 1 : 0;
+    // ---- the x-only denominators of every point (in the launch's own layout), inverted in place
+    void* inv_tables = nullptr;
+    if (den_n) {
+        size_t words = 0;
+        for (unsigned w : isplit.table_words) words += (size_t)w * n;
+        MSCHK(pooled.alloc(words * 8, &inv_tables));
+        uint64_t* tp = (uint64_t*)inv_tables;
+        for (size_t t = 0; t < isplit.table_words.size(); t++) {
+            E.periodic[nperiodic + short_tables + t] = tp; E.periodic_len[nperiodic + short_tables + t] = (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu);
+            tp += (size_t)isplit.table_words[t] * n;
+        }
+        EvalParams Q = E;
+        Q.prog = (const Instr*)((char*)ctx->prog_buf + doff); Q.ninstr = den_n;
+        {
+            hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(isplit.denom.data(), den_n) : nullptr;
+            ProfScope ps(ctx, "eval_denominators", 0.0);
+            launch(Q, fn);
+        }
+        tp = (uint64_t*)inv_tables;
+        for (size_t t = 0; t < isplit.table_words.size(); t++) {
+            const unsigned w = isplit.table_words[t];
+            ProfScope ps(ctx, "eval_batch_inverse", 16.0 * w * n);
+            if (w == 1) hipLaunchKernelGGL((batch_inverse<msstage::FpT, 16>), dim3((unsigned)((n + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, tp, n);
+            else if (w == 3) hipLaunchKernelGGL((batch_inverse<msstage::Fq3T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
+            else if (n < ((size_t)1 << 16)) hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
+            else {                                             // two levels: one 252-bit Fermat inverse per 64 elements
+                const unsigned blocks = (unsigned)(n / (NT * 8));
+                const size_t m = (size_t)blocks * NT;          // lanes of the sweep = entries of the product array
+                void* prod = nullptr;
+                MSCHK(pooled.alloc(m * 32, &prod));
+                hipLaunchKernelGGL((batch_inverse_up<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, n, (uint64_t*)prod);
+                hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((m + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
+                hipLaunchKernelGGL((batch_inverse_down<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, n, (const uint64_t*)prod);
+            }
+            tp += (size_t)w * n;
+        }
+    }
     {
         hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(main_prog, main_n) : nullptr;   // small domains: the interpreter is quicker than a compilation
         ProfScope ps(ctx, fn ? (is252 ? "eval_program252_jit" : "eval_program_jit") : (is252 ? "eval_program252" : "eval_program"),

@@ -257,3 +257,44 @@ def test_fp252_small_tables_from_the_host(kind):
 @pytest.mark.gpu
 def test_fp252_specialised_kernel_2_16_hip():
     assert "eval_program252_jit" in _check252("hip", 16)
+
+
+@pytest.mark.parametrize("kind", ["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def test_x_only_denominators_are_batch_inverted(kind):
+    """eval_opt.h split_inversions: the (X - 1), (X - g^-1) divisions of the reference's fib AIR (examples/fib/main.rs:73-140) become
+    full-length tables inverted with Montgomery's trick; results must equal the per-point evaluation of eval_cpu::eval -- also
+    on the bit-reversed layout, over the 252-bit field, and with a denominator that is zero at a domain point (0^-1 = 0)."""
+    from ministark_amd import STARK252_FP, pipeline
+    pl = backends.planner(kind)
+    log_n = 12 if kind == "emu" else 17
+    n = 1 << log_n
+    base = [cref.random_elements(n, 100 + k) for k in range(8)]
+    for lde_step in (1, 4):
+        comp, ce, nch = pipeline.fib_constraints(n // lde_step)
+        ch = cref.random_elements(nch, 5).reshape(-1, 1)
+        h = cref.random_elements(1, 6).reshape(-1, 1)
+        prog = E.compile_expr(comp, 8, False)
+        cols = [GpuVec.from_numpy(pl, c, FP) for c in base]
+        want = cref.eval_expr(comp, log_n, lde_step, 7, base, [], ch, h, False)
+        assert np.array_equal(E.eval(prog, pl, ch, h, lde_step, 7, n, cols).to_numpy(), want)
+        br = [GpuVec.from_numpy(pl, cref.bit_reverse(c.copy(), log_n), FP) for c in base]
+        got = E.eval(prog, pl, ch, h, lde_step, 7, n, br, bit_reversed=True).to_numpy()
+        assert np.array_equal(got, cref.bit_reverse(want.copy(), log_n))
+    # a denominator with a root ON the domain (offset 1: x_0 = 1 makes X - 1 vanish) and an Fq3 numerator
+    x = E.X()
+    expr = (E.Trace(0) * E.Challenge(0) + E.Trace(8)) / (x - E.Constant(1)) + E.Trace(1, 1) / (x * x - E.Constant(4))
+    ext = [cref.random_elements(3 * n, 77)]
+    chq = cref.random_elements(3, 8).reshape(-1, 3)
+    prog = E.compile_expr(expr, 8, True)
+    got = E.eval(prog, pl, chq, chq[:1], 1, 1, n, [GpuVec.from_numpy(pl, c, FP) for c in base], [GpuVec.from_numpy(pl, ext[0], FQ3)]).to_numpy()
+    assert np.array_equal(got, cref.eval_expr(expr, log_n, 1, 1, base, ext, chq, chq[:1], True))
+    # the 252-bit field
+    comp, ce, nch = pipeline.fib_constraints(n // 4, 8, STARK252_FP)
+    rng = np.random.default_rng(252)
+    cols = [rng.integers(0, 1 << 63, size=4 * n, dtype=np.uint64) for _ in range(8)]
+    for c in cols:
+        c[3::4] >>= np.uint64(4)
+    ch = rng.integers(0, 1 << 59, size=(nch, 4), dtype=np.uint64)
+    prog = E.compile_expr(comp, 8, False, STARK252_FP)
+    got = E.eval(prog, pl, ch, ch[:1], 4, 3, n, [GpuVec.from_numpy(pl, c, STARK252_FP) for c in cols]).to_numpy()
+    assert np.array_equal(got, cref.eval_expr(comp, log_n, 4, 3, cols, [], ch, ch[:1], False, field="f252"))
