@@ -7,8 +7,9 @@
 //!   * `gpu/Cargo.toml`:  `[features] hip = []`
 //!   * `gpu/build.rs`:    link `ministark_hip` from `$MINISTARK_HIP_LIB_DIR`
 //!   * `gpu/src/lib.rs`:  `#[cfg(feature = "hip")] pub mod hip;`
-//!                        `#[cfg(feature = "hip")] pub use hip::{plan, stage, utils};`
-//!     next to the existing `#[cfg(all(target_arch = "aarch64", target_os = "macos"))]` modules.
+//!   * `gpu/src/prelude.rs`: `#[cfg(feature = "hip")] pub use crate::hip::{get_planner, GpuFft, GpuIfft, ...};`
+//!     next to the existing `#[cfg(all(target_arch = "aarch64", target_os = "macos"))]` re-exports
+//!   (rust/patches/gpu_*.patch; the main crate's arms are rust/patches/src_*.patch).
 //!
 //! These files are source only: the build image has no Rust toolchain.  `sys.rs` is generated from the
 //! header (scripts/gen_rust_sys.py) and checked against it by tests/test_rust_shim.py; the item-for-item
@@ -21,5 +22,6 @@ pub mod stage;
 pub mod sys;
 pub mod utils;
 
-pub use plan::{gen_rpo_merkle_tree, GpuFft, GpuIfft, GpuRpo256ColumnMajor, GpuRpo256RowMajor, Planner, PLANNER};
-pub use utils::{bit_reverse, GpuField, GpuVec};
+pub use plan::{evaluate_device, gen_rpo_merkle_tree, get_planner, lde_device, sha256_commit_device, GpuFft, GpuIfft, GpuRpo256ColumnMajor,
+               GpuRpo256RowMajor, Planner};
+pub use utils::{bit_reverse_device, field_id, DeviceVec};

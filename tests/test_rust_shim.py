@@ -6,6 +6,8 @@ import os
 import re
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP = os.path.join(ROOT, "rust", "gpu", "src", "hip")
 
@@ -74,14 +76,99 @@ def test_wrappers_declare_the_reference_items():
         assert re.search(rf"pub struct {s}<", stage), s
         assert re.search(rf"impl<[^>]*> {s}<[^>]*> \{{\s*pub fn new\(n: usize\)", stage), s
     plan = open(os.path.join(HIP, "plan.rs")).read()
-    for item in ("pub struct Planner", "pub static PLANNER", "pub struct GpuFft", "pub struct GpuIfft", "pub fn encode", "pub fn execute(self)",
+    for item in ("pub struct Planner", "pub fn get_planner() -> &'static Planner", "impl Default for Planner", "transform!(GpuFft, false", "transform!(GpuIfft, true",
+                 "pub fn encode(&mut self, buffer: &'a mut [F])", "pub fn execute(mut self)",
                  "pub struct GpuRpo256ColumnMajor", "pub struct GpuRpo256RowMajor", "pub fn gen_rpo_merkle_tree"):
         assert item in plan, item
     utils = open(os.path.join(HIP, "utils.rs")).read()
-    for item in ("pub trait GpuField", "pub struct GpuVec", "pub fn bit_reverse"):
+    # GpuField and the slice functions bit_reverse / bit_reverse_index are the crate's own platform-independent items
+    # (gpu/src/lib.rs:20-41, gpu/src/utils.rs:4-78): the arm must use them, not redefine them
+    assert "use crate::GpuField;" in utils and "pub trait GpuField" not in utils
+    for item in ("pub struct DeviceVec", "pub fn field_id<F: GpuField>() -> c_int", "pub fn bit_reverse_device"):
         assert item in utils, item
     # every sys:: function the wrappers call is declared
     r = _rust_externs()
     for f in (stage, plan, utils):
         for fn in re.findall(r"sys::(ms_[a-z0-9_]+)\(", f):
             assert fn in r, fn
+
+
+# ---- the callers' view (round 3): what src/matrix.rs / src/fri.rs ask of GpuFft / GpuIfft must exist in the HIP arm with the same shapes
+def _shim_transform_macro():
+    """The `transform!` macro body of rust/gpu/src/hip/plan.rs (both GpuFft and GpuIfft are instances of it)."""
+    text = open(os.path.join(ROOT, "rust", "gpu", "src", "hip", "plan.rs")).read()
+    body = text[text.index("macro_rules! transform"):text.index("transform!(GpuFft")]
+    insts = re.findall(r"transform!\((\w+), (true|false)", text)
+    return body, dict(insts)
+
+
+def test_shim_serves_every_call_the_reference_makes():
+    import json
+    uses = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_gpu_api_uses.json")))
+    body, insts = _shim_transform_macro()
+    assert insts == {"GpuFft": "false", "GpuIfft": "true"}                     # forward / inverse
+    for ty in ("GpuFft", "GpuIfft"):
+        for item in uses[ty]:
+            if item == "from":
+                assert "impl<'a, F: GpuField> From<Radix2EvaluationDomain<F::FftField>> for $name<'a, F>" in body
+            elif item == "MIN_SIZE":
+                m = re.search(r"pub const MIN_SIZE: usize = (\d+);", body)
+                assert m and m.group(1) == uses["metal_signatures"][ty]["MIN_SIZE"]   # the callers' CPU fall-back threshold
+            else:
+                m = re.search(r"pub fn %s\(([^)]*)\)" % item, body)
+                assert m, f"{ty}::{item} missing in the HIP arm"
+                want = uses["metal_signatures"][ty][item]
+                norm = lambda sig: [re.sub(r"'\w+\s*", "", p.split(":", 1)[-1].strip()) for p in sig.replace("mut self", "self").split(",")]
+                assert norm(m.group(1)) == norm(want), (ty, item, m.group(1), want)    # same receiver, same `&mut [F]` host slice
+    # prelude items: planner and the stage the callers name; buffer_no_copy / buffer_mut_no_copy are Metal's unified-memory
+    # wrappers, replaced by DeviceVec in the one arm that uses them (rust/patches/src_matrix.rs.patch: sum_columns_gpu)
+    mod = open(os.path.join(ROOT, "rust", "gpu", "src", "hip", "mod.rs")).read()
+    stage = open(os.path.join(ROOT, "rust", "gpu", "src", "hip", "stage.rs")).read()
+    prelude_patch = open(os.path.join(ROOT, "rust", "patches", "gpu_src_prelude.rs.patch")).read()
+    for item in uses["prelude_items"]:
+        if item.startswith("buffer_"):
+            assert "sum_columns_gpu" in open(os.path.join(ROOT, "rust", "patches", "src_matrix.rs.patch")).read()
+            continue
+        assert re.search(r"\b%s\b" % item, mod + stage), item
+        assert re.search(r"\+pub use crate::hip::\w+::%s;" % item, prelude_patch), item
+
+
+def test_shim_only_calls_declared_entry_points_with_the_right_arity():
+    externs = _rust_externs()
+    for name in ("plan.rs", "stage.rs", "utils.rs"):
+        text = open(os.path.join(ROOT, "rust", "gpu", "src", "hip", name)).read()
+        for m in re.finditer(r"sys::(ms_\w+)\(", text):
+            fn = m.group(1)
+            assert fn in externs, f"{name} calls {fn}, which sys.rs does not declare"
+            # count top-level commas of the call
+            depth, i, commas, nonempty = 1, m.end(), 0, False
+            while depth:
+                ch = text[i]
+                if ch in "([{<" and not (ch == "<" and text[i - 1] == " "):
+                    depth += ch in "([{"
+                elif ch in ")]}":
+                    depth -= 1
+                elif ch == "," and depth == 1:
+                    commas += 1
+                if depth and not ch.isspace():
+                    nonempty = True
+                i += 1
+            nargs = commas + 1 if nonempty else 0
+            assert nargs == len(externs[fn][0]), f"{name}: {fn} called with {nargs} arguments, declared with {len(externs[fn][0])}"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
+def test_patches_apply_to_the_reference(tmp_path):
+    import shutil
+    import subprocess
+    pdir = os.path.join(ROOT, "rust", "patches")
+    patches = sorted(f for f in os.listdir(pdir) if f.endswith(".patch"))
+    assert {"src_matrix.rs.patch", "src_merkle.rs.patch", "src_fri.rs.patch", "gpu_src_lib.rs.patch", "gpu_src_prelude.rs.patch"} <= set(patches)
+    for f in patches:
+        text = open(os.path.join(pdir, f)).read()
+        rel = re.match(r"--- a/(\S+)", text).group(1)
+        dst = tmp_path / rel
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        shutil.copy(os.path.join("/root/reference", rel), dst)
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(pdir, f)], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, f"{f}: {r.stdout}{r.stderr}"
