@@ -319,6 +319,12 @@ enum { MS_XCHG_SEND = 0, MS_XCHG_RECV = 1, MS_XCHG_COPY = 2 };
 typedef struct { uint32_t kind, peer, src_col, dst_col; uint64_t src_offset, bytes; } ms_xchg_op;
 int ms_cols_to_rows_schedule(unsigned nranks, unsigned rank, unsigned my_ncols, unsigned total_cols, size_t blk_bytes,
                              ms_xchg_op* ops, size_t cap, size_t* count);
+/* A batch of point-to-point transfers of device memory in one RCCL group (ncclSend / ncclRecv; kind = MS_XCHG_SEND or
+ * MS_XCHG_RECV): the exchange of whole row shards between the ranks that hold the constraint-evaluation rows when the
+ * number of ranks does not divide the blow-up (ministark_amd/distributed.py eval_constraints_sharded; SURVEY.md 8(e):
+ * src/eval_cpu.rs:116-119 reads rotated rows).  Asynchronous on the context's stream. */
+typedef struct { uint32_t kind, peer; void* d_ptr; uint64_t bytes; } ms_p2p_op;
+int ms_p2p_batch(ms_ctx* ctx, const ms_p2p_op* ops, size_t count);
 
 #ifdef __cplusplus
 }

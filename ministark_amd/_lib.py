@@ -86,6 +86,7 @@ class Lib:
             "ms_cols_to_rows_alltoall": (i, [vp, i, sz, c_void_pp, u, u, c_void_pp]),
             "ms_allgather_digests": (i, [vp, vp, vp]),
             "ms_cols_to_rows_schedule": (i, [u, u, u, u, sz, vp, sz, ctypes.POINTER(sz)]),
+            "ms_p2p_batch": (i, [vp, vp, sz]),
             "ms_sha256_rows_row_major": (i, [vp, i, sz, u, vp, vp]),
         }
         self.optional = {}

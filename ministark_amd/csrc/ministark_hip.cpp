@@ -2480,6 +2480,29 @@ extern "C" int ms_cols_to_rows_alltoall(ms_ctx* ctx, int field, size_t nrows, co
             HIPCHK(hipMemcpyAsync(d_shard_cols[op.dst_col], (const char*)d_my_cols[op.src_col] + op.src_offset, op.bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return MS_OK;
 }
+extern "C" int ms_p2p_batch(ms_ctx* ctx, const ms_p2p_op* ops, size_t count) {
+    if (!ctx || (count && !ops)) return fail(MS_ERR_INVALID, "ms_p2p_batch: null argument");
+    if (!ctx->comm) return fail(MS_ERR_INVALID, "ms_p2p_batch: no communicator (ms_comm_init)");
+    for (size_t k = 0; k < count; k++)
+        if (ops[k].kind > MS_XCHG_RECV || (int)ops[k].peer >= ctx->comm_size || (int)ops[k].peer == ctx->comm_rank || !ops[k].d_ptr)
+            return fail(MS_ERR_INVALID, "ms_p2p_batch: operation %zu (kind %u, peer %u)", k, ops[k].kind, ops[k].peer);
+    if (!count) return MS_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    double bytes = 0;
+    for (size_t k = 0; k < count; k++) bytes += (double)ops[k].bytes;
+    ProfScope ps(ctx, "p2p_batch", bytes);
+    ncclResult_t first = ncclSuccess;
+    NCCLCHK(g_rccl.GroupStart());
+    for (size_t k = 0; k < count && first == ncclSuccess; k++)
+        first = ops[k].kind == MS_XCHG_SEND ? g_rccl.Send(ops[k].d_ptr, ops[k].bytes, ncclUint8, (int)ops[k].peer, comm, ctx->stream)
+                                            : g_rccl.Recv(ops[k].d_ptr, ops[k].bytes, ncclUint8, (int)ops[k].peer, comm, ctx->stream);
+    const ncclResult_t rend = g_rccl.GroupEnd();                 // always closed, see ms_cols_to_rows_alltoall
+    if (first != ncclSuccess) return fail(MS_ERR_HIP, "ncclSend/ncclRecv: %s", g_rccl.GetErrorString(first));
+    if (rend != ncclSuccess) return fail(MS_ERR_HIP, "ncclGroupEnd: %s", g_rccl.GetErrorString(rend));
+    return MS_OK;
+}
 extern "C" int ms_allgather_digests(ms_ctx* ctx, const void* d_my_digest32, void* d_all_digests) {
     if (!ctx || !d_my_digest32 || !d_all_digests) return fail(MS_ERR_INVALID, "ms_allgather_digests: null argument");
     if (!ctx->comm) return fail(MS_ERR_INVALID, "ms_allgather_digests: no communicator (ms_comm_init)");
@@ -2496,4 +2519,5 @@ extern "C" int ms_comm_destroy(ms_ctx*) { return MS_OK; }
 extern "C" int ms_comm_rank(ms_ctx* ctx, int* rank, int* nranks) { if (rank) *rank = 0; if (nranks) *nranks = 1; (void)ctx; return MS_OK; }
 extern "C" int ms_cols_to_rows_alltoall(ms_ctx*, int, size_t, const void* const*, unsigned, unsigned, void* const*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
 extern "C" int ms_allgather_digests(ms_ctx*, const void*, void*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
+extern "C" int ms_p2p_batch(ms_ctx*, const ms_p2p_op*, size_t) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
 #endif

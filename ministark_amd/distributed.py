@@ -37,6 +37,10 @@ def owned_columns(total_cols, rank, world):
     return list(range(rank, total_cols, world))
 
 
+class P2POp(ctypes.Structure):                        # ms_p2p_op
+    _fields_ = [("kind", ctypes.c_uint32), ("peer", ctypes.c_uint32), ("d_ptr", ctypes.c_void_p), ("bytes", ctypes.c_uint64)]
+
+
 class XchgOp(ctypes.Structure):                       # ms_xchg_op (include/ministark_hip.h)
     _fields_ = [("kind", ctypes.c_uint32), ("peer", ctypes.c_uint32), ("src_col", ctypes.c_uint32), ("dst_col", ctypes.c_uint32),
                 ("src_offset", ctypes.c_uint64), ("bytes", ctypes.c_uint64)]
@@ -99,6 +103,14 @@ class RcclComm:
         L.check(L.ms_cols_to_rows_alltoall(pl.handle, field, nrows, _ptr_array(my_cols), len(my_cols), total_cols, _ptr_array(shard)))
         return shard
 
+    def p2p(self, ops):
+        """ops: [(XCHG_SEND | XCHG_RECV, peer, device pointer, bytes)] -> one RCCL group (ms_p2p_batch)."""
+        if not ops:
+            return
+        arr = (P2POp * len(ops))(*[P2POp(k, peer, ptr, nbytes) for k, peer, ptr, nbytes in ops])
+        L = self.planner.lib
+        L.check(L.ms_p2p_batch(self.planner.handle, arr, len(ops)))
+
     def allgather_digests(self, my_digest_ptr):
         out = DeviceBytes(self.planner, 32 * self.world)
         L = self.planner.lib
@@ -147,24 +159,64 @@ def lde_commit_sharded(planner, comm, local_cols, total_cols, log_n, log_blowup,
     return top.root(), shard
 
 
-def eval_constraints_sharded(prog, planner, comm, challenges, hints, lde_step, domain_offset, n, base_shard, ext_shard=()):
-    """Constraint evaluation on this rank's ROW shard of the committed (bit-reversed) LDE, without communication,
-    for lde_step a multiple of the number of ranks G (blow-up >= G, e.g. 8 GPUs and blow-up 8 or 16).
+def eval_constraints_sharded(prog, planner, comm, challenges, hints, lde_step, domain_offset, n, base_shard, ext_shard=(), n_lde=None):
+    """Constraint evaluation on the ROW shards of the committed (bit-reversed) LDE that ms_cols_to_rows_alltoall leaves on
+    the ranks.  n = trace_len * lde_step points of the constraint-evaluation domain (lde_step = the AIR's ce_blowup_factor,
+    src/prover.rs:97-107); n_lde >= n: the LDE domain the shards belong to (rank r holds positions [r n_lde/G, (r+1) n_lde/G)).
+    The first n positions of the bit-reversed LDE are the constraint-evaluation coset in its own bit-reversed order, so the
+    evaluation rows live on the first G_ce = n G / n_lde ranks.
 
-    After ms_cols_to_rows_alltoall rank r holds positions R = r N/G + R' of every column, i.e. the natural indices
-    i = bitrev(R) = G i' + rho with rho = bitrev_g(r), i' = bitrev(R').  Those are the points x_i = (h w^rho) (w^G)^i' -- a
-    coset of the subgroup of order N/G -- and a rotation by lde_step * offset rows moves i' by (lde_step / G) * offset
-    and leaves rho alone: the shard is a self-contained evaluation problem of size N/G with offset h w^rho and step
-    lde_step / G (`eval_cpu::eval`'s arguments, src/eval_cpu.rs:33-42), on which the ordinary evaluator runs.
-    Concatenating the ranks' results in rank order gives the bit-reversed evaluation vector of the whole domain.
-    (When G does not divide lde_step a rotated row lives on another rank; that exchange is not implemented.)"""
+    Returns (GpuVec, first_position, count): this rank's slice of the bit-reversed evaluation vector, or None on a rank
+    that holds no constraint-evaluation row.  Three cases:
+      * n <= n_lde / G: rank 0 holds the whole coset as a prefix of its shard -- the ordinary evaluator, no communication;
+      * G_ce divides lde_step: positions R = r rows + R' are the natural indices i = G_ce i' + rho, rho = bitrev(r): the coset
+        (h w^rho)<w^G_ce>, and a rotation by lde_step * offset rows moves i' by (lde_step / G_ce) * offset and leaves rho
+        alone -- a self-contained problem of size n / G_ce with offset h w^rho and step lde_step / G_ce, no communication;
+      * otherwise (BASELINE configs[4]: blow-up 4, ce_blowup_factor 1, 8 GPUs -> G_ce = 2, lde_step = 1) a rotated row lives
+        on another rank.  In the bit-reversed layout the natural-order neighbour of EVERY row is on the other rank (rows that
+        differ in the low bits of i differ in the high bits of the position), so the "halo" of SURVEY.md 8(e) is a whole
+        shard per peer: the G_ce ranks exchange their shards of every column (ms_p2p_batch, (G_ce - 1) rows columns s bytes
+        into each of them), every one of them then holds the whole coset and evaluates it; the slice it owns is returned."""
     from . import expr as E
     from .api import GL_P, Radix2EvaluationDomain
     G, r = comm.world, comm.rank
-    if lde_step % G:
-        raise ValueError(f"row-sharded evaluation needs lde_step ({lde_step}) to be a multiple of the number of ranks ({G})")
-    g = G.bit_length() - 1
-    rho = int(format(r, f"0{g}b")[::-1], 2) if g else 0
-    w = Radix2EvaluationDomain(n).group_gen
-    shard_offset = (domain_offset * pow(w, rho, GL_P)) % GL_P
-    return E.eval(prog, planner, challenges, hints, lde_step // G, shard_offset, n // G, list(base_shard), list(ext_shard), bit_reversed=True)
+    n_lde = n if n_lde is None else n_lde
+    if n_lde % G or n_lde < n:
+        raise ValueError("the LDE domain must split over the ranks and contain the constraint-evaluation domain")
+    rows = n_lde // G
+    base_shard, ext_shard = list(base_shard), list(ext_shard)
+    if n <= rows:                                   # the whole coset is a prefix of rank 0's shard
+        if r != 0:
+            return None
+        return E.eval(prog, planner, challenges, hints, lde_step, domain_offset, n, base_shard, ext_shard, bit_reversed=True), 0, n
+    G_ce = n // rows
+    if r >= G_ce:
+        return None
+    if lde_step % G_ce == 0:
+        g = G_ce.bit_length() - 1
+        rho = int(format(r, f"0{g}b")[::-1], 2) if g else 0
+        w = Radix2EvaluationDomain(n).group_gen
+        shard_offset = (domain_offset * pow(w, rho, GL_P)) % GL_P
+        out = E.eval(prog, planner, challenges, hints, lde_step // G_ce, shard_offset, rows, base_shard, ext_shard, bit_reversed=True)
+        return out, r * rows, rows
+    # shards of every column -> the whole coset on each of the G_ce ranks
+    L = planner.lib
+    full, ops = [], []
+    for col in base_shard + ext_shard:
+        words = FIELD_WORDS[col.field]
+        if len(col) != rows:
+            raise ValueError("shard column of the wrong length")
+        whole = GpuVec(planner, n, col.field)
+        blk = rows * words * 8
+        L.check(L.ms_copy(planner.handle, whole.ptr + r * blk, col.ptr, blk))
+        for peer in range(G_ce):
+            if peer != r:
+                ops.append((XCHG_SEND, peer, col.ptr, blk))
+                ops.append((XCHG_RECV, peer, whole.ptr + peer * blk, blk))
+        full.append(whole)
+    comm.p2p(ops)
+    res = E.eval(prog, planner, challenges, hints, lde_step, domain_offset, n, full[:len(base_shard)], full[len(base_shard):], bit_reversed=True)
+    mine = GpuVec(planner, rows, res.field)
+    wq = FIELD_WORDS[res.field] * 8
+    L.check(L.ms_copy(planner.handle, mine.ptr, res.ptr + r * rows * wq, rows * wq))
+    return mine, r * rows, rows

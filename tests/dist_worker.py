@@ -33,29 +33,40 @@ def main():
         mine = [allc[c] for c in owned_columns(total_cols, rank, world)]
         root, shard = lde_commit_sharded(pl, comm, mine, total_cols, log_n, log_b, 7, field)
         results.append(root.hex())
-    # row-sharded constraint evaluation on the exchanged shard (lde_step a multiple of the world size): own slice of the
-    # single-device result, computed here from the same seeds
-    if world <= 4:
-        from ministark_amd import GpuVec, Matrix
-        from ministark_amd import expr as E
-        from ministark_amd.distributed import eval_constraints_sharded
-        log_n, log_b, ncols = 6, 2, 3
-        n_lde, step = 1 << (log_n + log_b), 1 << log_b
-        allc = [cref.random_elements(1 << log_n, 2000 + c) for c in range(ncols)]
+    # row-sharded constraint evaluation on the exchanged shards, every shape of eval_constraints_sharded: (log_n, log_b, ce)
+    #   ce a multiple of the ranks that hold evaluation rows -> no communication; otherwise the shard exchange (ms_p2p_batch);
+    #   a coset smaller than one shard -> rank 0 alone.  Each rank checks its slice of the single-device result.
+    from ministark_amd import GpuVec, Matrix
+    from ministark_amd import expr as E
+    from ministark_amd.distributed import eval_constraints_sharded
+    ok = True
+    for log_n, log_b, ce in ((6, 2, 4), (6, 2, 1), (6, 2, 2), (6, 3, 8), (7, 4, 1)):
+        ncols = 3
+        n_t, n_lde, n_ce = 1 << log_n, 1 << (log_n + log_b), (1 << log_n) * ce
+        if n_lde % world or n_lde // world < 2:
+            continue
+        allc = [cref.random_elements(n_t, 2000 + c) for c in range(ncols)]
         mine = [allc[c] for c in owned_columns(ncols, rank, world)]
-        lde_local = Matrix([GpuVec.from_numpy(pl, c) for c in mine]).lde(step, 7, True).columns if mine else []
+        lde_local = Matrix([GpuVec.from_numpy(pl, c) for c in mine]).lde(1 << log_b, 7, True).columns if mine else []
         shard = comm.cols_to_rows(lde_local, ncols, n_lde)
         x = E.X()
         t = [lambda o=0, k=k: E.Trace(k, o) for k in range(ncols)]
-        expr = ((t[0](1) - t[1]() * t[2](-1)) * (x - E.Constant(3)) / (x ** (1 << log_n) - 1) * (E.Challenge(0) * x ** 3 + E.Challenge(1))
+        expr = ((t[0](1) - t[1]() * t[2](-1)) * (x - E.Constant(3)) / (x ** n_t - 1) * (E.Challenge(0) * x ** 3 + E.Challenge(1))
                 + E.Periodic([1, 2, 3, 4]) * t[1](2) + x * t[2]())
         prog = E.compile_expr(expr, ncols, False)
         ch = cref.random_elements(2, 9).reshape(2, 1)
-        got = eval_constraints_sharded(prog, pl, comm, ch, ch[:1], step, 7, n_lde, shard).to_numpy()
-        full_cols = [GpuVec.from_numpy(pl, cref.lde(c, log_n, log_b, 1, 7, True)) for c in allc]
-        want = E.eval(prog, pl, ch, ch[:1], step, 7, n_lde, full_cols, bit_reversed=True).to_numpy()
+        got = eval_constraints_sharded(prog, pl, comm, ch, ch[:1], ce, 7, n_ce, shard, n_lde=n_lde)
+        # single device: the constraint-evaluation coset = the first n_ce rows of the bit-reversed LDE
+        full_cols = [GpuVec.from_numpy(pl, cref.lde(c, log_n, log_b, 1, 7, True)[:n_ce].copy()) for c in allc]
+        want = E.eval(prog, pl, ch, ch[:1], ce, 7, n_ce, full_cols, bit_reversed=True).to_numpy()
         rows = n_lde // world
-        results.append("eval_ok" if np.array_equal(got, want[rank * rows:(rank + 1) * rows]) else "eval_MISMATCH")
+        holds = rank * rows < n_ce
+        if got is None:
+            ok = ok and not holds
+        else:
+            vec, first, count = got
+            ok = ok and holds and first == (0 if n_ce <= rows else rank * rows) and np.array_equal(vec.to_numpy(), want[first:first + count])
+    results.append("eval_ok" if ok else "eval_MISMATCH")
     with open(outfile, "w") as f:
         f.write("\n".join(results))
     dist.destroy_process_group()

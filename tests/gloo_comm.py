@@ -48,6 +48,19 @@ class GlooComm:
                 w.wait()
         return shard
 
+    def p2p(self, ops):
+        """RcclComm.p2p over gloo: [(kind, peer, simulator "device" pointer, bytes)] as one batch of isend / irecv."""
+        from ministark_amd.distributed import XCHG_SEND
+        self.planner.sync()
+        batch = []
+        for kind, peer, ptr, nbytes in ops:
+            assert nbytes % 8 == 0
+            view = _host_view(ptr, nbytes // 8)
+            batch.append(dist.P2POp(dist.isend if kind == XCHG_SEND else dist.irecv, view, peer, self.group))
+        if batch:
+            for w in dist.batch_isend_irecv(batch):
+                w.wait()
+
     def allgather_digests(self, my_digest_ptr):
         self.planner.sync()
         mine = _host_view(my_digest_ptr, 4).clone()

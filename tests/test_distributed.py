@@ -20,7 +20,7 @@ def _expected():
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_commit_matches_single_device_gloo(tmp_path, world):
     port = str(29500 + (os.getpid() % 400) + world)
     procs, files = [], []
