@@ -13,10 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libministark_hip.so")
-SOURCES = ["ministark_hip.cpp"]
+SOURCES = ["ms_core.cpp", "ms_ntt.cpp", "ms_stage.cpp", "ms_hash.cpp", "ms_eval.cpp", "ms_deep.cpp", "ms_comm.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-         "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+OBJDIR = os.path.join(HERE, "_obj")
 
 
 def _deps():
@@ -60,19 +60,39 @@ def source_hash(cmd):
 
 
 def build(force=False, verbose=True):
+    """One hipcc -c per translation unit, in parallel, then one link: the library is seven units (context / NTT / stages /
+    hashes / constraint evaluation / DEEP / RCCL exchange) instead of one 2 400-line file."""
+    from concurrent.futures import ThreadPoolExecutor
     embed_headers()
-    cmd = [HIPCC] + FLAGS + os.environ.get("MS_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO, "-lhiprtc", "-ldl"]
-    want = source_hash(cmd)
-    if not force and os.path.exists(SO) and os.path.exists(STAMP) and open(STAMP).read().strip() == want:
+    extra = os.environ.get("MS_HIPCC_FLAGS", "").split()
+    cmd_id = [HIPCC] + FLAGS + extra + SOURCES + ["-lhiprtc", "-ldl"]
+    want = source_hash(cmd_id)
+    have = open(STAMP).read().strip() if os.path.exists(STAMP) else None
+    if not force and os.path.exists(SO) and have == want:
         return SO
     if not os.path.exists(HIPCC):
-        # a box without the compiler (none is expected): keep a binary that is at least present
+        # a box without the compiler (none is expected): keep a binary that is at least present -- and say so when it is stale
         if os.path.exists(SO):
+            if have != want:
+                print(f"[ministark_amd.build] WARNING: {HIPCC} not found and {SO} was built from different sources "
+                      f"(stamp {str(have)[:12]} != {want[:12]}); using it as it is", file=sys.stderr, flush=True)
             return SO
         raise FileNotFoundError(f"{HIPCC} not found and {SO} has not been built")
+    os.makedirs(OBJDIR, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, src.replace(".cpp", ".o"))
+        cmd = [HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[ministark_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO, "-lhiprtc", "-ldl"]
     if verbose:
-        print("[ministark_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print("[ministark_amd.build]", " ".join(link), flush=True)
+    subprocess.check_call(link)
     with open(STAMP, "w") as f:
         f.write(want + "\n")
     return SO

@@ -187,7 +187,7 @@ struct HornerParams {
     size_t n;
     unsigned nblocks;
 };
-__global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
+static __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
     __shared__ uint64_t sh[NT * 4];
     const unsigned q = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
     const uint64_t* col = P.cols[P.qcol[q]];
@@ -223,7 +223,7 @@ struct DeepParams {
     size_t n;
     unsigned nterms, npoints, lo_bits;
 };
-__global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
+static __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= P.n) return;
     E x = ld(P.tw_lo, i & ((1u << P.lo_bits) - 1));
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
     }
     st(P.out, i, acc);
 }
-__global__ void __launch_bounds__(NT) deep_degree_adjust(uint64_t* dst, const uint64_t* src, size_t n, E alpha, E beta) {
+static __global__ void __launch_bounds__(NT) deep_degree_adjust(uint64_t* dst, const uint64_t* src, size_t n, E alpha, E beta) {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
     const E c = ld(src, i), prev = i ? ld(src, i - 1) : f252::zero();

@@ -32,7 +32,7 @@ __device__ __forceinline__ f252::E pow2l(const uint64_t* lo, const uint64_t* hi,
 }
 
 // stages 1..min(CHUNK_LOG, log_n) of a DIT transform whose input is already bit-reversed
-__global__ void __launch_bounds__(NT) ntt252_local(Params P) {
+static __global__ void __launch_bounds__(NT) ntt252_local(Params P) {
     __shared__ uint64_t lds[4 << CHUNK_LOG];
     const unsigned clog = P.log_n < (unsigned)CHUNK_LOG ? P.log_n : (unsigned)CHUNK_LOG;
     const size_t chunk = (size_t)1 << clog, base = (size_t)blockIdx.x * chunk;

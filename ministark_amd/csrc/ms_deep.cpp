@@ -1,0 +1,260 @@
+// DEEP composition on the device: out-of-domain evaluations and the composition polynomial (src/composer.rs:43-188).
+#include "ms_internal.h"
+#include "stage_kernels.h"
+#include "fp252_kernels.h"
+#include "deep_kernels.h"
+
+// ---------------------------------------------------------------------------------------
+// DEEP composition
+// ---------------------------------------------------------------------------------------
+static int point_words(int point_field, unsigned* PW) {
+    if (point_field == MS_GOLDILOCKS_FP) { *PW = 1; return MS_OK; }
+    if (point_field == MS_GOLDILOCKS_FQ3) { *PW = 3; return MS_OK; }
+    return fail(MS_ERR_UNSUPPORTED, "point field must be Goldilocks Fp or Fq3");
+}
+static gl::Fq3 q3_load(const uint64_t* p, unsigned PW) { return PW == 3 ? gl::Fq3{p[0], p[1], p[2]} : gl::Fq3{p[0], 0, 0}; }
+
+// ---- the 252-bit instantiations (Fq = Fp = Fp252)
+static int horner_eval252(ms_ctx* ctx, size_t n, const void* const* d_cols, unsigned ncols, const unsigned* h_qcol, const uint64_t* h_qpoints,
+                          unsigned nq, uint64_t* h_out) {
+    if (ncols > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per call", msdeep::MAXCOLS);
+    if (nq == 0) return MS_OK;
+    for (unsigned q = 0; q < nq; q++) if (h_qcol[q] >= ncols) return fail(MS_ERR_INVALID, "query %u names column %u of %u", q, h_qcol[q], ncols);
+    const unsigned nblocks = (unsigned)std::max<size_t>(1, (n + 4095) / 4096);
+    void *d_qcol = nullptr, *d_pts = nullptr, *d_part = nullptr;
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
+    MSCHK(pooled.alloc((size_t)nq * 32, &d_pts));
+    MSCHK(pooled.alloc((size_t)nq * nblocks * 32, &d_part));
+    std::vector<uint64_t> part((size_t)nq * nblocks * 4);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIPCHK(hipSetDevice(ctx->device));
+        HIPCHK(hipMemcpyAsync(d_qcol, h_qcol, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_pts, h_qpoints, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+        msdeep252::HornerParams H;
+        memset(&H, 0, sizeof H);
+        for (unsigned c = 0; c < ncols; c++) H.cols[c] = (const uint64_t*)d_cols[c];
+        H.qcol = (const uint32_t*)d_qcol; H.qpoint = (const uint64_t*)d_pts; H.partial = (uint64_t*)d_part; H.n = n; H.nblocks = nblocks;
+        {
+            ProfScope ps(ctx, "horner_blocks252", 32.0 * n * nq);
+            hipLaunchKernelGGL(msdeep252::horner_blocks, dim3(nblocks, nq), dim3(msdeep252::NT), 0, ctx->stream, H);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    for (unsigned q = 0; q < nq; q++) {                       // sum_b E_b * (x^4096)^b
+        f252::E xb;
+        memcpy(xb.l, h_qpoints + 4 * (size_t)q, 32);
+        for (int sq = 0; sq < 12; sq++) xb = f252::mul(xb, xb);
+        f252::E acc = f252::zero();
+        for (unsigned b = nblocks; b-- > 0;) {
+            f252::E e;
+            memcpy(e.l, &part[((size_t)q * nblocks + b) * 4], 32);
+            acc = f252::add(f252::mul(acc, xb), e);
+        }
+        memcpy(h_out + 4 * (size_t)q, acc.l, 32);
+    }
+    return MS_OK;
+}
+static int deep_compose252(ms_ctx* ctx, unsigned log_n, const void* h_offset, const void* const* d_polys, unsigned ncols,
+                           const uint64_t* h_points, unsigned npoints, const unsigned* h_term_col, const unsigned* h_term_point,
+                           const uint64_t* h_term_alpha, const uint64_t* h_term_ood, unsigned nterms,
+                           const uint64_t* h_degree_alpha, const uint64_t* h_degree_beta, void* d_out) {
+    if (ncols > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns", msdeep::MAXCOLS);
+    if (npoints == 0 || npoints > (unsigned)msdeep::MAXPOINTS) return fail(MS_ERR_UNSUPPORTED, "1..%d distinct out-of-domain points", msdeep::MAXPOINTS);
+    if (log_n > 40) return fail(MS_ERR_INVALID, "log_n too large");
+    for (unsigned t = 0; t < nterms; t++)
+        if (h_term_col[t] >= ncols || h_term_point[t] >= npoints) return fail(MS_ERR_INVALID, "term %u out of range", t);
+    f252::E h = f252::to_mont(f252::E{{3, 0, 0, 0}});          // the field's generator (gpu/src/fields.rs:241)
+    if (h_offset) memcpy(h.l, h_offset, 32);
+    if (f252::is_zero(h) || f252::geq_p(h)) return fail(MS_ERR_INVALID, "coset offset must be a non-zero canonical element");
+    const size_t n = (size_t)1 << log_n;
+    std::vector<void*> ev(ncols, nullptr);
+    void *d_terms = nullptr, *d_q = nullptr;
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    for (unsigned c = 0; c < ncols; c++) MSCHK(pooled.alloc(n * 32, &ev[c]));
+    MSCHK(pooled.alloc(std::max<size_t>(1, nterms) * sizeof(msdeep252::Term), &d_terms));
+    MSCHK(pooled.alloc(n * 32, &d_q));
+    std::vector<msdeep252::Term> terms(nterms);
+    for (unsigned t = 0; t < nterms; t++) {
+        terms[t].col = h_term_col[t]; terms[t].point = h_term_point[t];
+        memcpy(terms[t].alpha, h_term_alpha + 4 * (size_t)t, 32);
+        memcpy(terms[t].ood, h_term_ood + 4 * (size_t)t, 32);
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIPCHK(hipSetDevice(ctx->device));
+        if (nterms) HIPCHK(hipMemcpyAsync(d_terms, terms.data(), nterms * sizeof(msdeep252::Term), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ms_ntt_plan *fwd = nullptr, *inv = nullptr, *sub = nullptr;
+        MSCHK(plan252_cached(ctx, log_n, false, h, &fwd));
+        MSCHK(plan252_cached(ctx, log_n, true, h, &inv));
+        MSCHK(plan252_cached(ctx, log_n, false, f252::one(), &sub));           // its tables hold w_n^i
+        if (ncols) MSCHK(plan_run(fwd, d_polys, ev.data(), ncols, 256));
+        msdeep252::DeepParams D;
+        memset(&D, 0, sizeof D);
+        for (unsigned c = 0; c < ncols; c++) D.cols[c] = (const uint64_t*)ev[c];
+        D.terms = (const msdeep252::Term*)d_terms; D.tw_lo = sub->d252_tw_lo; D.tw_hi = sub->d252_tw_hi; D.lo_bits = sub->lo_bits;
+        memcpy(D.points, h_points, (size_t)npoints * 32);
+        memcpy(D.h, h.l, 32);
+        D.out = (uint64_t*)d_q; D.n = n; D.nterms = nterms; D.npoints = npoints;
+        const dim3 g((unsigned)((n + msdeep252::NT - 1) / msdeep252::NT));
+        { ProfScope ps(ctx, "deep_points252", 32.0 * n * (ncols + 1));
+          hipLaunchKernelGGL(msdeep252::deep_points, g, dim3(msdeep252::NT), 0, ctx->stream, D); }
+        HIPCHK(hipGetLastError());
+        const void* qsrc[1] = {d_q};
+        void* qdst[1] = {d_q};
+        MSCHK(plan_run(inv, qsrc, qdst, 1, 256));
+        f252::E da, db;
+        memcpy(da.l, h_degree_alpha, 32);
+        memcpy(db.l, h_degree_beta, 32);
+        { ProfScope ps(ctx, "deep_degree_adjust252", 64.0 * n);
+          hipLaunchKernelGGL(msdeep252::deep_degree_adjust, g, dim3(msdeep252::NT), 0, ctx->stream, (uint64_t*)d_out, (const uint64_t*)d_q, n, da, db); }
+        HIPCHK(hipGetLastError());
+    }
+    return MS_OK;
+}
+
+extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, size_t n, const void* const* d_cols, unsigned ncols,
+                              const unsigned* h_qcol, const void* h_qpoints, unsigned nq, void* h_out) {
+    if (!ctx || !d_cols || !h_qcol || !h_qpoints || !h_out) return fail(MS_ERR_INVALID, "ms_horner_eval: null argument");
+    if (coeff_field == MS_STARK252_FP || point_field == MS_STARK252_FP) {
+        if (coeff_field != point_field) return fail(MS_ERR_UNSUPPORTED, "the 252-bit field has no extension: coefficients and points must both be Fp252");
+        return horner_eval252(ctx, n, d_cols, ncols, h_qcol, (const uint64_t*)h_qpoints, nq, (uint64_t*)h_out);
+    }
+    unsigned CW = 0, PW = 0;
+    MSCHK(point_words(coeff_field, &CW));
+    MSCHK(point_words(point_field, &PW));
+    if (CW > PW) return fail(MS_ERR_UNSUPPORTED, "coefficients must embed into the point field");
+    if (ncols > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per call", msdeep::MAXCOLS);
+    if (nq == 0) return MS_OK;
+    for (unsigned q = 0; q < nq; q++) if (h_qcol[q] >= ncols) return fail(MS_ERR_INVALID, "query %u names column %u of %u", q, h_qcol[q], ncols);
+    const unsigned nblocks = (unsigned)std::max<size_t>(1, (n + 4095) / 4096);
+    // device staging: qcol (u32), qpoints (3 words), partials
+    std::vector<uint64_t> pts((size_t)nq * 3, 0);
+    for (unsigned q = 0; q < nq; q++) memcpy(&pts[3 * q], (const uint64_t*)h_qpoints + (size_t)q * PW, PW * 8);
+    void *d_qcol = nullptr, *d_pts = nullptr, *d_part = nullptr;
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
+    MSCHK(pooled.alloc((size_t)nq * 24, &d_pts));
+    MSCHK(pooled.alloc((size_t)nq * nblocks * 24, &d_part));
+    std::vector<uint64_t> part((size_t)nq * nblocks * 3);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIPCHK(hipSetDevice(ctx->device));
+        HIPCHK(hipMemcpyAsync(d_qcol, h_qcol, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_pts, pts.data(), (size_t)nq * 24, hipMemcpyHostToDevice, ctx->stream));
+        msdeep::HornerParams H;
+        memset(&H, 0, sizeof H);
+        for (unsigned c = 0; c < ncols; c++) H.cols[c] = (const uint64_t*)d_cols[c];
+        H.qcol = (const uint32_t*)d_qcol; H.qpoint = (const uint64_t*)d_pts; H.partial = (uint64_t*)d_part; H.n = n; H.nblocks = nblocks;
+        dim3 g(nblocks, nq);
+        {
+            ProfScope ps(ctx, "horner_blocks", 8.0 * CW * n * nq);
+            if (CW == 1 && PW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 1>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+            else if (CW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 3>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+            else hipLaunchKernelGGL((msdeep::horner_blocks<3, 3>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    // combine the block values on the host: sum_b E_b * (x^4096)^b
+    for (unsigned q = 0; q < nq; q++) {
+        gl::Fq3 x = q3_load(&pts[3 * q], 3), xb = x;
+        for (int sq = 0; sq < 12; sq++) xb = gl::mont_mul(xb, xb);
+        gl::Fq3 acc = {0, 0, 0};
+        for (unsigned b = nblocks; b-- > 0;) acc = gl::add(gl::mont_mul(acc, xb), q3_load(&part[((size_t)q * nblocks + b) * 3], 3));
+        uint64_t* o = (uint64_t*)h_out + (size_t)q * PW;
+        o[0] = acc.c0;
+        if (PW == 3) { o[1] = acc.c1; o[2] = acc.c2; }
+    }
+    return MS_OK;
+}
+
+extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, const void* h_offset,
+                               const void* const* d_base_polys, unsigned nbase, const void* const* d_ext_polys, unsigned next,
+                               const void* h_points, unsigned npoints, const unsigned* h_term_col, const unsigned* h_term_point,
+                               const void* h_term_alpha, const void* h_term_ood, unsigned nterms,
+                               const void* h_degree_alpha, const void* h_degree_beta, void* d_out) {
+    if (!ctx || !h_points || !h_term_col || !h_term_point || !h_term_alpha || !h_term_ood || !h_degree_alpha || !h_degree_beta || !d_out)
+        return fail(MS_ERR_INVALID, "ms_deep_compose: null argument");
+    if (point_field == MS_STARK252_FP) {
+        if (next) return fail(MS_ERR_INVALID, "the 252-bit field has no extension columns: pass every polynomial as a base column");
+        if (nbase && !d_base_polys) return fail(MS_ERR_INVALID, "ms_deep_compose: null column table");
+        return deep_compose252(ctx, log_n, h_offset, d_base_polys, nbase, (const uint64_t*)h_points, npoints, h_term_col, h_term_point,
+                               (const uint64_t*)h_term_alpha, (const uint64_t*)h_term_ood, nterms, (const uint64_t*)h_degree_alpha,
+                               (const uint64_t*)h_degree_beta, d_out);
+    }
+    unsigned PW = 0;
+    MSCHK(point_words(point_field, &PW));
+    if (PW == 1 && next) return fail(MS_ERR_INVALID, "extension columns need point_field = Fq3");
+    if (nbase > (unsigned)msdeep::MAXCOLS || next > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns of each kind", msdeep::MAXCOLS);
+    if (npoints == 0 || npoints > (unsigned)msdeep::MAXPOINTS) return fail(MS_ERR_UNSUPPORTED, "1..%d distinct out-of-domain points", msdeep::MAXPOINTS);
+    if ((nbase && !d_base_polys) || (next && !d_ext_polys)) return fail(MS_ERR_INVALID, "ms_deep_compose: null column table");
+    if (log_n > 32) return fail(MS_ERR_INVALID, "log_n too large");
+    for (unsigned t = 0; t < nterms; t++)
+        if (h_term_col[t] >= nbase + next || h_term_point[t] >= npoints) return fail(MS_ERR_INVALID, "term %u out of range", t);
+    uint64_t h = gl::GENERATOR;
+    if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
+    if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
+    const size_t n = (size_t)1 << log_n;
+    // scratch: coset evaluations of every polynomial + the evaluation/coefficient column of Q
+    std::vector<void*> ev(nbase + next, nullptr);
+    void *d_terms = nullptr, *d_q = nullptr;
+    PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    for (unsigned c = 0; c < nbase; c++) MSCHK(pooled.alloc(n * 8, &ev[c]));
+    for (unsigned c = 0; c < next; c++) MSCHK(pooled.alloc(n * 24, &ev[nbase + c]));
+    MSCHK(pooled.alloc(std::max<size_t>(1, nterms) * sizeof(msdeep::Term), &d_terms));
+    MSCHK(pooled.alloc(n * PW * 8, &d_q));
+    std::vector<msdeep::Term> terms(nterms);
+    for (unsigned t = 0; t < nterms; t++) {
+        memset(&terms[t], 0, sizeof(msdeep::Term));
+        terms[t].col = h_term_col[t]; terms[t].point = h_term_point[t];
+        memcpy(terms[t].alpha, (const uint64_t*)h_term_alpha + (size_t)t * PW, PW * 8);
+        memcpy(terms[t].ood, (const uint64_t*)h_term_ood + (size_t)t * PW, PW * 8);
+    }
+    int rc = MS_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIPCHK(hipSetDevice(ctx->device));
+        if (nterms) HIPCHK(hipMemcpyAsync(d_terms, terms.data(), nterms * sizeof(msdeep::Term), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));            // `terms` is a host temporary
+        ms_ntt_plan *f1 = nullptr, *f3 = nullptr, *inv = nullptr, *tw = nullptr;
+        if (nbase) { MSCHK(ctx_plan(ctx, 1, log_n, false, h, &f1)); rc = plan_run(f1, d_base_polys, ev.data(), nbase, 256); }
+        if (rc == MS_OK && next) { MSCHK(ctx_plan(ctx, 3, log_n, false, h, &f3)); rc = plan_run(f3, d_ext_polys, ev.data() + nbase, next, 256); }
+        if (rc != MS_OK) return rc;
+        const unsigned tl = std::max(log_n, 12u);
+        MSCHK(ctx_plan(ctx, 1, tl, false, 1, &tw));
+        msdeep::DeepParams D;
+        memset(&D, 0, sizeof D);
+        for (unsigned c = 0; c < nbase; c++) D.base[c] = (const uint64_t*)ev[c];
+        for (unsigned c = 0; c < next; c++) D.ext[c] = (const uint64_t*)ev[nbase + c];
+        D.terms = (const msdeep::Term*)d_terms; D.tw_lo = tw->d_tw_lo; D.tw_hi = tw->d_tw_hi; D.lo_bits = tw->lo_bits; D.xshift = tl - log_n;
+        for (unsigned k = 0; k < npoints; k++) memcpy(D.points[k], (const uint64_t*)h_points + (size_t)k * PW, PW * 8);
+        D.out = (uint64_t*)d_q; D.h_mont = gl::to_mont(h); D.n = n; D.nbase = nbase; D.nterms = nterms; D.npoints = npoints;
+        dim3 g((unsigned)((n + msdeep::NT - 1) / msdeep::NT));
+        {
+            ProfScope ps(ctx, "deep_points", 8.0 * n * (nbase + 3.0 * next + PW));
+            if (PW == 1) hipLaunchKernelGGL((msdeep::deep_points<1>), g, dim3(msdeep::NT), 0, ctx->stream, D);
+            else hipLaunchKernelGGL((msdeep::deep_points<3>), g, dim3(msdeep::NT), 0, ctx->stream, D);
+        }
+        HIPCHK(hipGetLastError());
+        MSCHK(ctx_plan(ctx, PW, log_n, true, h, &inv));
+        const void* qsrc[1] = {d_q};
+        void* qdst[1] = {d_q};
+        MSCHK(plan_run(inv, qsrc, qdst, 1, 256));
+        msdeep::Q da = {{0, 0, 0}}, db = {{0, 0, 0}};
+        memcpy(da.w, h_degree_alpha, PW * 8);
+        memcpy(db.w, h_degree_beta, PW * 8);
+        {
+            ProfScope ps(ctx, "deep_degree_adjust", 16.0 * n * PW);
+            if (PW == 1) hipLaunchKernelGGL((msdeep::deep_degree_adjust<1>), g, dim3(msdeep::NT), 0, ctx->stream, (uint64_t*)d_out, (const uint64_t*)d_q, n, da, db);
+            else hipLaunchKernelGGL((msdeep::deep_degree_adjust<3>), g, dim3(msdeep::NT), 0, ctx->stream, (uint64_t*)d_out, (const uint64_t*)d_q, n, da, db);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return MS_OK;
+}

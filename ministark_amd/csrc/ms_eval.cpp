@@ -1,0 +1,317 @@
+// Fused constraint evaluation: program validation, rewriting (eval_opt.h), specialisation (eval_jit.h), launches
+// (src/eval_gpu.rs, parity with src/eval_cpu.rs:33-150).
+#include "ms_internal.h"
+#include "stage_kernels.h"
+#include "eval_kernels.h"
+#include "eval_opt.h"
+#ifndef MS_NO_JIT
+#include "eval_jit.h"
+#endif
+
+// ---------------------------------------------------------------------------------------
+// fused constraint evaluation
+// ---------------------------------------------------------------------------------------
+extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                               unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                               const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                               const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                               int out_field, void* d_out) {
+    return ms_eval_program_ex(ctx, h_prog, ninstr, h_consts, nconst_words, log_n, lde_step, h_domain_offset, d_x_lde, d_base_cols, nbase,
+                              d_ext_cols, next, d_periodic, periodic_len, nperiodic, out_field, d_out, 0u);
+}
+extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                                  unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                                  const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                                  const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                                  int out_field, void* d_out, unsigned flags) {
+    using namespace mseval;
+    if (flags & ~(unsigned)MS_EVAL_BIT_REVERSED) return fail(MS_ERR_INVALID, "ms_eval_program_ex: unknown flags 0x%x", flags);
+    if (!ctx || !h_prog || !d_out || (nconst_words && !h_consts)) return fail(MS_ERR_INVALID, "ms_eval_program: null argument");
+    if (nbase > (unsigned)MAXCOLS || next > (unsigned)MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d base and %d extension columns", MAXCOLS, MAXCOLS);
+    if (nperiodic > 16u) return fail(MS_ERR_UNSUPPORTED, "at most 16 periodic columns");      // the other slots hold hoisted tables
+    if ((nbase && !d_base_cols) || (next && !d_ext_cols) || (nperiodic && (!d_periodic || !periodic_len))) return fail(MS_ERR_INVALID, "ms_eval_program: null column table");
+    if (log_n > 32) return fail(MS_ERR_INVALID, "log_n too large");
+    if (lde_step == 0) return fail(MS_ERR_INVALID, "lde_step must be positive");
+    const bool is252 = out_field == MS_STARK252_FP;          // Fq = Fp = Fp252: P-typed opcodes only, 4-word elements
+    if (out_field != MS_GOLDILOCKS_FP && out_field != MS_GOLDILOCKS_FQ3 && !is252) return fail(MS_ERR_UNSUPPORTED, "unknown output field");
+    const unsigned PW = is252 ? 4 : 1;
+    // ---- validate: every register is written before it is read, all operands are in range
+    unsigned maxp = 0, maxq = 0;
+    std::vector<char> pw(256, 0), qw(128, 0);
+    bool stored = false;
+    const Instr* prog = (const Instr*)h_prog;
+    auto P_ok = [&](uint32_t r) { return r < 256 && pw[r]; };
+    auto Q_ok = [&](uint32_t r) { return r < 128 && qw[r]; };
+    for (unsigned k = 0; k < ninstr; k++) {
+        const Instr I = prog[k];
+        bool ok = true, dp = false, dq = false;
+        switch (I.op) {
+        case OP_X_P: dp = true; break;
+        case OP_CONST_P: ok = (uint64_t)I.a + PW <= nconst_words; dp = true; break;
+        case OP_CONST_Q: ok = (uint64_t)I.a + 3 <= nconst_words; dq = true; break;
+        case OP_TRACE_P: ok = I.a < nbase; dp = true; break;
+        case OP_TRACE_Q: ok = I.a < next; dq = true; break;
+        case OP_PERIODIC_P: ok = I.a < nperiodic && periodic_len[I.a] > 0; dp = true; break;
+        case OP_PERIODIC_Q: ok = I.a < nperiodic && periodic_len[I.a] > 0; dq = true; break;
+        case OP_NEG_P: case OP_INV_P: case OP_POW_P: ok = P_ok(I.a); dp = true; break;
+        case OP_NEG_Q: case OP_INV_Q: case OP_POW_Q: ok = Q_ok(I.a); dq = true; break;
+        case OP_ADD_PP: case OP_MUL_PP: ok = P_ok(I.a) && P_ok(I.b); dp = true; break;
+        case OP_ADD_QQ: case OP_MUL_QQ: ok = Q_ok(I.a) && Q_ok(I.b); dq = true; break;
+        case OP_ADD_QP: case OP_MUL_QP: ok = Q_ok(I.a) && P_ok(I.b); dq = true; break;
+        case OP_EMBED: ok = P_ok(I.a); dq = true; break;
+        case OP_STORE_Q: ok = Q_ok(I.a) && I.b == 0 && out_field == MS_GOLDILOCKS_FQ3; stored = true; break;
+        case OP_STORE_P: ok = P_ok(I.a) && I.b == 0 && (out_field == MS_GOLDILOCKS_FP || is252); stored = true; break;
+        default: ok = false;
+        }
+        if (is252 && (dq || I.op == OP_STORE_Q)) ok = false;
+        if (dp) { if (I.dst >= 256) ok = false; else { pw[I.dst] = 1; maxp = std::max(maxp, I.dst + 1); } }
+        if (dq) { if (I.dst >= 128) ok = false; else { qw[I.dst] = 1; maxq = std::max(maxq, I.dst + 1); } }
+        if (!ok) return fail(MS_ERR_INVALID, "constraint program: invalid instruction %u (op %u dst %u a %u b %u)", k, I.op, I.dst, I.a, I.b);
+    }
+    if (!stored) return fail(MS_ERR_INVALID, "constraint program never stores a result");
+    const size_t n = (size_t)1 << log_n;
+    uint64_t h = 1;
+    if (h_domain_offset && !is252) { uint64_t h_m; memcpy(&h_m, h_domain_offset, 8); h = gl::from_mont(h_m); }
+    f252::E h252 = f252::one();
+    if (h_domain_offset && is252) memcpy(h252.l, h_domain_offset, 32);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    // ---- rewrite: short-period sub-expressions -> tables, long x^e chains -> twiddle lookups (eval_opt.h)
+    static const bool no_opt = getenv("MS_EVAL_NO_HOIST") != nullptr;
+    SplitProgram split;
+    if (!no_opt) {
+        split = split_periodic(prog, ninstr, log_n, d_x_lde == nullptr, periodic_len, nperiodic, (unsigned)MAXPERIODIC - nperiodic, PW);
+        size_t words = 0;
+        for (unsigned w : split.table_words) words += (size_t)w << split.log_period;
+        if (words * 8 > ((size_t)64 << 20))                   // keep the tables cache-sized: fall back to short periods only
+            split = split_periodic(prog, ninstr, log_n, d_x_lde == nullptr, periodic_len, nperiodic, (unsigned)MAXPERIODIC - nperiodic, PW, 12);
+    }
+    std::vector<uint64_t> consts((const uint64_t*)h_consts, (const uint64_t*)h_consts + nconst_words);
+    for (auto& xp : split.xpows) {
+        split.main[xp.instr].a = (uint32_t)consts.size();
+        if (is252) { const f252::E v = f252::pow_u64(h252, xp.e); consts.insert(consts.end(), v.l, v.l + 4); }
+        else consts.push_back(gl::to_mont(gl::pow(h, xp.e)));
+    }
+    if (getenv("MS_EVAL_DEBUG")) {
+        fprintf(stderr, "split active=%d log_period=%u tables=%zu\n", (int)split.active, split.log_period, split.table_words.size());
+        for (unsigned k = 0; k < ninstr; k++) fprintf(stderr, "  orig %3u: op %2u dst %u a %u b %u\n", k, prog[k].op, prog[k].dst, prog[k].a, prog[k].b);
+        for (auto& I : split.prologue) fprintf(stderr, "  pro : op %2u dst %u a %u b %u\n", I.op, I.dst, I.a, I.b);
+        for (auto& I : split.main) fprintf(stderr, "  main: op %2u dst %u a %u b %u\n", I.op, I.dst, I.a, I.b);
+    }
+    const unsigned h252_slot = (unsigned)consts.size();       // the Fp252 domain offset travels as one more constant
+    if (is252) consts.insert(consts.end(), h252.l, h252.l + 4);
+    const Instr* main_prog = split.active ? split.main.data() : prog;
+    unsigned main_n = split.active ? (unsigned)split.main.size() : ninstr;
+    const unsigned pro_n = (unsigned)split.prologue.size();
+    // ---- rewrite 3: divisions by x-only denominators -> full-length tables, inverted in batches (eval_opt.h split_inversions)
+    const unsigned short_tables = (unsigned)split.table_words.size();
+    InvSplit isplit;
+    if (log_n >= 12) isplit = split_inversions(main_prog, main_n, nperiodic + short_tables, (unsigned)MAXPERIODIC - nperiodic - short_tables, PW);
+    if (isplit.active) { main_prog = isplit.main.data(); main_n = (unsigned)isplit.main.size(); }
+    const unsigned den_n = (unsigned)isplit.denom.size();
+    // ---- program(s) + constants -> device
+    const size_t mbytes = (size_t)main_n * sizeof(Instr), pbytes = (size_t)pro_n * sizeof(Instr), dbytes = (size_t)den_n * sizeof(Instr), cbytes = consts.size() * 8;
+    const size_t poff = (mbytes + 15) & ~(size_t)15, doff = (poff + pbytes + 15) & ~(size_t)15, coff = (doff + dbytes + 15) & ~(size_t)15, total = coff + cbytes + 64;
+    HIPCHK(hipStreamSynchronize(ctx->stream));               // a previous evaluation may still read the buffer
+    if (ctx->prog_bytes < total) {
+        if (ctx->prog_buf) HIPCHK(hipFree(ctx->prog_buf));
+        ctx->prog_buf = nullptr; ctx->prog_bytes = 0;
+        if (hipMalloc(&ctx->prog_buf, total) != hipSuccess) return fail(MS_ERR_NOMEM, "program buffer");
+        ctx->prog_bytes = total;
+    }
+    HIPCHK(hipMemcpy(ctx->prog_buf, main_prog, mbytes, hipMemcpyHostToDevice));
+    if (pbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + poff, split.prologue.data(), pbytes, hipMemcpyHostToDevice));
+    if (dbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + doff, isplit.denom.data(), dbytes, hipMemcpyHostToDevice));
+    if (cbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + coff, consts.data(), cbytes, hipMemcpyHostToDevice));
+    EvalParams E;
+    memset(&E, 0, sizeof E);
+    E.consts = (const uint64_t*)((char*)ctx->prog_buf + coff);
+    for (unsigned c = 0; c < nbase; c++) E.base_cols[c] = (const uint64_t*)d_base_cols[c];
+    for (unsigned c = 0; c < next; c++) E.ext_cols[c] = (const uint64_t*)d_ext_cols[c];
+    for (unsigned c = 0; c < nperiodic; c++) { E.periodic[c] = (const uint64_t*)d_periodic[c]; E.periodic_len[c] = periodic_len[c]; }
+    E.out = (uint64_t*)d_out; E.x_lde = (const uint64_t*)d_x_lde;
+    E.h_mont = is252 ? h252_slot : gl::to_mont(h); E.lde_step = lde_step;
+    unsigned table_log = log_n;                               // domain the w table was built for
+    if (!d_x_lde) {
+        ms_ntt_plan* plan = nullptr;
+        if (is252) {
+            MSCHK(plan252_cached(ctx, log_n, false, f252::one(), &plan));
+            E.tw_lo = plan->d252_tw_lo; E.tw_hi = plan->d252_tw_hi; E.lo_bits = plan->lo_bits;
+        } else {
+            table_log = std::max(log_n, 12u);
+            MSCHK(ctx_plan(ctx, 1, table_log, false, 1, &plan));
+            E.tw_lo = plan->d_tw_lo; E.tw_hi = plan->d_tw_hi; E.lo_bits = plan->lo_bits;
+        }
+    }
+    // specialised kernel for a program (compiled on first use), or nullptr -> interpreter
+    auto specialised = [&](const Instr* pr, unsigned cnt) -> hipFunction_t {
+#ifndef MS_NO_JIT
+        static const bool off = getenv("MS_EVAL_JIT") && !strcmp(getenv("MS_EVAL_JIT"), "0");
+        if (off) return nullptr;
+        const std::string src = jit_source(pr, cnt, is252, maxp, maxq);
+        const std::string& key = src;
+        auto it = ctx->jit_cache.find(key);
+        if (it != ctx->jit_cache.end()) return it->second;
+        hipFunction_t fn = nullptr;
+        std::vector<char> code;
+        std::string log;
+        if (jit_compile(src, code, log)) {
+            hipModule_t mod = nullptr;
+            if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, "ms_eval_jit") == hipSuccess) ctx->jit_modules.push_back(mod);
+            else { fn = nullptr; (void)hipGetLastError(); }
+        } else if (getenv("MS_EVAL_DEBUG")) fprintf(stderr, "[ministark_hip] constraint kernel compilation failed, using the interpreter:\n%s\n", log.c_str());
+        ctx->jit_cache[key] = fn;
+        return fn;
+#else
+        (void)pr; (void)cnt;
+        return nullptr;
+#endif
+    };
+    auto launch = [&](const EvalParams& Q, hipFunction_t fn) {
+        dim3 g((unsigned)((Q.n + NT - 1) / NT));
+        if (fn) {
+            EvalParams A = Q;
+            void* args[] = {&A};
+            if (hipModuleLaunchKernel(fn, g.x, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr) == hipSuccess) return;
+            // a module-API launch error does not reliably surface in hipGetLastError(): do not leave d_out unwritten,
+            // run the interpreter instead and stop offering this kernel
+            (void)hipGetLastError();
+            for (auto& kv : ctx->jit_cache) if (kv.second == fn) kv.second = nullptr;
+        }
+        if (is252) {
+            if (maxp <= 16) hipLaunchKernelGGL((eval_program252<16>), g, dim3(NT), 0, ctx->stream, Q);
+            else if (maxp <= 64) hipLaunchKernelGGL((eval_program252<64>), g, dim3(NT), 0, ctx->stream, Q);
+            else hipLaunchKernelGGL((eval_program252<256>), g, dim3(NT), 0, ctx->stream, Q);
+        } else {
+            if (maxp <= 16 && maxq <= 8) hipLaunchKernelGGL((eval_program<16, 8>), g, dim3(NT), 0, ctx->stream, Q);
+            else if (maxp <= 64 && maxq <= 32) hipLaunchKernelGGL((eval_program<64, 32>), g, dim3(NT), 0, ctx->stream, Q);
+            else hipLaunchKernelGGL((eval_program<256, 128>), g, dim3(NT), 0, ctx->stream, Q);
+        }
+    };
+    // ---- prologue: the short-period values on the first 2^log_period points -> tables
+    void* tables = nullptr;
+    LockedPoolGuard pooled(ctx);                              // stream-ordered: the next user of a block queues behind these kernels
+    if (pro_n) {
+        const size_t period = (size_t)1 << split.log_period;
+        size_t words = 0;
+        for (unsigned w : split.table_words) words += w * period;
+        MSCHK(pooled.alloc(words * 8, &tables));
+        uint64_t* tp = (uint64_t*)tables;
+        for (size_t t = 0; t < split.table_words.size(); t++) {
+            E.periodic[nperiodic + t] = tp; E.periodic_len[nperiodic + t] = (uint32_t)period;
+            tp += split.table_words[t] * period;
+        }
+        // Fp252 with a handful of points: one lane running the 252-bit Fermat inverse is ~0.6 ms of pure latency on
+        // the device and microseconds on a host core -- the same fp252.h functions, so the same values
+        bool on_host = false;
+        if (is252 && period <= 64 && !d_x_lde) {
+            on_host = true;
+            for (auto& I : split.prologue) if (I.op == OP_PERIODIC_P) on_host = false;       // caller tables live on the device
+        }
+        if (on_host) {
+            std::vector<uint64_t> host_tabs(words, 0);
+            const f252::E w = f252::root_of_unity(log_n);
+            f252::E xi = h252;                                                                // x_i = h * w^i
+            std::vector<f252::E> rp(256);
+            for (size_t i = 0; i < period; i++) {
+                for (auto& I : split.prologue) {
+                    switch (I.op) {
+                    case OP_X_P: rp[I.dst] = xi; break;
+                    case OP_CONST_P: memcpy(rp[I.dst].l, &consts[I.a], 32); break;
+                    case OP_NEG_P: rp[I.dst] = f252::neg(rp[I.a]); break;
+                    case OP_ADD_PP: rp[I.dst] = f252::add(rp[I.a], rp[I.b]); break;
+                    case OP_MUL_PP: rp[I.dst] = f252::mul(rp[I.a], rp[I.b]); break;
+                    case OP_INV_P: rp[I.dst] = f252::inv(rp[I.a]); break;
+                    case OP_POW_P: rp[I.dst] = f252::pow_u64(rp[I.a], I.b); break;
+                    case OP_STORE_P: {
+                        size_t off = 0;
+                        for (unsigned t = 0; t + nperiodic + 1 < I.b; t++) off += split.table_words[t] * period;
+                        memcpy(&host_tabs[off + 4 * i], rp[I.a].l, 32);
+                    } break;
+                    default: break;
+                    }
+                }
+                xi = f252::mul(xi, w);
+            }
+            HIPCHK(hipMemcpyAsync(tables, host_tabs.data(), words * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));           // host_tabs is pageable and about to go out of scope
+        } else {
+            EvalParams Q = E;
+            Q.prog = (const Instr*)((char*)ctx->prog_buf + poff); Q.ninstr = pro_n;
+            Q.n = period; Q.log_n = split.log_period; Q.xshift = table_log - log_n;      // the first points of the same domain
+        Q.bitrev = 0;
+            ProfScope ps(ctx, "eval_prologue", 0.0);
+            launch(Q, nullptr);                                   // runs on a few points: not worth a compilation
+        }
+    }
+    E.prog = (const Instr*)ctx->prog_buf; E.ninstr = main_n; E.n = n; E.log_n = log_n; E.xshift = table_log - log_n;
+    E.bitrev = (flags & MS_EVAL_BIT_REVERSED) ? 1 : 0;
+    // ---- the x-only denominators of every point (in the launch's own layout), inverted in place
+    void* inv_tables = nullptr;
+    if (den_n) {
+        size_t words = 0;
+        for (unsigned w : isplit.table_words) words += (size_t)w * n;
+        MSCHK(pooled.alloc(words * 8, &inv_tables));
+        uint64_t* tp = (uint64_t*)inv_tables;
+        for (size_t t = 0; t < isplit.table_words.size(); t++) {
+            E.periodic[nperiodic + short_tables + t] = tp; E.periodic_len[nperiodic + short_tables + t] = (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu);
+            tp += (size_t)isplit.table_words[t] * n;
+        }
+        EvalParams Q = E;
+        Q.prog = (const Instr*)((char*)ctx->prog_buf + doff); Q.ninstr = den_n;
+        {
+            hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(isplit.denom.data(), den_n) : nullptr;
+            ProfScope ps(ctx, "eval_denominators", 0.0);
+            launch(Q, fn);
+        }
+        tp = (uint64_t*)inv_tables;
+        for (size_t t = 0; t < isplit.table_words.size(); t++) {
+            const unsigned w = isplit.table_words[t];
+            ProfScope ps(ctx, "eval_batch_inverse", 16.0 * w * n);
+            if (w == 1) hipLaunchKernelGGL((batch_inverse<msstage::FpT, 16>), dim3((unsigned)((n + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, tp, n);
+            else if (w == 3) hipLaunchKernelGGL((batch_inverse<msstage::Fq3T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
+            else if (n < ((size_t)1 << 16)) hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
+            else {                                             // two levels: one 252-bit Fermat inverse per 64 elements
+                const unsigned blocks = (unsigned)(n / (NT * 8));
+                const size_t m = (size_t)blocks * NT;          // lanes of the sweep = entries of the product array
+                void* prod = nullptr;
+                MSCHK(pooled.alloc(m * 32, &prod));
+                hipLaunchKernelGGL((batch_inverse_up<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, n, (uint64_t*)prod);
+                hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((m + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
+                hipLaunchKernelGGL((batch_inverse_down<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, n, (const uint64_t*)prod);
+            }
+            tp += (size_t)w * n;
+        }
+    }
+    {
+        hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(main_prog, main_n) : nullptr;   // small domains: the interpreter is quicker than a compilation
+        ProfScope ps(ctx, fn ? (is252 ? "eval_program252_jit" : "eval_program_jit") : (is252 ? "eval_program252" : "eval_program"),
+                     is252 ? 32.0 * n * (nbase + 1) : 8.0 * n * (nbase + 3.0 * next + (out_field == MS_GOLDILOCKS_FQ3 ? 3 : 1)));
+        launch(E, fn);
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
+
+extern "C" int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int out_field, size_t* code_bytes) {
+#ifndef MS_NO_JIT
+    using namespace mseval;
+    if (!h_prog || !code_bytes) return fail(MS_ERR_INVALID, "ms_eval_jit_check: null argument");
+    const bool is252 = out_field == MS_STARK252_FP;
+    const Instr* prog = (const Instr*)h_prog;
+    unsigned maxp = 0, maxq = 0;
+    for (unsigned k = 0; k < ninstr; k++) {
+        if (prog[k].op >= OP_COUNT || prog[k].dst >= 256) return fail(MS_ERR_INVALID, "invalid instruction %u", k);
+        if (op_is_store(prog[k].op)) continue;
+        if (op_is_q_dst(prog[k].op)) maxq = std::max(maxq, prog[k].dst + 1); else maxp = std::max(maxp, prog[k].dst + 1);
+    }
+    std::vector<char> code;
+    std::string log;
+    if (!jit_compile(jit_source(prog, ninstr, is252, maxp, maxq), code, log)) return fail(MS_ERR_UNSUPPORTED, "hiprtc: %s", log.c_str());
+    *code_bytes = code.size();
+    return MS_OK;
+#else
+    (void)h_prog; (void)ninstr; (void)out_field; (void)code_bytes;
+    return fail(MS_ERR_UNSUPPORTED, "built without hiprtc");
+#endif
+}

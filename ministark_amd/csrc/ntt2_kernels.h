@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
 // store one whole 128-byte line.  The buffer is shared with the exchange, so here the second half of the first networks'
 // results waits in registers until round 0 has stored (a few spilled registers, as before round 2b).
 static constexpr int BR_PITCH = 129;
-__global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) {
+static __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) {
     __shared__ uint64_t xch[64 * BR_PITCH];                  // >= 16 * 8 * TW words of the exchange
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
     uint64_t* __restrict__ dst = P.dst[blockIdx.y];

@@ -309,7 +309,7 @@ struct SmallParams {
     unsigned log_n;
     unsigned V;
 };
-__global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
+static __global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
     __shared__ uint64_t lds[2048];
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
     uint64_t* __restrict__ dst = P.dst[blockIdx.y];

@@ -122,7 +122,7 @@ struct RowsParams {
     unsigned ncols;
     unsigned row_stride;     // words between rows of one column: 1 (column-major) or ncols (row-major matrix)
 };
-__global__ void __launch_bounds__(NT) rpo256_rows(RowsParams P) {
+static __global__ void __launch_bounds__(NT) rpo256_rows(RowsParams P) {
     const size_t r = (size_t)blockIdx.x * NT + threadIdx.x;
     if (r >= P.nrows) return;
     State st;
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(NT) rpo256_rows(RowsParams P) {
     o[0] = st.s[4]; o[1] = st.s[5]; o[2] = st.s[6]; o[3] = st.s[7];
 }
 // dst[i] = merge(src[2i], src[2i+1]) for i < count; digests are 4 elements
-__global__ void __launch_bounds__(NT) rpo256_merge_level(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t count) {
+static __global__ void __launch_bounds__(NT) rpo256_merge_level(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t count) {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= count) return;
     State st;

@@ -153,7 +153,7 @@ struct GatherRowsParams {
     size_t npos;
     unsigned ncols, V;
 };
-__global__ void __launch_bounds__(NT) gather_rows(GatherRowsParams P) {
+static __global__ void __launch_bounds__(NT) gather_rows(GatherRowsParams P) {
     const size_t words_per_row = (size_t)P.ncols * P.V;
     const size_t total = P.npos * words_per_row;
     for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(NT) gather_rows(GatherRowsParams P) {
     }
 }
 // out[k] = src[idx[k]] for records of `words` u64 words (Merkle digests: 4 words)
-__global__ void __launch_bounds__(NT) gather_records(const uint64_t* __restrict__ src, const uint64_t* __restrict__ idx, uint64_t* __restrict__ out, size_t count, unsigned words) {
+static __global__ void __launch_bounds__(NT) gather_records(const uint64_t* __restrict__ src, const uint64_t* __restrict__ idx, uint64_t* __restrict__ out, size_t count, unsigned words) {
     const size_t total = count * words;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT)
         out[i] = src[(size_t)idx[i / words] * words + i % words];
@@ -177,7 +177,7 @@ struct DeinterleaveParams {
     size_t n_out;
     unsigned k, V;
 };
-__global__ void __launch_bounds__(NT) deinterleave(DeinterleaveParams P) {
+static __global__ void __launch_bounds__(NT) deinterleave(DeinterleaveParams P) {
     const size_t total = P.n_out * P.k * P.V;
     for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
         const size_t e = idx / P.V;                    // input element

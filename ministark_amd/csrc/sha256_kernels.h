@@ -146,7 +146,7 @@ static inline void sha256_fold_pad_block(uint64_t bits, uint32_t kw[64]) {
 // bswap32(lo32(x)), bswap32(hi32(x)) (little-endian bytes); slot nslots holds the 0x80 pad, the last
 // slot of the last block the bit length.  Blocks of 8 slots are filled with compile-time register
 // indices (no dynamic indexing of the schedule).
-__global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
+static __global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
     const size_t r = (size_t)blockIdx.x * NT + threadIdx.x;
     if (r >= P.nrows) return;
     Sha s;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(NT) sha256_rows(RowsParams P) {
 }
 
 // nodes[out0 + i] = SHA-256(src[2i] || src[2i+1]) for i < count; digests are 32 raw bytes
-__global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t count) {
+static __global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t count) {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= count) return;
     Sha s;
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* __restri
 // The top of the tree in ONE launch: levels of <= 256 parents are latency-bound as separate launches
 // (nine launches for the last 511 nodes).  One workgroup keeps the current level in LDS, every
 // level is also written to its slot of nodes[].  `src` holds 2*count digests, count <= 256.
-__global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __restrict__ src, uint8_t* __restrict__ nodes, unsigned count) {
+static __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __restrict__ src, uint8_t* __restrict__ nodes, unsigned count) {
     __shared__ uint32_t lvl[2][NT * 8];
     const unsigned t = threadIdx.x;
     Sha s;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __restric
 // One nonce per lane over a window [base, base + count); the minimum hit is kept with atomicMin.
 // The 40-byte message is one block: seed words are loaded once (wave-uniform).
 struct PowParams { uint32_t seed[8]; unsigned long long base; unsigned long long count; unsigned bits; unsigned long long* found; };
-__global__ void __launch_bounds__(NT) sha256_pow_grind(PowParams P) {
+static __global__ void __launch_bounds__(NT) sha256_pow_grind(PowParams P) {
     const unsigned long long i = (unsigned long long)blockIdx.x * NT + threadIdx.x;
     if (i >= P.count) return;
     const unsigned long long nonce = P.base + i;

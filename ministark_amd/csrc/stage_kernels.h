@@ -140,18 +140,18 @@ __global__ void __launch_bounds__(NT) k_unary(uint64_t* dst, const uint64_t* src
         F::store(dst, i, OP == 0 ? F::neg(a) : OP == 1 ? F::inv(a) : powu<F>(a, e));
     }
 }
-__global__ void __launch_bounds__(NT) k_convert_fp_fq3(uint64_t* dst, const uint64_t* src, size_t n) {
+static __global__ void __launch_bounds__(NT) k_convert_fp_fq3(uint64_t* dst, const uint64_t* src, size_t n) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
         const uint64_t x = src[i];
         dst[3 * i] = x; dst[3 * i + 1] = 0; dst[3 * i + 2] = 0;
     }
 }
 // word-granular fill: element pattern c.w[0..V)
-__global__ void __launch_bounds__(NT) k_fill(uint64_t* dst, Const3 c, size_t nwords, unsigned V) {
+static __global__ void __launch_bounds__(NT) k_fill(uint64_t* dst, Const3 c, size_t nwords, unsigned V) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nwords; i += (size_t)gridDim.x * NT) dst[i] = c.w[i % V];
 }
 struct SumParams { const uint64_t* cols[MAXCOLS]; uint64_t* dst; size_t nwords; unsigned ncols; };
-__global__ void __launch_bounds__(NT) k_sum_columns(SumParams P) {
+static __global__ void __launch_bounds__(NT) k_sum_columns(SumParams P) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < P.nwords; i += (size_t)gridDim.x * NT) {
         uint64_t acc = P.cols[0][i];                         // canonical
         for (unsigned c = 1; c < P.ncols; c++) acc = gl::add(acc, P.cols[c][i]);
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(NT) k_sum_columns(SumParams P) {
     }
 }
 
-__global__ void __launch_bounds__(NT) k_sum_columns252(SumParams P) {      // nwords = number of elements here
+static __global__ void __launch_bounds__(NT) k_sum_columns252(SumParams P) {      // nwords = number of elements here
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < P.nwords; i += (size_t)gridDim.x * NT) {
         f252::E acc = Fp252T::load(P.cols[0], i);
         for (unsigned c = 1; c < P.ncols; c++) acc = f252::add(acc, Fp252T::load(P.cols[c], i));

@@ -12,7 +12,10 @@ SO = os.path.join(HERE, "_build", "libministark_emu.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, "ministark_hip.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
+    import sys
+    sys.path.insert(0, ROOT)
+    from ministark_amd.build import SOURCES                    # the same translation units as the product library
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "emu_runtime.cpp")]
     deps = list(srcs) + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "ministark_hip.h")]
     for d, _, files in os.walk(CSRC):
         deps += [os.path.join(d, f) for f in files]
