@@ -9,6 +9,7 @@ ministark_amd/csrc/host/ministark.hpp stand where the `cfg(feature = "hip")`
 shim of INTEGRATION.md would.)
 """
 import ctypes
+import weakref
 from collections import deque
 
 import numpy as np
@@ -59,6 +60,7 @@ class Planner:
         self.lib.check(self.lib.ms_ctx_create(device, ctypes.byref(h)))
         self.handle = h
         self.device = device
+        self._plans = weakref.WeakSet()                  # GpuFft / GpuIfft objects created on this context
 
     def sync(self):
         self.lib.check(self.lib.ms_sync(self.handle))
@@ -84,7 +86,9 @@ class Planner:
 
     def close(self):
         if self.handle:
-            self.lib.ms_ctx_destroy(self.handle)
+            for plan in list(self._plans):               # plans refer to the context: release them first
+                plan.close()
+            self.lib.ms_ctx_destroy(self.handle)         # (the library also releases any plan it still knows of)
             self.handle = None
 
     def __del__(self):
@@ -353,6 +357,7 @@ class _FftBase:
                                      off.ctypes.data, gen.ctypes.data, ctypes.byref(h)))
         self.handle = h
         self._keep = []
+        self.planner._plans.add(self)
 
     @classmethod
     def from_domain(cls, domain, field=GOLDILOCKS_FP, planner=None):

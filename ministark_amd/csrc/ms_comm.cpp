@@ -30,7 +30,19 @@ extern "C" int ms_cols_to_rows_schedule(unsigned nranks, unsigned rank, unsigned
 
 #ifndef MS_EMU
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A build host without the RCCL development headers (a single-GPU box) still builds the library: the few types and
+// constants of the NCCL API that the lazily loaded entry points need, as RCCL 2.x defines them.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+}
+#endif
 namespace {
 struct RcclApi {
     void* lib = nullptr;

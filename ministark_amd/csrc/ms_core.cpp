@@ -64,13 +64,14 @@ extern "C" int ms_ctx_create(int device, ms_ctx** out) {
     *out = ctx;
     return MS_OK;
 }
-extern "C" int ms_ntt_plan_destroy(ms_ntt_plan* plan);
 extern "C" int ms_comm_destroy(ms_ctx* ctx);
 extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     if (!ctx) return MS_OK;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     (void)ms_comm_destroy(ctx);
-    for (auto& kv : ctx->plan_cache) ms_ntt_plan_destroy(kv.second);
+    plans_release_ctx(ctx);                                    // handles the caller still holds (they refer to this context)
+    for (auto& kv : ctx->plan_cache) plan_free_cached(kv.second);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);

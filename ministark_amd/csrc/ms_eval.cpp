@@ -77,9 +77,8 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     // ---- rewrite: short-period sub-expressions -> tables, long x^e chains -> twiddle lookups (eval_opt.h)
-    static const bool no_opt = getenv("MS_EVAL_NO_HOIST") != nullptr;
     SplitProgram split;
-    if (!no_opt) {
+    {
         split = split_periodic(prog, ninstr, log_n, d_x_lde == nullptr, periodic_len, nperiodic, (unsigned)MAXPERIODIC - nperiodic, PW);
         size_t words = 0;
         for (unsigned w : split.table_words) words += (size_t)w << split.log_period;

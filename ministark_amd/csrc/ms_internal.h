@@ -166,3 +166,5 @@ int plan252_cached(ms_ctx* ctx, unsigned log_n, bool inverse, const f252::E& h, 
 int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows, bool bitrev_out = false);
 int bit_reverse_run(ms_ctx* ctx, unsigned V, unsigned log_n, const void* const* src, void* const* dst, unsigned ncols);
 unsigned stream_grid(size_t n);
+void plans_release_ctx(ms_ctx* ctx);                 // ms_ctx_destroy: plans still held by the caller go with their context
+int plan_free_cached(ms_ntt_plan* plan);             // the context's own (cached) plans

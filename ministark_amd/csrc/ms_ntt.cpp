@@ -21,9 +21,35 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uin
 int ctx_plan(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse, uint64_t h, ms_ntt_plan** out);
 static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* h_offset, const void* h_group_gen, ms_ntt_plan** out);
 
+// Plan objects handed to the caller (ms_ntt_plan_create): a plan refers to its context (lock, stream, cached tables), so a
+// context that is destroyed first releases them itself and takes them out of this registry; every entry point that receives
+// a plan looks it up before touching it -- a plan destroyed after its context (a GpuFft collected after Planner.close()) is a
+// no-op, a transform on it an error, never a read of freed memory.
+#include <set>
+static std::mutex g_user_plans_mu;
+static std::set<ms_ntt_plan*> g_user_plans;
+static bool user_plan_alive(ms_ntt_plan* p) { std::lock_guard<std::mutex> lk(g_user_plans_mu); return g_user_plans.count(p) != 0; }
+static int plan_free(ms_ntt_plan* plan);
+
+static int plan_create_impl(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset, const void* h_group_gen, ms_ntt_plan** out);
 extern "C" int ms_ntt_plan_create(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset,
                                   const void* h_group_gen, ms_ntt_plan** out) {
     if (!ctx || !out) return fail(MS_ERR_INVALID, "ms_ntt_plan_create: null argument");
+    MSCHK(plan_create_impl(ctx, field, log_n, inverse, h_offset, h_group_gen, out));
+    std::lock_guard<std::mutex> lk(g_user_plans_mu);
+    g_user_plans.insert(*out);
+    return MS_OK;
+}
+void plans_release_ctx(ms_ctx* ctx) {
+    std::vector<ms_ntt_plan*> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_user_plans_mu);
+        for (auto it = g_user_plans.begin(); it != g_user_plans.end();)
+            if ((*it)->ctx == ctx) { mine.push_back(*it); it = g_user_plans.erase(it); } else ++it;
+    }
+    for (ms_ntt_plan* p : mine) (void)plan_free(p);
+}
+static int plan_create_impl(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset, const void* h_group_gen, ms_ntt_plan** out) {
     unsigned V = 0;
     MSCHK(field_words(field, &V));
     if (V == 4) return plan_build252(ctx, log_n, inverse != 0, h_offset, h_group_gen, out);
@@ -134,7 +160,7 @@ static void plan_cache_insert(ms_ctx* ctx, const PlanKey& key, ms_ntt_plan* plan
         if (victim + 1 >= ctx->plan_cache.size()) break;       // everything older than the new plan is in use: let the cache grow
         ms_ntt_plan* old = ctx->plan_cache[victim].second;
         ctx->plan_cache.erase(ctx->plan_cache.begin() + (long)victim);
-        (void)ms_ntt_plan_destroy(old);                        // synchronises the stream before freeing the tables
+        (void)plan_free(old);                                  // synchronises the stream before freeing the tables
     }
 }
 int plan252_cached(ms_ctx* ctx, unsigned log_n, bool inverse, const f252::E& h, ms_ntt_plan** out);   // Fp252: keyed by the offset itself
@@ -317,12 +343,23 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
 
 extern "C" int ms_ntt_plan_destroy(ms_ntt_plan* plan) {
     if (!plan) return MS_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_user_plans_mu);
+        if (!g_user_plans.erase(plan)) return MS_OK;               // released together with its context
+    }
+    return plan_free(plan);
+}
+int plan_free_cached(ms_ntt_plan* plan) { return plan_free(plan); }
+// cached plans (owned by the context) and plans leaving the registry
+static int plan_free(ms_ntt_plan* plan) {
+    if (!plan) return MS_OK;
     if (plan->base) {                                              // a handle: the cached plan keeps the tables
         { std::lock_guard<std::mutex> lk(plan->ctx->mu); plan->base->refs--; }
         delete plan;
         return MS_OK;
     }
     (void)hipStreamSynchronize(plan->ctx->stream);
+    if (plan->ctx->stream2) (void)hipStreamSynchronize(plan->ctx->stream2);
     if (plan->d_tables) (void)hipFree(plan->d_tables);
     for (auto& l : plan->lde2) if (l.d) (void)hipFree(l.d);
     delete plan;
@@ -416,8 +453,7 @@ static int plan_run252_tiled(ms_ntt_plan* p, const void* const* src, void* const
 }
 
 static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols) {
-    static const bool radix2_only = getenv("MS_NTT252_RADIX2") != nullptr && atoi(getenv("MS_NTT252_RADIX2")) != 0;   // A/B measurements
-    if (p->np252 && !radix2_only) return plan_run252_tiled(p, src, dst, ncols, 0, false);
+    if (p->np252) return plan_run252_tiled(p, src, dst, ncols, 0, false);
     ms_ctx* ctx = p->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -629,8 +665,7 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
 // ---- two-pass coset LDE (lde2_kernels.h) ------------------------------------------------------------------------------
 // fwd = the forward plan of the LDE domain (N = n << log_b points, offset h).  Applies to Fp columns of 2^17..2^20 rows.
 static bool lde2_applicable(const ms_ntt_plan* fwd, unsigned V, unsigned log_n, unsigned log_b) {
-    static const bool off = getenv("MS_LDE2") != nullptr && atoi(getenv("MS_LDE2")) == 0;       // A/B measurements
-    return !off && V == 1 && log_n >= 17 && log_n <= 20 && log_b >= 1 && log_b <= 6 && !fwd->small && fwd->d_wr4[0] != nullptr;
+    return V == 1 && log_n >= 17 && log_n <= 20 && log_b >= 1 && log_b <= 6 && !fwd->small && fwd->d_wr4[0] != nullptr;
 }
 static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_plan::Lde2** out) {
     for (auto& l : fwd->lde2) if (l.log_b == log_b) { *out = &l; return MS_OK; }
@@ -706,8 +741,7 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
         mslde2::Params P;
         memset(&P, 0, sizeof P);
         P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2; P.tin4 = tb->tin4; P.tout4 = tb->tout4;
-        static const bool no_uni = getenv("MS_LDE2_PERLANE") != nullptr && atoi(getenv("MS_LDE2_PERLANE")) != 0;    // A/B measurements
-        const bool uni = tb->tin4 != nullptr && !no_uni;
+        const bool uni = tb->tin4 != nullptr;
         P.tw_lo = fwd->d_tw_lo; P.tw_hi = fwd->d_tw_hi; P.lo_bits = fwd->lo_bits; P.log_n = log_n; P.log_b = log_b;
         for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)src[c0 + c]; P.dst[c] = (uint64_t*)((char*)scratch + (size_t)c * col_bytes); }
         {
@@ -734,18 +768,21 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
 
 extern "C" int ms_ntt_encode(ms_ntt_plan* plan, void* d_column) {
     if (!plan || !d_column) return fail(MS_ERR_INVALID, "ms_ntt_encode: null argument");
+    if (!user_plan_alive(plan)) return fail(MS_ERR_INVALID, "ms_ntt_encode: the plan's context has been destroyed");
     std::lock_guard<std::mutex> lk(plan->ctx->mu);
     plan->queue.push_back(d_column);
     return MS_OK;
 }
 extern "C" int ms_ntt_enqueue(ms_ntt_plan* plan, void* const* d_columns, unsigned ncols) {
     if (!plan || (!d_columns && ncols)) return fail(MS_ERR_INVALID, "ms_ntt_enqueue: null argument");
+    if (!user_plan_alive(plan)) return fail(MS_ERR_INVALID, "ms_ntt_enqueue: the plan's context has been destroyed");
     if (ncols == 0) return MS_OK;
     std::lock_guard<std::mutex> lk(plan->ctx->mu);
     return plan_run(plan, (const void* const*)d_columns, d_columns, ncols, 256);
 }
 extern "C" int ms_ntt_execute(ms_ntt_plan* plan) {
     if (!plan) return fail(MS_ERR_INVALID, "ms_ntt_execute: null plan");
+    if (!user_plan_alive(plan)) return fail(MS_ERR_INVALID, "ms_ntt_execute: the plan's context has been destroyed");
     std::vector<void*> q;
     { std::lock_guard<std::mutex> lk(plan->ctx->mu); q.swap(plan->queue); }
     if (!q.empty()) MSCHK(ms_ntt_enqueue(plan, q.data(), (unsigned)q.size()));
@@ -827,7 +864,7 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         MSCHK(plan_run252(inv, d_in, d_out, ncols));
         // tiled passes: the coefficients are read straight from the head of the output column (zeros implicit), the
         // bit reversal is part of the last pass
-        if (fwd->np252 && log_blowup <= fwd->lr252[0] && !getenv("MS_NTT252_RADIX2"))
+        if (fwd->np252 && log_blowup <= fwd->lr252[0])
             return plan_run252_tiled(fwd, (const void* const*)d_out, d_out, ncols, log_blowup, bit_reversed != 0);
         const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
         if (N > n)
@@ -903,7 +940,7 @@ extern "C" int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_
         if (!bit_reversed) MSCHK(bit_reverse_run(ctx, V, log_domain, (const void* const*)d_out, d_out, ncols));
         return MS_OK;
     }
-    if (V == 4 && fwd->np252 && log_blowup <= fwd->lr252[0] && !getenv("MS_NTT252_RADIX2"))
+    if (V == 4 && fwd->np252 && log_blowup <= fwd->lr252[0])
         return plan_run252_tiled(fwd, d_in, d_out, ncols, log_blowup, bit_reversed != 0);
     if (V != 4 && !fwd->small && log_blowup >= 2 && log_blowup <= 4) {
         // pass 1 reads only the rows that hold coefficients (straight from d_in), zero padding is implicit,

@@ -5,13 +5,20 @@ examples/fib/main.rs:225).
 
 The Fiat-Shamir channel (src/channel.rs: SHA-256 over a few digests, host work in the reference too) is
 replaced by draws the caller fixes in advance, so that the CPU oracle can follow the same transcript and every
-intermediate commitment can be compared (tests/test_pipeline_parity.py); nothing else is left out:
+intermediate commitment can be compared (tests/test_pipeline_parity.py):
     interpolate + LDE + commit            prover.rs:50-55
     constraint evaluation                 prover.rs:88-107   (on the committed bit-reversed layout)
-    composition trace                     prover.rs:111-124  (iNTT, split into blowup columns, LDE, commit)
+    composition trace                     prover.rs:111-124  (iNTT, split into ce_blowup columns, LDE, commit)
     DEEP composition + its LDE            prover.rs:137-152  (composer.rs:43-188)
     FRI layers: commit + fold             fri.rs:179-231
-    proof of work, query openings         prover.rs:160-173
+    FRI remainder                         fri.rs:232-248     (bit_reverse, iNTT on the subgroup; the first n / blowup coefficients)
+    proof of work                         prover.rs:160, channel.rs:76-93
+    trace / composition query openings    prover.rs:163-173  (trace.rs:113-157)
+    FRI layer openings                    prover.rs:161, fri.rs:148-165, 615-622 (fold_positions, rows + Merkle views per layer)
+What differs from a real run, on purpose: (i) the draws are fixed, so the proof-of-work seed is the last FRI root instead
+of the channel's running digest (the same SHA-256 search either way); (ii) traces are random columns, not valid executions
+(the data-parallel work does not depend on validity), so fri.rs:244's assertion that the remainder's high coefficients
+vanish is not made.  Proof serialisation and the channel's hashing of a few digests stay on the host in the reference too.
 """
 import time
 
@@ -151,6 +158,32 @@ class Draws:
         self.positions = [int(p) for p in rng.integers(0, n_lde, size=nqueries)]
 
 
+def fold_positions(positions, folding_factor):
+    """`fold_positions` (src/fri.rs:615-622): strictly increasing positions -> their cosets, deduplicated."""
+    assert all(a < b for a, b in zip(positions, positions[1:]))
+    out = []
+    for p in positions:
+        if not out or out[-1] != p // folding_factor:
+            out.append(p // folding_factor)
+    return out
+
+
+def fri_layer_rows(layer, folding_factor, positions):
+    """Rows `positions` of `Matrix::from_arrays(evaluations.as_chunks::<N>())` (src/fri.rs:213-215): N consecutive
+    evaluations each, gathered on the device (32-byte records of ms_gather_digests) -> numpy [len(positions), N * words]."""
+    import ctypes
+    from .api import FIELD_WORDS, DeviceBytes
+    pl = layer.planner
+    words = folding_factor * FIELD_WORDS[layer.field]
+    if words % 4:
+        return layer.to_numpy().reshape(-1, words)[positions]              # rows shorter than a 32-byte record: tiny layers only
+    per = words // 4
+    ids = np.array([p * per + k for p in positions for k in range(per)], dtype=np.uint64)
+    out = DeviceBytes(pl, 32 * len(ids))
+    pl.lib.check(pl.lib.ms_gather_digests(pl.handle, len(layer) * FIELD_WORDS[layer.field] // 4, layer.ptr, ids.ctypes.data, len(ids), out.ptr))
+    return out.to_numpy().view(np.uint64).reshape(len(positions), words)
+
+
 def fri_num_layers(n_lde, blowup, folding, max_remainder_coeffs):
     """FriOptions::num_layers (src/fri.rs:49-56)."""
     layers, n = 0, n_lde
@@ -207,17 +240,28 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
     deep_poly = composer.into_deep_poly(draws.deep)                            # prover.rs:149
     deep = Matrix([deep_poly.clone() if keep else deep_poly]).into_bit_reversed_evaluations(lde_dom)   # prover.rs:150-152
     lap("DEEP: OOD evaluations + composition + LDE")
-    cur, n, roots, layers = deep.columns[0], n_lde, [], []                     # fri.rs:179-231
+    cur, n, roots, layers, fri_layers, fri_trees = deep.columns[0], n_lde, [], [], [], []     # fri.rs:179-231
     for alpha in draws.fri_alphas:
-        roots.append(MerkleTree.from_fri_layer(cur, folding, hash).root())
+        tree = MerkleTree.from_fri_layer(cur, folding, hash)
+        roots.append(tree.root())
+        fri_layers.append(cur); fri_trees.append(tree)                        # FriLayer { merkle_tree, evaluations } (fri.rs:218-221)
         if keep:
             layers.append(cur)
         cur = apply_drp(cur, np.array([gl_to_mont(alpha)], dtype=np.uint64), folding, 1)
         n //= folding
     out["fri_roots"], out["remainder"] = roots, cur
-    lap("FRI layers (commit + fold)")
+    # FriProver::set_remainder (fri.rs:232-248): bit_reverse, iNTT over the subgroup of the remainder's size, keep n / blowup coefficients
+    rem = Matrix([cur.clone()]).bit_reverse_rows().into_polynomials(Radix2EvaluationDomain(n)).columns[0]
+    out["remainder_coeffs"] = rem.to_numpy()[: max(n // blowup, 1)]
+    lap("FRI layers (commit + fold) + remainder")
     out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)   # prover.rs:160
     out["queries"] = Queries(lde_t, None, comp_lde, tree_t, None, tree_c, draws.positions)                # prover.rs:163-173
+    # fri_prover.into_proof(&query_positions) (prover.rs:161, fri.rs:148-165): per layer the folded positions' rows and Merkle view
+    pos, fri_openings = sorted(set(int(p) for p in draws.positions)), []
+    for layer, tree in zip(fri_layers, fri_trees):
+        pos = fold_positions(pos, folding)
+        fri_openings.append({"positions": pos, "rows": fri_layer_rows(layer, folding, pos), "proof": tree.prove(pos)})
+    out["fri_openings"] = fri_openings
     lap("proof of work + queries")
     out["phases_ms"] = {k: round(v, 3) for k, v in phase.items()}
     if keep:

@@ -1,5 +1,5 @@
 """Fp252 NTT / LDE timing probe: per-kernel microseconds (hipEvents) and wall time per column.
-MS_NTT252_RADIX2=1 selects the round-1 radix-2 sequence for comparison."""
+(The round-2 A/B switch MS_NTT252_RADIX2 is gone: profiles/r02_ntt252_probe.txt keeps that comparison.)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

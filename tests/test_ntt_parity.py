@@ -472,3 +472,27 @@ def _big_known_answer(log_n):
 def test_known_answer_largest_domains_hip(log_n):
     # 2^32 is the field's whole two-adic subgroup (32 GiB column + 32 GiB of scratch): the maximum size there is
     _big_known_answer(log_n)
+
+
+@pytest.mark.parametrize("kind", ["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def test_plan_outlives_its_context_safely(kind):
+    """A GpuFft collected / used after its Planner was closed: the library releases the caller's plan objects
+    together with the context; destroying one afterwards is a no-op and using one is an error, not a read of freed memory."""
+    import ctypes
+    from ministark_amd import Planner
+    lib = backends.planner(kind).lib
+    pl = Planner(0, lib)
+    dom = Radix2EvaluationDomain(1 << 13, 7)
+    f = GpuFft(dom, GOLDILOCKS_FP, pl)
+    raw = ctypes.c_void_p(f.handle.value)
+    col = GpuVec.from_numpy(pl, cref.random_elements(1 << 13, 5))
+    f.encode(col); f.execute()
+    handle = pl.handle
+    f2 = GpuIfft(dom, GOLDILOCKS_FP, pl)
+    raw2 = ctypes.c_void_p(f2.handle.value)
+    pl._plans.clear()                                     # as if the Python side had lost track: the C side must cope alone
+    col.free()
+    lib.check(lib.ms_ctx_destroy(handle)); pl.handle = None
+    assert lib.ms_ntt_execute(raw2) != 0                  # an error, reported
+    assert lib.ms_ntt_plan_destroy(raw) == 0 and lib.ms_ntt_plan_destroy(raw2) == 0      # no-ops
+    f.handle = None; f2.handle = None

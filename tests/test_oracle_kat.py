@@ -211,3 +211,54 @@ def test_c_oracle_field_ops_match_pyref():
         assert tuple(GL.from_mont(int(x)) for x in out) == F.FQ3.mul(a, b)
         L.oracle_fq3_inv(cref._p(am), cref._p(out))
         assert tuple(GL.from_mont(int(x)) for x in out) == F.FQ3.inv(a)
+
+
+# ---- an independent implementation as a second pin (round 3): sympy's number-theoretic transform, tests/golden/sympy_ntt_goldilocks.json
+def _sympy_cases():
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sympy_ntt_goldilocks.json")))
+    a, c = doc["lcg"]
+    for case in doc["cases"]:
+        s, x = case["seed"], []
+        for _ in range(1 << case["log_n"]):
+            s = (s * a + c) % (1 << 64)
+            x.append(s % F.GL.p)
+        yield case, x
+
+
+def _le_digest(v):
+    import struct
+    return hashlib.sha256(b"".join(struct.pack("<Q", int(e)) for e in v)).hexdigest()
+
+
+def test_both_oracles_match_sympys_ntt():
+    """oracle/pyref (big integers) and oracle/c (Montgomery words) against vectors produced by sympy.discrete.transforms.ntt / intt
+    (scripts/gen_sympy_ntt_vectors.py): same prime, same root 7^((p-1)/n) as arkworks' domain, subgroup transforms 2^4 .. 2^12,
+    forward and inverse; plus the coset transform as the subgroup transform of x_i 7^i."""
+    to_mont = lambda v: np.array([cref.lib().oracle_gl_to_mont(int(e)) for e in v], dtype=np.uint64)
+    from_mont = lambda a: [F.GL.from_mont(int(e)) for e in a]
+    for case, x in _sympy_cases():
+        log_n = case["log_n"]
+        n = 1 << log_n
+        dom = pyntt.Domain(F.GL, n)
+        fwd_py = pyntt.fft(dom, x) if log_n <= 10 else None
+        inv_py = pyntt.ifft(dom, x) if log_n <= 10 else None
+        fwd_c = from_mont(cref.ntt(to_mont(x), log_n, 1, False, 1))
+        inv_c = from_mont(cref.ntt(to_mont(x), log_n, 1, True, 1))
+        assert _le_digest(fwd_c) == case["forward_sha256"] and _le_digest(inv_c) == case["inverse_sha256"]
+        if fwd_py is not None:
+            assert fwd_py == fwd_c and inv_py == inv_c
+        if "forward" in case:
+            assert [format(v, "016x") for v in fwd_c] == case["forward"] and [format(v, "016x") for v in inv_c] == case["inverse"]
+    # live re-computation when sympy is importable (it is in the build container; the fixture is what travels)
+    try:
+        from sympy.discrete.transforms import ntt as sympy_ntt
+    except ImportError:
+        return
+    case, x = next(_sympy_cases())
+    n = len(x)
+    assert _le_digest([int(v) for v in sympy_ntt(x, F.GL.p)]) == case["forward_sha256"]
+    coset_in = [(v * pow(7, i, F.GL.p)) % F.GL.p for i, v in enumerate(x)]
+    want = [int(v) for v in sympy_ntt(coset_in, F.GL.p)]
+    assert from_mont(cref.ntt(to_mont(x), case["log_n"], 1, False, 7)) == want

@@ -191,13 +191,18 @@ def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr, ce_blowup=N
                                   (R(draws.deep.degree[0]), R(draws.deep.degree[1])))
     out["deep_poly"] = deep_poly
     layer = evaluate_br(deep_poly)
-    out["fri_roots"], n = [], n_l
+    out["fri_roots"], n, fri_layers = [], n_l, []
     for alpha in draws.fri_alphas:
+        fri_layers.append(layer)
         rows = [np.ascontiguousarray(layer[k::folding]) for k in range(folding)]              # rows of `folding` consecutive evaluations
         out["fri_roots"].append(cref.sha256_merkle(cref.sha256_rows(rows, 1))[1].tobytes())
         layer = cref.fri_fold(layer, n.bit_length() - 1, 1, folding, R(alpha), 1)
         n //= folding
     out["remainder"] = layer
+    out["fri_layers"] = fri_layers
+    # FriProver::set_remainder (fri.rs:232-248)
+    log_r = n.bit_length() - 1
+    out["remainder_coeffs"] = cref.ntt(cref.bit_reverse(layer.copy(), log_r), log_r, 1, True, 1)[: max(n // blowup, 1)]
     seed = out["fri_roots"][-1]
     nonce = 1
     while int.from_bytes(hashlib.sha256(seed + nonce.to_bytes(8, "big")).digest()[:8], "big") >> (64 - 8):
@@ -234,6 +239,21 @@ def _run_c5(kind, log_t, seed, air="fib"):
     pos = draws.positions
     assert np.array_equal(q.base_trace_values, np.stack([c[pos] for c in want["lde_br"]], axis=1))
     assert np.array_equal(q.composition_trace_values, np.stack([c[pos] for c in want["comp_lde"]], axis=1))
+    assert np.array_equal(got["remainder_coeffs"], want["remainder_coeffs"])
+    # FRI layer openings (fri.rs:148-165): rows of `folding` consecutive evaluations at the folded positions + the Merkle views
+    from oracle.pyref import merkle as omerkle
+    fp = sorted(set(pos))
+    assert len(got["fri_openings"]) == nlayers
+    for opening, layer in zip(got["fri_openings"], want["fri_layers"]):
+        fp = pipeline.fold_positions(fp, folding)
+        assert opening["positions"] == fp
+        rows = layer.reshape(-1, folding)
+        assert np.array_equal(opening["rows"], rows[fp])
+        cols = [np.ascontiguousarray(rows[:, k]) for k in range(folding)]
+        leaves_np = cref.sha256_rows(cols, 1)
+        leaves = [bytes(x) for x in leaves_np]
+        nodes = [bytes(x) for x in cref.sha256_merkle(leaves_np)]
+        assert opening["proof"] == omerkle.prove(leaves, nodes, fp)
 
 
 def test_prover_pipeline_c5_shape_emu():
