@@ -45,6 +45,19 @@ __device__ static const uint32_t KW_PAD64[64] = {
     0xc39c91f2, 0x9eccabbd, 0xb5c9a0e6, 0x532fb63c, 0xd2c741c6, 0x07237ea3, 0xa4954b68, 0x4c191d76,};
 
 __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }   // -> v_alignbit_b32
+// a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 (any boolean function of three operands; 0x96 = parity).  The compiler
+// finds Ch and Maj by itself but keeps the sigma functions as two v_xor_b32 each -- 352 of the 2 864 VALU instructions of
+// a Merkle node (every instruction costs an issue slot here: profiles/r03_sha256_isa.txt).
+// (truth tables: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA; Ch = e ? f : g = 0xCA, Maj = 0xE8)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t ch3(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+#else
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+__device__ __forceinline__ uint32_t ch3(uint32_t e, uint32_t f, uint32_t g) { return (e & f) ^ (~e & g); }
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return (a & b) ^ (a & c) ^ (b & c); }
+#endif
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }                  // -> v_perm_b32
 
 struct Sha {
@@ -63,16 +76,16 @@ struct Sha {
             if (i < 16) wi = w[i];
             else {
                 const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-                const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
-                const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+                const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+                const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
                 wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
                 w[i & 15] = wi;
             }
-            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
-            const uint32_t ch = (e & f) ^ (~e & g);
+            const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
+            const uint32_t ch = ch3(e, f, g);
             const uint32_t t1 = hh + S1 + ch + K256[i] + wi;
-            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
-            const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
+            const uint32_t mj = maj3(a, b, c);
             const uint32_t t2 = S0 + mj;
             hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }
@@ -83,11 +96,11 @@ struct Sha {
         uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
         #pragma unroll
         for (int i = 0; i < 64; i++) {
-            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
-            const uint32_t ch = (e & f) ^ (~e & g);
+            const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
+            const uint32_t ch = ch3(e, f, g);
             const uint32_t t1 = hh + S1 + ch + kw[i];
-            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
-            const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
+            const uint32_t mj = maj3(a, b, c);
             const uint32_t t2 = S0 + mj;
             hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }
@@ -98,11 +111,11 @@ struct Sha {
         uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
         #pragma unroll
         for (int i = 0; i < 64; i++) {
-            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
-            const uint32_t ch = (e & f) ^ (~e & g);
+            const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
+            const uint32_t ch = ch3(e, f, g);
             const uint32_t t1 = hh + S1 + ch + KW_PAD64[i];
-            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
-            const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
+            const uint32_t mj = maj3(a, b, c);
             const uint32_t t2 = S0 + mj;
             hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""C2 sweep at the column counts a prover has (2^20 x 32, 2^22 x 16, 2^24 x 8): forward coset NTT per column, by column-group
+size (MS_NTT_GROUP_BYTES is read at context creation: one process per setting).  One JSON line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ministark_amd import GOLDILOCKS_FP as FP, GpuFft, GpuVec, Planner, Radix2EvaluationDomain  # noqa: E402
+
+P = (1 << 64) - (1 << 32) + 1
+pl = Planner(0)
+rng = np.random.default_rng(1)
+out = {"group_bytes": os.environ.get("MS_NTT_GROUP_BYTES", "default"), "streams": os.environ.get("MS_NTT_STREAMS", "1")}
+for log_n, ncol in ((20, 32), (22, 16), (24, 8)):
+    n = 1 << log_n
+    cols = [GpuVec.from_numpy(pl, rng.integers(0, P, size=n, dtype=np.uint64), FP) for _ in range(ncol)]
+    plan = GpuFft(Radix2EvaluationDomain(n, 7), FP, pl)
+    t_end = time.perf_counter() + 0.4
+    while time.perf_counter() < t_end:
+        plan.enqueue(cols); pl.sync()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan.enqueue(cols)
+    pl.sync()
+    us = (time.perf_counter() - t0) / reps / ncol * 1e6
+    out[f"2^{log_n}x{ncol}"] = {"us_per_column": round(us, 2), "hbm_frac": round(2.0 * n * 8 / (us * 1e-6) / 8e12, 4)}
+    del cols, plan
+print(json.dumps(out))
