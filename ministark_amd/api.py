@@ -185,16 +185,24 @@ class DeviceBytes:
             pass
 
 
-def _gather_digests(planner, digests, ndigests, ids):
-    """32-byte records `ids` of a device digest array -> list of bytes (one device gather + one copy)."""
+def _gather_digests_launch(planner, digests, ndigests, ids):
+    """Launch the gather of the 32-byte records `ids` of a device digest array; returns a function that downloads them as a
+    list of bytes.  (Launch every gather of an opening first, fetch afterwards: one wait instead of one per call.)"""
     if not ids:
-        return []
+        return lambda: []
     idx = np.asarray(ids, dtype=np.uint64)
     out = DeviceBytes(planner, 32 * len(ids))
     L = planner.lib
     L.check(L.ms_gather_digests(planner.handle, ndigests, digests.ptr, idx.ctypes.data, len(ids), out.ptr))
-    raw = out.to_numpy().tobytes()
-    return [raw[32 * k:32 * k + 32] for k in range(len(ids))]
+
+    def fetch():
+        raw = out.to_numpy().tobytes()
+        return [raw[32 * k:32 * k + 32] for k in range(len(ids))]
+    return fetch
+
+
+def _gather_digests(planner, digests, ndigests, ids):
+    return _gather_digests_launch(planner, digests, ndigests, ids)()
 
 
 HASHES = ("sha256", "rpo256")
@@ -249,6 +257,10 @@ class MerkleTree:
         reference's MerkleView -> dict(nodes, initial_leaves, sibling_leaves, height), digests as
         bytes.  The walk over indices is bookkeeping; the digests are gathered on the device and
         come back in one copy."""
+        return self.prove_launch(indices)()
+
+    def prove_launch(self, indices):
+        """`prove` in two halves: the device gathers are launched now, the returned function fetches and assembles the view."""
         n = self.nleaves
         for i in indices:
             if i >= n:
@@ -273,12 +285,16 @@ class MerkleTree:
                 node_queue.popleft()
                 continue
             node_ids.append(index ^ 1)
-        leaves = _gather_digests(self.planner, self.leaves, n, leaf_ids)
-        nodes = _gather_digests(self.planner, self.nodes, n, node_ids)
-        return {"nodes": [nodes[k] for k in range(len(node_ids))],
-                "initial_leaves": [leaves[k] for k in initial],
-                "sibling_leaves": [leaves[k] for k in sibling],
-                "height": n.bit_length() - 1}
+        fetch_leaves = _gather_digests_launch(self.planner, self.leaves, n, leaf_ids)
+        fetch_nodes = _gather_digests_launch(self.planner, self.nodes, n, node_ids)
+
+        def fetch():
+            leaves, nodes = fetch_leaves(), fetch_nodes()
+            return {"nodes": [nodes[k] for k in range(len(node_ids))],
+                    "initial_leaves": [leaves[k] for k in initial],
+                    "sibling_leaves": [leaves[k] for k in sibling],
+                    "height": n.bit_length() - 1}
+        return fetch
 
     def root(self):
         out = np.empty(32, dtype=np.uint8)
@@ -503,9 +519,15 @@ class Matrix:
         pl, L = self.planner, self.planner.lib
         pos = np.asarray(positions, dtype=np.uint64)
         words = self.num_cols() * FIELD_WORDS[self.field]
+        return self.get_rows_launch(positions)()
+
+    def get_rows_launch(self, positions):
+        pl, L = self.planner, self.planner.lib
+        pos = np.asarray(positions, dtype=np.uint64)
+        words = self.num_cols() * FIELD_WORDS[self.field]
         out = DeviceBytes(pl, max(1, len(pos) * words * 8))
         L.check(L.ms_gather_rows(pl.handle, self.field, self.num_rows(), _ptr_array(self.columns), self.num_cols(), pos.ctypes.data, len(pos), out.ptr))
-        return out.to_numpy().view(np.uint64)[: len(pos) * words].reshape(len(pos), words)
+        return lambda: out.to_numpy().view(np.uint64)[: len(pos) * words].reshape(len(pos), words)
 
     def hash_rows(self, hash="sha256"):
         """`hash_rows::<F, H>` (src/merkle.rs:412-436, src/matrix.rs:254-280): one digest per row ->
@@ -567,12 +589,15 @@ class Queries:
 
     def __init__(self, base_trace_lde, extension_trace_lde, composition_trace_lde, base_tree, extension_tree, composition_tree, positions):
         positions = [int(p) for p in positions]
-        self.base_trace_proof = base_tree.prove(positions)
-        self.extension_trace_proof = extension_tree.prove(positions) if extension_tree is not None else None
-        self.composition_trace_proof = composition_tree.prove(positions)
-        self.base_trace_values = base_trace_lde.get_rows(positions)
-        self.extension_trace_values = extension_trace_lde.get_rows(positions) if extension_trace_lde is not None else None
-        self.composition_trace_values = composition_trace_lde.get_rows(positions)
+        none = lambda: None
+        launched = [base_tree.prove_launch(positions),                      # every gather is in flight before the first download
+                    extension_tree.prove_launch(positions) if extension_tree is not None else none,
+                    composition_tree.prove_launch(positions),
+                    base_trace_lde.get_rows_launch(positions),
+                    extension_trace_lde.get_rows_launch(positions) if extension_trace_lde is not None else none,
+                    composition_trace_lde.get_rows_launch(positions)]
+        (self.base_trace_proof, self.extension_trace_proof, self.composition_trace_proof, self.base_trace_values,
+         self.extension_trace_values, self.composition_trace_values) = [f() for f in launched]
 
 
 def apply_drp(evals, alpha, folding_factor, domain_offset=1):

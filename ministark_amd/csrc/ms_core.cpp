@@ -75,6 +75,7 @@ extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     for (auto m : ctx->jit_modules) (void)hipModuleUnload(m);
     if (ctx->stream2) { (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     (void)hipStreamDestroy(ctx->stream);
@@ -148,6 +149,28 @@ int pool_free(ms_ctx* ctx, void* d_ptr) {
     if (ctx->pool_bytes + bytes <= ctx->pool_cap) { ctx->pool.insert({bytes, d_ptr}); ctx->pool_bytes += bytes; return MS_OK; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(d_ptr));
+    return MS_OK;
+}
+int stage_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    static constexpr size_t RING = (size_t)1 << 20;
+    if (!bytes) return MS_OK;
+    if (!ctx->stage) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, RING, 0) == hipSuccess) { ctx->stage = (char*)p; ctx->stage_bytes = RING; } else (void)hipGetLastError();
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (!ctx->stage || need > ctx->stage_bytes / 2) {            // large or no pinned memory: pageable copy, wait for it
+        HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return MS_OK;
+    }
+    if (ctx->stage_off + need > ctx->stage_bytes) {              // wrap: every copy out of the ring has to be done first
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->stage_off = 0;
+    }
+    memcpy(ctx->stage + ctx->stage_off, h_src, bytes);
+    HIPCHK(hipMemcpyAsync(d_dst, ctx->stage + ctx->stage_off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->stage_off += need;
     return MS_OK;
 }
 extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {

@@ -56,6 +56,10 @@ struct ms_ctx {
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)96 << 30;
     std::map<void*, size_t> live;            // size of every block handed out by ms_alloc
+    // pinned staging ring for the small host arrays entry points take (query positions, digest indices): the copy to the
+    // device is then truly asynchronous and the call does not drain the stream (stage_upload)
+    char* stage = nullptr;
+    size_t stage_bytes = 0, stage_off = 0;
     void* comm = nullptr;                    // ncclComm_t once ms_comm_init has run
     int comm_rank = 0, comm_size = 1;
     void* prog_buf = nullptr;                // device copy of the current constraint program + constants
@@ -89,6 +93,7 @@ struct ProfScope {
 int ctx_scratch(ms_ctx* ctx, size_t bytes, void** out);
 int pool_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr);          // the caller holds ctx->mu
 int pool_free(ms_ctx* ctx, void* d_ptr);
+int stage_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   // the caller holds ctx->mu; h_src may be reused at once
 // Pooled temporaries of an entry point, returned to the pool on EVERY exit path (an early return through
 // MSCHK / HIPCHK used to strand them in ctx->live until ms_ctx_destroy).  PoolGuard goes through the locking
 // public calls and must outlive the function's lock scope; LockedPoolGuard is for code that already holds

@@ -168,20 +168,24 @@ def fold_positions(positions, folding_factor):
     return out
 
 
-def fri_layer_rows(layer, folding_factor, positions):
+def fri_layer_rows_launch(layer, folding_factor, positions):
     """Rows `positions` of `Matrix::from_arrays(evaluations.as_chunks::<N>())` (src/fri.rs:213-215): N consecutive
-    evaluations each, gathered on the device (32-byte records of ms_gather_digests) -> numpy [len(positions), N * words]."""
-    import ctypes
+    evaluations each, gathered on the device (32-byte records of ms_gather_digests).  Returns a function that downloads
+    them as numpy [len(positions), N * words]."""
     from .api import FIELD_WORDS, DeviceBytes
     pl = layer.planner
     words = folding_factor * FIELD_WORDS[layer.field]
     if words % 4:
-        return layer.to_numpy().reshape(-1, words)[positions]              # rows shorter than a 32-byte record: tiny layers only
+        return lambda: layer.to_numpy().reshape(-1, words)[positions]      # rows shorter than a 32-byte record: tiny layers only
     per = words // 4
     ids = np.array([p * per + k for p in positions for k in range(per)], dtype=np.uint64)
     out = DeviceBytes(pl, 32 * len(ids))
     pl.lib.check(pl.lib.ms_gather_digests(pl.handle, len(layer) * FIELD_WORDS[layer.field] // 4, layer.ptr, ids.ctypes.data, len(ids), out.ptr))
-    return out.to_numpy().view(np.uint64).reshape(len(positions), words)
+    return lambda: out.to_numpy().view(np.uint64).reshape(len(positions), words)
+
+
+def fri_layer_rows(layer, folding_factor, positions):
+    return fri_layer_rows_launch(layer, folding_factor, positions)()
 
 
 def fri_num_layers(n_lde, blowup, folding, max_remainder_coeffs):
@@ -257,11 +261,11 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
     out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)   # prover.rs:160
     out["queries"] = Queries(lde_t, None, comp_lde, tree_t, None, tree_c, draws.positions)                # prover.rs:163-173
     # fri_prover.into_proof(&query_positions) (prover.rs:161, fri.rs:148-165): per layer the folded positions' rows and Merkle view
-    pos, fri_openings = sorted(set(int(p) for p in draws.positions)), []
-    for layer, tree in zip(fri_layers, fri_trees):
+    pos, launched = sorted(set(int(p) for p in draws.positions)), []
+    for layer, tree in zip(fri_layers, fri_trees):                            # all gathers first, then the downloads
         pos = fold_positions(pos, folding)
-        fri_openings.append({"positions": pos, "rows": fri_layer_rows(layer, folding, pos), "proof": tree.prove(pos)})
-    out["fri_openings"] = fri_openings
+        launched.append((pos, fri_layer_rows_launch(layer, folding, pos), tree.prove_launch(pos)))
+    out["fri_openings"] = [{"positions": p, "rows": rows(), "proof": proof()} for p, rows, proof in launched]
     lap("proof of work + queries")
     out["phases_ms"] = {k: round(v, 3) for k, v in phase.items()}
     if keep:
