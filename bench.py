@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed transforms before the warm-up steps (clock ramp)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
     ap.add_argument("--mode", choices=["ntt", "lde-commit"], default="ntt", help="lde-commit: only the column-sharded LDE + commitment (any N)")
     ap.add_argument("--no-extras", action="store_true", help="skip the lde_commit / prove / sharded objects")
     args = ap.parse_args()
@@ -482,6 +482,19 @@ def main():
             pl.sync()
             variants[name + "_us_per_transform"] = round((time.perf_counter() - t1) / 5 / args.cols * 1e6, 2)
             plan.close()
+        # the shape of the reference's own criterion harness (gpu/benches/fft.rs:36-43): ONE column transformed again and again
+        # in place -- column + scratch = 256 MiB, the size of the Infinity Cache; next to the batch, never instead of it
+        plan = GpuFft(dom, GOLDILOCKS_FP, pl)
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < 0.3:
+            plan.enqueue(cols[:1])
+            pl.sync()
+        t1 = time.perf_counter()
+        for _ in range(40):
+            plan.enqueue(cols[:1])
+        pl.sync()
+        variants["single_column_repeated_us_per_transform"] = round((time.perf_counter() - t1) / 40 * 1e6, 2)
+        plan.close()
         out["variants"] = variants
     if not args.no_extras:
         state["line"] = dict(out)                                # what rank 0 prints if the exchange never returns

@@ -80,48 +80,34 @@ emit("C3 LDE 2^20 x 32, blowup 8 (iNTT + coset NTT + bit-reverse) + SHA-256 rows
 lde = state["lde"]
 del m
 
-# ---- C4: constraint evaluation on 2^23 points (i) fib AIR Fp=Fq
-x = E.X()
-c = [lambda o=0, kk=kk: E.Trace(kk, o) for kk in range(8)]
-cons = [c[0](1) - (c[6]() + c[7]()), c[1](1) - (c[7]() + c[0](1))] + [c[kk]() - (c[kk - 2]() + c[kk - 1]()) for kk in range(2, 8)]
-n_trace = 1 << 21
-zer = (x - E.Constant(3)) / (x ** n_trace - 1)
-comp = None
-for kk, cn in enumerate(cons):
-    term = cn * zer * (E.Challenge(2 * kk) * x ** 3 + E.Challenge(2 * kk + 1))
-    comp = term if comp is None else comp + term
-prog = E.compile_expr(comp, 8, False)
-ch = rand(16).reshape(-1, 1)
-base = lde.columns[:8]
-wall, k = timed(lambda: E.eval(prog, pl, ch, ch[:1], 4, 7, 1 << 23, base), reps=3)
-emit("C4(i) fib AIR 8 Fp columns, 2^23 points, lde_step 4", wall, k, ninstr=len(prog.instrs), regs=[prog.max_p, prog.max_q],
-     algorithmic_GBps=round(9 * 8 * (1 << 23) / wall / 1e9, 1))
-
-# (ii) mixed 17 Fp + 9 Fq3 at 2^23
-b = [lambda o=0, kk=kk: E.Trace(kk, o) for kk in range(17)]
-e = [lambda o=0, kk=kk: E.Trace(17 + kk, o) for kk in range(9)]
-expr = None
-for kk in range(9):
-    t = (e[kk](1) - e[kk]() * (E.Challenge(kk % 4) - b[kk]() * E.Challenge((kk + 1) % 4) - b[kk + 8](1))) * (x - 1) / (x ** 64 - 1)
-    expr = t if expr is None else expr + t * E.Challenge(kk % 4)
-prog2 = E.compile_expr(expr, 17, True)
+# ---- C4: constraint evaluation on 2^23 points: the same three AIRs as bench.py's `constraint_eval` object (ministark_amd/pipeline.py)
+from ministark_amd import pipeline   # noqa: E402
+N23 = 1 << 23
+for lde_step in (1, 4):           # (i) the reference's fib AIR (examples/fib/main.rs:73-140); 1 = its ce_blowup_factor
+    comp, _, nch = pipeline.fib_constraints(N23 // lde_step)
+    prog = E.compile_expr(comp, 8, False)
+    ch = rand(nch).reshape(-1, 1)
+    base = lde.columns[:8]
+    wall, k = timed(lambda: E.eval(prog, pl, ch, ch[:1], lde_step, 7, N23, base), reps=3)
+    emit(f"C4(i) fib AIR (FibAirConfig::constraints, 17 constraints), 8 Fp columns, 2^23 points, lde_step {lde_step}", wall, k, ninstr=len(prog.instrs),
+         regs=[prog.max_p, prog.max_q], algorithmic_GBps=round(9 * 8 * N23 / (sum(k.values()) * 1e-6) / 1e9, 1))
+expr2, nch2 = pipeline.mixed_air_constraints()                       # (ii) 17 Fp + 9 Fq3
+prog2 = E.compile_expr(expr2, 17, True)
 ext = [GpuVec.from_numpy(pl, rand(3 << 23), FQ3) for _ in range(9)]
-ch3 = rand(12).reshape(-1, 3)
-wall, k = timed(lambda: E.eval(prog2, pl, ch3, ch3[:1], 2, 7, 1 << 23, lde.columns[:17], ext), reps=3)
+ch3 = rand(3 * nch2).reshape(-1, 3)
+wall, k = timed(lambda: E.eval(prog2, pl, ch3, ch3[:1], 2, 7, N23, lde.columns[:17], ext), reps=3)
 emit("C4(ii) mixed 17 Fp + 9 Fq3 columns, 2^23 points", wall, k, ninstr=len(prog2.instrs), regs=[prog2.max_p, prog2.max_q],
-     algorithmic_GBps=round((17 * 8 + 9 * 24 + 24) * (1 << 23) / wall / 1e9, 1))
+     algorithmic_GBps=round((17 * 8 + 9 * 24 + 24) * N23 / (sum(k.values()) * 1e-6) / 1e9, 1))
 del ext
-
-# (iii) Fp252 (the reference's only 256-bit field; Fq = Fp), 8 columns, at 2^20 and at BASELINE's 2^23 points
-prog3 = E.compile_expr(comp, 8, False, STARK252_FP)
-ch252 = rng.integers(0, 1 << 59, size=(16, 4), dtype=np.uint64)
-for lg in (20, 23):
+for lg in (20, 23):               # (iii) the fib AIR over the 252-bit field, at 2^20 and at BASELINE's 2^23 points
+    comp3, _, nch3 = pipeline.fib_constraints((1 << lg) // 4, 8, STARK252_FP)
+    prog3 = E.compile_expr(comp3, 8, False, STARK252_FP)
+    ch252 = rng.integers(0, 1 << 59, size=(nch3, 4), dtype=np.uint64)
     cols252 = [GpuVec.from_numpy(pl, rng.integers(0, 1 << 59, size=4 << lg, dtype=np.uint64), STARK252_FP) for _ in range(8)]
     wall, k = timed(lambda: E.eval(prog3, pl, ch252, ch252[:1], 4, 3, 1 << lg, cols252), reps=2)
     emit(f"C4(iii) fib AIR on Fp252 (Fq = Fp), 8 columns, 2^{lg} points", wall, k, ninstr=len(prog3.instrs),
-         algorithmic_GBps=round(9 * 32 * (1 << lg) / wall / 1e9, 1))
-    if lg == 23:
-        del cols252
+         algorithmic_GBps=round(9 * 32 * (1 << lg) / (sum(k.values()) * 1e-6) / 1e9, 1))
+    del cols252
 cols252 = [GpuVec.from_numpy(pl, rng.integers(0, 1 << 59, size=4 << 20, dtype=np.uint64), STARK252_FP) for _ in range(2)]
 plan252 = GpuFft(Radix2EvaluationDomain(1 << 20, 3, STARK252_FP), STARK252_FP, pl)
 wall, k = timed(lambda: plan252.enqueue(cols252[:2]), reps=2)
@@ -145,59 +131,28 @@ def fri():
 wall, k = timed(fri, reps=3)
 emit("FRI folds 2^23 -> 2^8 by 8 (Fq3), 5 layers", wall, k, first_layer_GBps=round((24 * (1 << 23) * 9 / 8) / (k.get("fri_fold", 1) * 1e-6) / 1e9, 1))
 
-# ---- C5-shaped pipeline on ONE GPU: every data-parallel phase of default_prove (src/prover.rs:25-174), device-resident,
-# on a 2^22-row x 8-column fib-shaped trace, ProofOptions::new(32, 4, 8, 8, 64) (examples/fib/main.rs:225): 32 queries,
-# blow-up 4, grinding 8 bits, FRI folding 8, remainder <= 64.  The channel (Fiat-Shamir hashing of a few digests) is
-# replaced by fixed pseudo-random challenges: timings only; every phase's parity is asserted in tests/.
-from ministark_amd import Queries, grind_proof_of_work   # noqa: E402
+# ---- C5 on ONE GPU: ministark_amd/pipeline.py (every data-parallel phase of default_prove, src/prover.rs:25-174) on a
+# 2^22-row x 8-column trace with the reference's fib AIR, ProofOptions::new(32, 4, 8, 8, 64) (examples/fib/main.rs:225); the
+# channel is replaced by fixed draws: timings only, every phase's parity is asserted in tests/test_pipeline_parity.py.
 from ministark_amd.composer import DeepCompositionCoeffs, DeepPolyComposer   # noqa: E402
+from ministark_amd import Queries, grind_proof_of_work   # noqa: E402
 
 del lde, state
 log_t, blow = 22, 4
-n_t, n_lde = 1 << log_t, 1 << (log_t + 2)
+n_t = 1 << log_t
 trace = Matrix.from_numpy(pl, [rand(n_t) for _ in range(8)], FP)
-prog_c5 = E.compile_expr(comp, 8, False)
-trace_args = [(c, o) for c in range(8) for o in (0, 1)]          # every column at the current and the next row
-coeffs = DeepCompositionCoeffs([int(v) for v in rand(len(trace_args))], [int(v) for v in rand(blow)], (int(rand(1)[0]), int(rand(1)[0])))
-positions = [int(p) for p in rng.integers(0, n_lde, size=32)]
-phase = {}
+comp5, ce5, nch5 = pipeline.fib_constraints(n_t)
+draws5 = pipeline.Draws(0xC5, 8, nch5, ce5, 32, n_t * blow, pipeline.fri_num_layers(n_t * blow, blow, 8, 64))
+res5 = {}
 
 
 def c5():
-    t = time.perf_counter()
-    trace_dom, lde_dom = Radix2EvaluationDomain(n_t), Radix2EvaluationDomain(n_lde, 7)
-    base_polys = trace.interpolate(trace_dom)                          # prover.rs:50
-    lde_t = base_polys.bit_reversed_evaluate(lde_dom)                  # prover.rs:51
-    tree_t = MerkleTree.from_matrix(lde_t); tree_t.root()              # prover.rs:52-55
-    phase["base trace: interpolate + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
-    comp_evals = E.eval(prog_c5, pl, ch, ch[:1], blow, 7, n_lde, lde_t.columns, bit_reversed=True)   # prover.rs:88-107, on the committed layout
-    phase["constraint evaluation"] = time.perf_counter() - t; t = time.perf_counter()
-    comp_poly = Matrix([comp_evals]).bit_reverse_rows().into_polynomials(lde_dom).columns[0]   # prover.rs:111-112
-    comp_polys = Matrix.from_chunks(comp_poly, blow)                   # prover.rs:113-121
-    comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)               # prover.rs:122
-    tree_c = MerkleTree.from_matrix(comp_lde); tree_c.root()           # prover.rs:123-124
-    phase["composition trace: iNTT + split + LDE + commit"] = time.perf_counter() - t; t = time.perf_counter()
-    composer = DeepPolyComposer(trace_args, n_t, 0x1234567890abcdef % P, base_polys, None, comp_polys)   # prover.rs:137-144
-    composer.get_ood_evals()                                           # prover.rs:145-146
-    deep = Matrix([composer.into_deep_poly(coeffs)]).into_bit_reversed_evaluations(lde_dom)   # prover.rs:149-152
-    phase["DEEP: OOD evaluations + composition + LDE"] = time.perf_counter() - t; t = time.perf_counter()
-    cur, n = deep.columns[0], n_lde                                    # fri.rs:179-231
-    alpha1 = rand(1)
-    last_root = None
-    while n > 64 * blow:
-        last_root = MerkleTree.from_fri_layer(cur, 8).root()
-        cur = apply_drp(cur, alpha1, 8, 1)
-        n //= 8
-    pl.sync()
-    phase["FRI layers (commit + fold)"] = time.perf_counter() - t; t = time.perf_counter()
-    grind_proof_of_work(pl, last_root, 8)                              # prover.rs:160 (grinding factor 8)
-    Queries(lde_t, None, comp_lde, tree_t, None, tree_c, positions)    # prover.rs:163-173
-    phase["proof of work + queries"] = time.perf_counter() - t
+    res5.update(pipeline.prove_phases(pl, trace, comp5, draws5, blow, 8, 64, 8, ce_blowup=ce5))
 
 
 wall, k = timed(c5, reps=2)
-emit("C5-shaped single-GPU pipeline: 2^22 rows x 8 cols, blow-up 4, FRI fold 8, 32 queries, 8 grinding bits (fixed challenges instead of the channel)", wall, k,
-     phases_ms={kk: round(v * 1e3, 2) for kk, v in phase.items()})
+emit("C5 on one GPU: 2^22 rows x 8 cols, fib AIR, blow-up 4, FRI fold 8, 32 queries, 8 grinding bits (fixed draws instead of the channel)", wall, k,
+     phases_ms=res5["phases_ms"])
 
 # ---- C1-shaped pipeline at scale: examples/brainfuck's column mix (17 base Fp + 9 extension Fq3 columns, blow-up 16,
 # FRI folding 16, examples/brainfuck/main.rs:92-105) on 2^16 rows (LDE 2^20), every data-parallel phase on the device;
