@@ -51,6 +51,7 @@ sys.path.insert(0, ROOT)
 
 LOG_N = 24
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+P_GOLDILOCKS = (1 << 64) - (1 << 32) + 1
 
 
 def sharded_lde_commit(pl, comm, steps, warmup, log_rows=22, total_cols=32, log_blowup=2, barrier=lambda: None):
@@ -134,6 +135,37 @@ def _profiled(pl, fn, reps, after_wall=None):
     prof = pl.profile_read()
     pl.profile(False)
     return wall, {k: round(v["total_us"] / reps, 1) for k, v in sorted(prof.items())}
+
+
+def bench_c2_sweep(pl):
+    """configs[1] over its whole range at the column counts a prover has: forward coset NTT and inverse coset NTT, wall time per
+    column over one enqueue of all columns (10 repetitions), with the fraction of the HBM roofline (16 bytes per point)."""
+    from ministark_amd import GOLDILOCKS_FP, GpuFft, GpuIfft, GpuVec, Radix2EvaluationDomain
+    rng = np.random.default_rng(5)
+    out = {"workload": "configs[1] sweep: forward / inverse coset NTT (offset 7), Fp, in place, per column", "peak_GBps": HBM_PEAK_GBS, "sizes": {}}
+    for log_n, ncol in ((17, 64), (18, 64), (19, 64), (20, 32), (21, 32), (22, 16), (23, 16), (24, 8)):
+        n = 1 << log_n
+        cols = [GpuVec.from_numpy(pl, rng.integers(0, P_GOLDILOCKS, size=n, dtype=np.uint64), GOLDILOCKS_FP) for _ in range(ncol)]
+        row = {"columns": ncol}
+        for name, cls in (("forward", GpuFft), ("inverse", GpuIfft)):
+            plan = cls(Radix2EvaluationDomain(n, 7), GOLDILOCKS_FP, pl)
+            t_end = time.perf_counter() + 0.25
+            while time.perf_counter() < t_end:
+                plan.enqueue(cols)
+                pl.sync()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                plan.enqueue(cols)
+            pl.sync()
+            us = (time.perf_counter() - t0) / reps / ncol * 1e6
+            row[name + "_us_per_column"] = round(us, 2)
+            row[name + "_hbm_frac"] = round(2.0 * n * 8 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            plan.close()
+        for c in cols:
+            c.free()
+        out["sizes"][f"2^{log_n}"] = row
+    return out
 
 
 def bench_lde_commit(pl, with_cpu):
@@ -505,6 +537,7 @@ def main():
     if world == 1 and not args.no_extras:
         for c in cols:
             c.free()
+        out["c2_sweep"] = bench_c2_sweep(pl)
         out["lde_commit"] = bench_lde_commit(pl, not args.no_cpu_baseline)
         out["constraint_eval"] = bench_constraint_eval(pl, not args.no_cpu_baseline)
         out["prove"] = bench_prove(pl, not args.no_cpu_baseline)

@@ -203,6 +203,9 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         // three passes: prefer (8, 8, rest - 8) to an even split whenever the last radix is still >= 16 -- two of the
         // three passes are then limb-form radix-256 passes (ntt2_kernels.h), e.g. 2^20 = 256 * 256 * 16 instead of 256 * 64 * 64
         if (extra == 2 && rest >= 12 && rest <= 16) { p->lr[1] = 8; p->lr[2] = rest - 8; }
+        // 2^17..2^20 points: (256, R, 256) with R = 2..16 -- the middle pass holds its whole network in registers
+        // (ntt2_small_mid_pass) and both outer passes are the limb-form radix-256 kernels with the uniform inter-pass factor
+        if (rest >= 9 && rest <= 12) { p->npass = 3; p->lr[1] = rest - 8; p->lr[2] = 8; }
         unsigned acc = 0;
         for (int q = 0; q < p->npass; q++) { p->log_s[q] = acc; acc += p->lr[q]; }
         // digit fields.  pass 1 maps j' = (j2..jm) [jm least significant] to layout (jm..j2) [j2 least]
@@ -257,7 +260,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
     size_t off_wr4[4] = {0, 0, 0, 0}, off_twu4[4] = {0, 0, 0, 0}, off_sc4 = 0, off_gp = 0, off_tin4 = 0, off_tout4 = 0;
     bool has_wr4[4] = {false, false, false, false}, has_twu4[4] = {false, false, false, false}, has_gp = false, has_scu4 = false;
     size_t off_scu4 = 0;
-    p->uni = !p->small && p->npass == 3 && p->lr[1] == 8 && p->lr[2] >= 6 && (n * V) % msntt2::TILE == 0;
+    p->uni = !p->small && p->npass == 3 && (p->lr[1] == 8 || (p->lr[1] <= 4 && p->lr[2] == 8)) && p->lr[2] >= 6 && (n * V) % msntt2::TILE == 0;
     if (!p->small) {
         const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
         auto append4 = [&](const std::vector<uint64_t>& plain) {
@@ -267,13 +270,15 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             return off;
         };
         for (int q = 0; q < p->npass; q++) {
-            if (p->lr[q] != 8) continue;
-            powers(t, 256, gl::pow(w, (uint64_t)n >> 8)); off_wr4[q] = append4(t); has_wr4[q] = true;
+            const bool small_mid = p->uni && q == 1 && p->lr[q] <= 4;      // ntt2_small_mid_pass: [U][k2], k2 < R
+            if (p->lr[q] != 8 && !small_mid) continue;
+            if (!small_mid) { powers(t, 256, gl::pow(w, (uint64_t)n >> 8)); off_wr4[q] = append4(t); has_wr4[q] = true; }
             if (q >= 1 && q < p->npass - 1) {
                 // w_U^k = w_n^((rev(U) k) << log_s): the factor ntt_mid_pass builds per tile in LDS (twl[])
-                const size_t nU = n >> (8 + p->log_s[q]);
+                const size_t R = (size_t)1 << p->lr[q];
+                const size_t nU = n >> (p->lr[q] + p->log_s[q]);
                 const uint64_t ws = gl::pow(w, (uint64_t)1 << p->log_s[q]);
-                t.resize(nU * 256);
+                t.resize(nU * R);
                 for (size_t U = 0; U < nU; U++) {
                     unsigned rU = 0;
                     for (unsigned f = 0; f < p->nfields[q]; f++)
@@ -281,7 +286,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
                     const uint64_t wu = gl::pow(ws, rU);
                     // UNI plans: pass 2 also carries h^j3 of the inter-pass factor (h w_n^k1)^(R3 j2 + j3), j3 = rev(U)
                     uint64_t x = (p->uni && q == 1 && !p->inverse && p->coset) ? gl::pow(h, rU) : 1;
-                    for (unsigned k = 0; k < 256; k++) { t[U * 256 + k] = x; x = gl::mul(x, wu); }
+                    for (size_t k = 0; k < R; k++) { t[U * R + k] = x; x = gl::mul(x, wu); }
                 }
                 off_twu4[q] = append4(t); has_twu4[q] = true;
             }
@@ -294,9 +299,10 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             // pass 1: tin4[j2][b][a'] = w_256^(a' b) w_n^(a' R3 j2) = w_n^(a' (b n/256 + R3 j2));
             //         tout4[j2][b'] = h^(R3 j2) w_n^(16 b' R3 j2)      (h = 1 unless this is a forward coset transform)
             const unsigned r3 = p->lr[2];
+            const unsigned R2 = 1u << p->lr[1];
             const uint64_t hh = (!p->inverse && p->coset) ? h : 1;
-            t.resize((size_t)256 * 256);
-            for (unsigned j2 = 0; j2 < 256; j2++)
+            t.resize((size_t)R2 * 256);
+            for (unsigned j2 = 0; j2 < R2; j2++)
                 for (unsigned b = 0; b < 16; b++) {
                     const uint64_t m = ((uint64_t)b * (n >> 8) + ((uint64_t)j2 << r3)) & (n - 1);
                     const uint64_t wm = gl::pow(w, m);
@@ -304,8 +310,8 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
                     for (unsigned a = 0; a < 16; a++) { t[((size_t)j2 * 16 + b) * 16 + a] = x; x = gl::mul(x, wm); }
                 }
             off_tin4 = append4(t);
-            t.resize((size_t)256 * 16);
-            for (unsigned j2 = 0; j2 < 256; j2++) {
+            t.resize((size_t)R2 * 16);
+            for (unsigned j2 = 0; j2 < R2; j2++) {
                 const uint64_t wm = gl::pow(w, (((uint64_t)j2 << r3) * 16) & (n - 1));
                 uint64_t x = gl::pow(hh, (uint64_t)j2 << r3);
                 for (unsigned bp = 0; bp < 16; bp++) { t[(size_t)j2 * 16 + bp] = x; x = gl::mul(x, wm); }
@@ -568,10 +574,11 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
             // (the per-element scale walk of an inverse coset transform stays with the round-1 last pass: the walk is two table
             // loads and a Montgomery product per word, which the 4-wave limb kernel hides worse -- 91 vs 75 us per 2^24
             // column; so does the fused bit-reversed store of Fq3 columns, whose runs interleave three words)
-            const bool v2_ok = p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
+            const bool small_mid = p->uni && q == 1 && p->lr[q] <= 4;
+            const bool v2_ok = small_mid || (p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
                                (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0
                                        : (pass_sw % msntt2::TW == 0 && !(last && p->scale_mode == 2 && p->d_scu4 == nullptr) &&
-                                          !(last && bitrev_out && (p->V != 1 || p->inverse || p->scale_mode != 0))));
+                                          !(last && bitrev_out && (p->V != 1 || p->inverse || p->scale_mode != 0)))));
             static const bool dbg = getenv("MS_NTT_DEBUG") != nullptr;
             if (dbg) fprintf(stderr, "[ms_ntt] log_n=%u V=%u pass %d/%d radix 2^%u: %s kernel\n", p->log_n, p->V, q + 1, p->npass, p->lr[q], v2_ok ? (p->uni && q < 2 ? "limb-form (ntt2), uniform inter-pass factor" : "limb-form (ntt2)") : "round-1");
             if (p->uni && q < 2 && !v2_ok) return fail(MS_ERR_INVALID, "internal: uniform inter-pass plan without its limb-form passes");
@@ -605,6 +612,13 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
                         else MS_P1(false, false, 16);
                     }
 #undef MS_P1
+                } else if (small_mid) {     // (256, R, 256) plans: the whole radix-R network in registers
+#define MS_SM(LOGR) do { if (p->inverse) { if (perm) hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, LOGR, true>), g2, b2, 0, st, Q); \
+                                           else hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, LOGR, false>), g2, b2, 0, st, Q); } \
+                         else { if (perm) hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, LOGR, true>), g2, b2, 0, st, Q); \
+                                else hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, LOGR, false>), g2, b2, 0, st, Q); } } while (0)
+                    switch (p->lr[q]) { case 1: MS_SM(1); break; case 2: MS_SM(2); break; case 3: MS_SM(3); break; default: MS_SM(4); break; }
+#undef MS_SM
                 } else if (!last) {
                     if (perm) {             // ... and reads pass 1's permuted rows, writes the natural order (in place)
                         if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0, true, true>), g2, b2, 0, st, Q);

@@ -127,6 +127,15 @@ __device__ __forceinline__ uint64_t pin(uint64_t x) { asm volatile("" : "+v"(x))
 MS_HD uint64_t pin(uint64_t x) { return x; }
 #endif
 
+// "Every lane of this wave has executed the loads above before any lane executes the stores below."  On the hardware that holds
+// by construction (a wave issues each instruction for all its lanes, in order), so this is only a fence for the compiler's
+// scheduler; the simulator of tests/emu runs the lanes one after the other between barriers and needs a real one.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_lockstep() { __builtin_amdgcn_wave_barrier(); }
+#else
+inline void wave_lockstep() { __syncthreads(); }
+#endif
+
 // three of the four copies of a table slot, for a product on the way into a network (wave-uniform: scalar registers)
 __device__ __forceinline__ glimb::Q3 q3_at(const uint64_t* t, unsigned slot) {
     const glimb::W4 w = w4_at(t, slot);
@@ -307,6 +316,77 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
                 dst[pos] = val;
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- middle pass of a three-pass plan (256, R, 256) with R = 2^LOGR <= 16: no exchange at all --------------------------
+// Columns of 2^17..2^20 points.  Rows of sw = 256 V words (log_s = 8), a block U = R rows.  A lane owns one word of a 64-word
+// run in all R rows of a block, so the whole radix-R network sits in its registers: the pass is the product on the loads
+// (LOADQ's per-lane factor, see ntt2_mid_pass), the network, and the wave-uniform factor w_U^k2 (twu4[U][k2], with h^j3 of a
+// coset transform) on the stores.  A workgroup takes 256 / R runs (32 words per lane, 16384 per workgroup, as everywhere).
+// PERM: the rows are in the order ntt2_first_pass<.., PERM> leaves them; the natural order is restored here, in place.
+template <bool INV, int LOGR, bool PERM>
+__global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
+    constexpr int R = 1 << LOGR, NNET = 32 / R;               // networks per lane
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t sw = ((size_t)1 << P.log_s) * P.V;
+    const unsigned runs_per_u = (unsigned)(sw / TW);          // runs of 64 words per row
+    const unsigned g0 = blockIdx.x * (256 / R) + w * NNET;    // this wave's first run (runs count through the blocks U)
+    const unsigned pl = PERM ? ((lane >> 5) & 1) * 32 + ((lane >> 3) & 1) * 16 + (lane & 7) * 2 + ((lane >> 4) & 1) : lane;
+
+    // every word of the lane is requested up front; the factors' table words four networks at a time, one group ahead
+    constexpr int CH = NNET < 4 ? NNET : 4, NCH = NNET / CH;
+    uint64_t x[NNET][R];
+    uint64_t qlo[CH], qhi[CH];
+    auto factor_words = [&](int c) {
+        #pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const unsigned U = (g0 + c * CH + i) / runs_per_u, q = (g0 + c * CH + i) % runs_per_u;
+            const unsigned k1 = (q * TW + lane) / P.V;
+            const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
+            qlo[i] = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+            qhi[i] = P.tw_hi[e >> P.lo_bits];
+        }
+    };
+    factor_words(0);
+    #pragma unroll
+    for (int i = 0; i < NNET; i++) {
+        const unsigned U = (g0 + i) / runs_per_u, q = (g0 + i) % runs_per_u;
+        const uint64_t* p = src + (size_t)U * R * sw + (size_t)q * TW + pl;
+        #pragma unroll
+        for (int a = 0; a < R; a++) { x[i][a] = *p; p += sw; }
+    }
+    if constexpr (PERM) wave_lockstep();      // in place: a lane's stores land on words that other lanes of its wave have read
+    #pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        uint64_t qm[CH];
+        #pragma unroll
+        for (int i = 0; i < CH; i++) qm[i] = gld::mmul(qlo[i], qhi[i]);
+        if (c + 1 < NCH) factor_words(c + 1);
+        #pragma unroll
+        for (int ii = 0; ii < CH; ii++) {
+            const int i = c * CH + ii;
+            const unsigned U = (g0 + i) / runs_per_u, q = (g0 + i) % runs_per_u;
+            const glimb::Q3 qpl = glimb::q3_from(gld::mmul(qm[ii], 1), gld::mmul(qm[ii], (uint64_t)1 << 24), gld::mmul(qm[ii], (uint64_t)1 << 48));
+            glimb::L4 v[R];
+            #pragma unroll
+            for (int a = 0; a < R; a++) v[a] = glimb::mul3_to_limbs(x[i][a], qpl);
+            glimb::dft<R, INV>(v);
+            uint64_t* o = dst + (size_t)U * R * sw + (size_t)q * TW + lane;
+            #pragma unroll
+            for (int k0 = 0; k0 < R; k0 += 4) {               // four factors (32 scalar registers) at a time
+                glimb::W4 wc[4];
+                #pragma unroll
+                for (int j = 0; j < 4 && k0 + j < R; j++) wc[j] = w4_at(P.twu4, U * R + k0 + j);
+                __builtin_amdgcn_sched_barrier(0);
+                #pragma unroll
+                for (int j = 0; j < 4 && k0 + j < R; j++, o += sw) *o = glimb::mul_fold_co<false>(v[k0 + j], wc[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }

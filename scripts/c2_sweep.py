@@ -16,7 +16,12 @@ P = (1 << 64) - (1 << 32) + 1
 pl = Planner(0)
 rng = np.random.default_rng(1)
 out = {"group_bytes": os.environ.get("MS_NTT_GROUP_BYTES", "default"), "streams": os.environ.get("MS_NTT_STREAMS", "1")}
-for log_n, ncol in ((20, 32), (22, 16), (24, 8)):
+SHAPES = ((17, 64), (18, 64), (19, 64), (20, 32), (21, 32), (22, 16), (23, 16), (24, 8)) if "--all" in sys.argv else ((20, 32), (22, 16), (24, 8))
+INVERSE = "--inverse" in sys.argv
+if INVERSE:
+    from ministark_amd import GpuIfft as GpuFft  # noqa: E402,F811
+    out["direction"] = "inverse"
+for log_n, ncol in SHAPES:
     n = 1 << log_n
     cols = [GpuVec.from_numpy(pl, rng.integers(0, P, size=n, dtype=np.uint64), FP) for _ in range(ncol)]
     plan = GpuFft(Radix2EvaluationDomain(n, 7), FP, pl)

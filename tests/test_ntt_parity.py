@@ -53,7 +53,9 @@ def test_multipass_forward_emu(log_n):
 
 
 @pytest.mark.parametrize("log_n,inverse,offset", [(12, False, 7), (12, True, 1), (12, True, 7), (16, True, 7),
-                                                   (17, False, 7), (18, True, 7), (20, False, 7)])
+                                                   (17, False, 7), (18, True, 7), (20, False, 7),
+                                                   # (256, R, 256) plans, R = 2..16: the register-resident middle pass
+                                                   (17, True, 1), (19, False, 7), (19, True, 7), (19, False, 1), (20, True, 7), (20, True, 1)])
 def test_multipass_variants_emu(log_n, inverse, offset):
     _run("emu", GOLDILOCKS_FP, log_n, inverse, offset)
 
@@ -133,7 +135,8 @@ def test_uniform_interpass_factor_lde_emu(log_b):
         _lde("emu", GOLDILOCKS_FP, 22 - log_b, log_b, ncols=2, bit_reversed=False)
 
 
-@pytest.mark.parametrize("log_n,inverse,offset", [(5, False, 7), (11, True, 7), (12, False, 1), (13, True, 7), (17, False, 7)])
+@pytest.mark.parametrize("log_n,inverse,offset", [(5, False, 7), (11, True, 7), (12, False, 1), (13, True, 7), (17, False, 7),
+                                                   (18, True, 7), (19, False, 1), (20, False, 7)])
 def test_fq3_emu(log_n, inverse, offset):
     _run("emu", GOLDILOCKS_FQ3, log_n, inverse, offset, ncols=2)
 
