@@ -205,7 +205,9 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         if (extra == 2 && rest >= 12 && rest <= 16) { p->lr[1] = 8; p->lr[2] = rest - 8; }
         // 2^17..2^20 points: (256, R, 256) with R = 2..16 -- the middle pass holds its whole network in registers
         // (ntt2_small_mid_pass) and both outer passes are the limb-form radix-256 kernels with the uniform inter-pass factor
-        if (rest >= 9 && rest <= 12) { p->npass = 3; p->lr[1] = rest - 8; p->lr[2] = 8; }
+        // 2^21..2^23: (256, 16 T2, 256) -- the middle pass is ntt2_mid_pass_r; the last pass is then always the limb-form radix-256
+        // kernel (incl. the scale of an inverse coset transform and the fused bit-reversed store)
+        if (rest >= 9 && rest <= 15) { p->npass = 3; p->lr[1] = rest - 8; p->lr[2] = 8; }
         unsigned acc = 0;
         for (int q = 0; q < p->npass; q++) { p->log_s[q] = acc; acc += p->lr[q]; }
         // digit fields.  pass 1 maps j' = (j2..jm) [jm least significant] to layout (jm..j2) [j2 least]
@@ -260,7 +262,7 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
     size_t off_wr4[4] = {0, 0, 0, 0}, off_twu4[4] = {0, 0, 0, 0}, off_sc4 = 0, off_gp = 0, off_tin4 = 0, off_tout4 = 0;
     bool has_wr4[4] = {false, false, false, false}, has_twu4[4] = {false, false, false, false}, has_gp = false, has_scu4 = false;
     size_t off_scu4 = 0;
-    p->uni = !p->small && p->npass == 3 && (p->lr[1] == 8 || (p->lr[1] <= 4 && p->lr[2] == 8)) && p->lr[2] >= 6 && (n * V) % msntt2::TILE == 0;
+    p->uni = !p->small && p->npass == 3 && (p->lr[1] == 8 || p->lr[2] == 8) && p->lr[2] >= 6 && (n * V) % msntt2::TILE == 0;
     if (!p->small) {
         const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
         auto append4 = [&](const std::vector<uint64_t>& plain) {
@@ -270,9 +272,16 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             return off;
         };
         for (int q = 0; q < p->npass; q++) {
-            const bool small_mid = p->uni && q == 1 && p->lr[q] <= 4;      // ntt2_small_mid_pass: [U][k2], k2 < R
+            const bool small_mid = p->uni && q == 1 && p->lr[q] < 8;       // ntt2_small_mid_pass / ntt2_mid_pass_r: [U][k2], k2 < R
             if (p->lr[q] != 8 && !small_mid) continue;
             if (!small_mid) { powers(t, 256, gl::pow(w, (uint64_t)n >> 8)); off_wr4[q] = append4(t); has_wr4[q] = true; }
+            else if (p->lr[q] > 4) {                                       // ntt2_mid_pass_r: rt4[b][a'] = w_R^(a' b), R = 16 T2, b < T2
+                const unsigned T2 = 1u << (p->lr[q] - 4);
+                const uint64_t wR = gl::pow(w, (uint64_t)n >> p->lr[q]);
+                t.resize((size_t)T2 * 16);
+                for (unsigned b = 0; b < T2; b++) for (unsigned a = 0; a < 16; a++) t[b * 16 + a] = gl::pow(wR, (uint64_t)a * b);
+                off_wr4[q] = append4(t); has_wr4[q] = true;
+            }
             if (q >= 1 && q < p->npass - 1) {
                 // w_U^k = w_n^((rev(U) k) << log_s): the factor ntt_mid_pass builds per tile in LDS (twl[])
                 const size_t R = (size_t)1 << p->lr[q];
@@ -574,7 +583,7 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
             // (the per-element scale walk of an inverse coset transform stays with the round-1 last pass: the walk is two table
             // loads and a Montgomery product per word, which the 4-wave limb kernel hides worse -- 91 vs 75 us per 2^24
             // column; so does the fused bit-reversed store of Fq3 columns, whose runs interleave three words)
-            const bool small_mid = p->uni && q == 1 && p->lr[q] <= 4;
+            const bool small_mid = p->uni && q == 1 && p->lr[q] < 8;
             const bool v2_ok = small_mid || (p->lr[q] == 8 && (n * p->V) % msntt2::TILE == 0 &&
                                (q == 0 ? ((n >> 8) * p->V) % msntt2::TW == 0
                                        : (pass_sw % msntt2::TW == 0 && !(last && p->scale_mode == 2 && p->d_scu4 == nullptr) &&
@@ -617,7 +626,16 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
                                            else hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, LOGR, false>), g2, b2, 0, st, Q); } \
                          else { if (perm) hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, LOGR, true>), g2, b2, 0, st, Q); \
                                 else hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, LOGR, false>), g2, b2, 0, st, Q); } } while (0)
-                    switch (p->lr[q]) { case 1: MS_SM(1); break; case 2: MS_SM(2); break; case 3: MS_SM(3); break; default: MS_SM(4); break; }
+#define MS_MR(LOGT2) do { if (p->inverse) { if (perm) hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, LOGT2, true>), g2, b2, 0, st, Q); \
+                                            else hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, LOGT2, false>), g2, b2, 0, st, Q); } \
+                          else { if (perm) hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, LOGT2, true>), g2, b2, 0, st, Q); \
+                                 else hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, LOGT2, false>), g2, b2, 0, st, Q); } } while (0)
+                    Q.tin4 = p->d_wr4[q];       // ntt2_mid_pass_r: the factor between its networks (unused by the small pass)
+                    switch (p->lr[q]) {
+                    case 1: MS_SM(1); break; case 2: MS_SM(2); break; case 3: MS_SM(3); break; case 4: MS_SM(4); break;
+                    case 5: MS_MR(1); break; case 6: MS_MR(2); break; default: MS_MR(3); break;
+                    }
+#undef MS_MR
 #undef MS_SM
                 } else if (!last) {
                     if (perm) {             // ... and reads pass 1's permuted rows, writes the natural order (in place)

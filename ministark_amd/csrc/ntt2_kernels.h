@@ -391,6 +391,100 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
     }
 }
 
+// ---- middle pass of a three-pass plan (256, R, 256) with R = 16 T2, T2 = 2, 4, 8 (columns of 2^21..2^23 points) ------------
+// Rows of sw = 256 V words, a block U = R rows, row j2 = a T2 + b.  A workgroup takes 16 / T2 runs of 64 words; a slot
+// (wave, h) = (run s, b) holds the 16 rows a of its b in registers: first network over a (ntt2_mid_pass's, with LOADQ's
+// per-lane factor on the loads), times w_R^(a' b) (wave-uniform, table rt4[b][a']), exchange through LDS in which every word
+// stays in its lane and slot (s, c) collects the outputs a' = c mod T2 of all b, radix-T2 networks over b, times the
+// wave-uniform w_U^k2 (twu4[U][k2], k2 = a' + 16 b') on the stores.  PERM as in ntt2_mid_pass (in place).
+template <bool INV, int LOGT2, bool PERM>
+__global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
+    constexpr int T2 = 1 << LOGT2, R = 16 * T2, NM = 8 / T2;  // NM networks of radix T2 per slot and round
+    static_assert(LOGT2 >= 1 && LOGT2 <= 3, "R = 32, 64 or 128");
+    __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [slot][a' - 8 round][lane]
+    const uint64_t* __restrict__ src = P.src[blockIdx.y];
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t sw = ((size_t)1 << P.log_s) * P.V;
+    const unsigned runs_per_u = (unsigned)(sw / TW);
+    const unsigned pl = PERM ? ((lane >> 5) & 1) * 32 + ((lane >> 3) & 1) * 16 + (lane & 7) * 2 + ((lane >> 4) & 1) : lane;
+
+    uint64_t x[2][16];
+    uint64_t qlo[2], qhi[2];
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {                            // the factors' table words first (see ntt2_mid_pass)
+        const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2;
+        const unsigned U = g / runs_per_u, q = g % runs_per_u;
+        const unsigned k1 = (q * TW + lane) / P.V;
+        const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
+        qlo[h] = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+        qhi[h] = P.tw_hi[e >> P.lo_bits];
+    }
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2, b = (w + 8 * h) % T2;
+        const unsigned U = g / runs_per_u, q = g % runs_per_u;
+        const uint64_t* p = src + (size_t)U * R * sw + (size_t)b * sw + (size_t)q * TW + pl;
+        #pragma unroll
+        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += T2 * sw; }
+    }
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const unsigned b = (w + 8 * h) % T2;
+        const uint64_t qm = gld::mmul(qlo[h], qhi[h]);
+        const glimb::Q3 qpl = glimb::q3_from(gld::mmul(qm, 1), gld::mmul(qm, (uint64_t)1 << 24), gld::mmul(qm, (uint64_t)1 << 48));
+        net1<INV, 16, 2, true>(x[h], P, 0, qpl, b * 16);      // the factor after the network: tin4 = rt4, slot 16 b + a'
+        #pragma unroll
+        for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    #pragma unroll
+    for (int r = 0; r < 2; r++) {
+        __syncthreads();
+        uint64_t y[2][NM][T2];
+        #pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned s = (w + 8 * h) / T2, c = (w + 8 * h) % T2;
+            #pragma unroll
+            for (int m = 0; m < NM; m++)
+                #pragma unroll
+                for (int b = 0; b < T2; b++) y[h][m][b] = xch[((s * T2 + b) * 8 + c + T2 * m) * TW + lane];
+        }
+        if (r == 0) {                                         // second half of the first networks' results (as ntt2_mid_pass)
+            __syncthreads();
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+                #pragma unroll
+                for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][8 + j];
+        }
+        #pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2, c = (w + 8 * h) % T2;
+            const unsigned U = g / runs_per_u, q = g % runs_per_u;
+            uint64_t* const o = dst + (size_t)U * R * sw + (size_t)q * TW + lane;
+            #pragma unroll
+            for (int m = 0; m < NM; m++) {
+                const unsigned ap = 8 * r + c + T2 * m;        // a'
+                glimb::L4 v[T2];
+                #pragma unroll
+                for (int b = 0; b < T2; b++) v[b] = glimb::from_u64(y[h][m][b]);
+                glimb::dft<T2, INV>(v);
+                #pragma unroll
+                for (int b0 = 0; b0 < T2; b0 += 4) {          // at most four factors (32 scalar registers) at a time
+                    glimb::W4 wc[4];
+                    #pragma unroll
+                    for (int j = 0; j < 4 && b0 + j < T2; j++) wc[j] = w4_at(P.twu4, U * R + ap + 16 * (b0 + j));
+                    __builtin_amdgcn_sched_barrier(0);
+                    #pragma unroll
+                    for (int j = 0; j < 4 && b0 + j < T2; j++) o[(size_t)(ap + 16 * (b0 + j)) * sw] = glimb::mul_fold_co<false>(v[b0 + j], wc[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+}
+
 // ---- last pass with the bit-reversed store fused (the LDE's forward transform, Fp columns) -----------------------
 // Same tile and arithmetic as ntt2_mid_pass<false, true, 0>; the output X[k], k = k3 2^log_s + low, goes to position
 // rev(low) 256 + rev8(k3): for every word of the tile a run of 256 consecutive words.  A round of the exchange yields

@@ -64,7 +64,10 @@ def test_multipass_variants_emu(log_n, inverse, offset):
 # pass 2 applies the per-lane remainder on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
 @pytest.mark.parametrize("field,log_n,inverse,offset", [(GOLDILOCKS_FP, 22, False, 7), (GOLDILOCKS_FP, 22, True, 1),
                                                         (GOLDILOCKS_FP, 22, False, 1), (GOLDILOCKS_FP, 22, True, 7),
-                                                        (GOLDILOCKS_FQ3, 22, False, 7)])
+                                                        (GOLDILOCKS_FQ3, 22, False, 7),
+                                                        # (256, 32, 256) and (256, 128, 256): ntt2_mid_pass_r with T2 = 2, 8
+                                                        (GOLDILOCKS_FP, 21, False, 7), (GOLDILOCKS_FP, 21, True, 7), (GOLDILOCKS_FP, 23, True, 7),
+                                                        (GOLDILOCKS_FP, 23, False, 1), (GOLDILOCKS_FQ3, 21, True, 1)])
 def test_uniform_interpass_factor_emu(field, log_n, inverse, offset):
     _run("emu", field, log_n, inverse, offset)
 
