@@ -112,6 +112,28 @@ def test_large_sizes_random_hip(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log_n", range(17, 24))
+@pytest.mark.parametrize("seed", range(2))
+def test_mid_sizes_random_hip(log_n, seed):
+    # every (256, R, 256) plan, R = 2 .. 128 (ntt2_small_mid_pass, ntt2_mid_pass_r): random field, direction, offset, column count
+    rng = np.random.default_rng(3000 + 16 * log_n + seed)
+    field = GOLDILOCKS_FQ3 if rng.integers(0, 3) == 0 else GOLDILOCKS_FP
+    offset = int([1, 7, int(rng.integers(2, cref.GL_P, dtype=np.uint64))][int(rng.integers(0, 3))])
+    _run("hip", field, log_n, bool(rng.integers(0, 2)), offset, ncols=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_dom", range(17, 22))
+def test_mid_lde_random_hip(log_dom):
+    # LDE domains of 2^17 .. 2^21 points that do not take the two-pass LDE (Fq3 columns, or fewer than 2^17 rows): pruned first
+    # networks + the fused bit-reversed store over the (256, R, 256) plans
+    rng = np.random.default_rng(4000 + log_dom)
+    log_b = int(rng.integers(1, 5))
+    for field in (GOLDILOCKS_FP, GOLDILOCKS_FQ3):
+        _lde("hip", field, log_dom - log_b, log_b, ncols=int(rng.integers(1, 3)), bit_reversed=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_large_lde_random_hip(seed):
     # LDE domains of 2^22 .. 2^24 points: random field, blow-up (pruned first networks), output order, column count
@@ -341,6 +363,13 @@ def _lde(kind, field, log_n, log_b, ncols=2, bit_reversed=True):
 @pytest.mark.parametrize("log_n,log_b", [(4, 1), (8, 3), (9, 3), (10, 4), (12, 1), (13, 3), (12, 3), (14, 3), (10, 2), (11, 4), (12, 0)])
 def test_lde_emu(log_n, log_b):
     _lde("emu", GOLDILOCKS_FP, log_n, log_b)
+
+
+@pytest.mark.parametrize("field,log_n,log_b,bit_reversed", [(GOLDILOCKS_FP, 15, 2, True), (GOLDILOCKS_FP, 16, 3, True), (GOLDILOCKS_FP, 16, 4, False),
+                                                            (GOLDILOCKS_FP, 16, 5, True), (GOLDILOCKS_FQ3, 17, 2, True), (GOLDILOCKS_FQ3, 16, 1, False)])
+def test_lde_over_register_resident_middle_pass_emu(field, log_n, log_b, bit_reversed):
+    # LDE domains of 2^17 .. 2^21 points outside the two-pass LDE: pruned first network, (256, R, 256) plan, fused bit reversal
+    _lde("emu", field, log_n, log_b, ncols=1, bit_reversed=bit_reversed)
 
 
 @pytest.mark.parametrize("offset", [1, 7])
