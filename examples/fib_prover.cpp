@@ -6,15 +6,18 @@
 //     ProofOptions::new(32, 4, 8, 8, 64)  :227              (32 queries, blow-up 4, 8 grinding bits, FRI fold 8, remainder <= 64)
 //     default_prove           src/prover.rs:25-174
 // The Fiat-Shamir channel is replaced by a fixed pseudo-random stream (it hashes a few digests on the host);
-// everything that touches column data runs on the device.  Self-checks: the composition polynomial of a valid
-// trace has degree < n (its upper 3n coefficients over the 4n-point LDE coset must vanish), the opened rows
-// hash back to the committed roots' leaves.
+// everything that touches column data runs on the device.  The composition constraint is AirConfig::composition_constraint's
+// (src/air.rs:50-82: degree adjustment X^adj alpha + beta per constraint; ce_blowup_factor = 1 for this AIR), evaluated on the
+// constraint-evaluation coset = the first n rows of the committed bit-reversed LDE; FRI ends with set_remainder and the layer
+// openings of into_proof.  Self-check (rows <= 2^18): over the whole 4n-point LDE coset the composition polynomial of a valid
+// trace has degree < n -- its upper 3n coefficients must vanish.
 //   build: g++ -O2 -std=c++17 examples/fib_prover.cpp ministark_amd/libministark_hip.so -Wl,-rpath,$PWD/ministark_amd -o fib_prover
 //   run:   ./fib_prover [log2(rows) = 21] [repetitions = 3]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include "../ministark_amd/csrc/host/ministark.hpp"
 #include "../ministark_amd/csrc/host/stages.hpp"
 #include "../ministark_amd/csrc/host/expr.hpp"
@@ -74,14 +77,16 @@ int main(int argc, char** argv) {
                    next(4) - next(2) * next(3), next(5) - next(3) * next(4), next(6) - next(4) * next(5), next(7) - next(5) * next(6)};
         for (auto& t : tr) constraints.push_back(t * zer);
     }
-    E composition = constraints[0] * Challenge(0);
-    for (unsigned k = 1; k < constraints.size(); k++) composition = composition + constraints[k] * Challenge(k);
-    Program prog = compile_expr(composition, 8, false);
+    const Composition comp = composition_constraint(n, constraints);                                                       // src/air.rs:50-82
+    const unsigned ce = comp.ce_blowup_factor;
+    const size_t n_ce = n * ce;
+    Program prog = compile_expr(comp.expr, 8, false);
     uint64_t seed = 0x6d696e69;
-    std::vector<uint64_t> challenges(constraints.size());
+    std::vector<uint64_t> challenges(comp.num_coeffs);
     for (auto& c : challenges) c = gl::to_mont(splitmix(seed));
     const std::vector<uint64_t> hints{claimed};
-    printf("composition constraint: %zu constraints -> %zu instructions, %u registers\n", constraints.size(), prog.instrs.size(), prog.max_p);
+    Radix2EvaluationDomain ce_dom(n_ce, 7);
+    printf("composition constraint: %zu constraints, ce_blowup_factor %u -> %zu instructions, %u registers\n", constraints.size(), ce, prog.instrs.size(), prog.max_p);
 
     bool checked = false;
     for (int rep = 0; rep < reps + 1; rep++) {                // rep 0 warms plans / the specialised kernel up
@@ -93,28 +98,32 @@ int main(int argc, char** argv) {
         MerkleTree base_tree = MerkleTree::from_matrix(base_lde);
         auto base_root = base_tree.root();
         ph[0] = ms_since(t); t = Clock::now();
-        // 2. constraint evaluation over the LDE coset, straight on the committed bit-reversed layout (the reference
-        //    re-orders all columns into natural order and back: bit_reverse_ce_trace)          prover.rs:88-107
+        // 2. constraint evaluation on the constraint-evaluation coset: the first n_ce rows of the committed bit-reversed LDE are
+        //    that coset in its own bit-reversed order, so the evaluator works on them where they lie (the reference re-orders
+        //    all columns into natural order and back: bit_reverse_ce_trace)                    prover.rs:88-107
         std::vector<const GpuVec<Fp>*> bc;
         for (auto& c : base_lde.columns) bc.push_back(&c);
-        GpuVec<Fp> comp_evals = eval<Fp>(prog, pl, challenges, hints, 1u << log_blowup, 7, N, bc, {}, true);
+        if (!checked && log_rows <= 18) {                     // a valid trace gives a composition polynomial of degree < n
+            Matrix<Fp> full;
+            full.columns.push_back(eval<Fp>(prog, pl, challenges, hints, 1u << log_blowup, 7, N, bc, {}, true));
+            full.bit_reverse_rows();
+            full.into_polynomials(lde_dom);
+            auto coeffs = full.columns[0].to_host();
+            for (size_t i = n_ce; i < N; i++) if (coeffs[i] != 0) { printf("FAILED: composition coefficient %zu is not zero\n", i); return 1; }
+            bool any = false;
+            for (size_t i = 0; i < n_ce; i++) any |= coeffs[i] != 0;
+            if (!any) { printf("FAILED: composition polynomial is identically zero\n"); return 1; }
+            checked = true;
+            t = Clock::now();
+        }
+        GpuVec<Fp> comp_evals = eval<Fp>(prog, pl, challenges, hints, ce, 7, n_ce, bc, {}, true);
         ph[1] = ms_since(t); t = Clock::now();
-        // 3. composition trace: coefficients, LDE, commit                            prover.rs:110-124
+        // 3. composition trace: coefficients, split into ce columns, LDE, commit     prover.rs:110-124
         Matrix<Fp> cm;
         cm.columns.push_back(std::move(comp_evals));
         cm.bit_reverse_rows();                                // one column back to natural order for the inverse transform
-        cm.into_polynomials(lde_dom);
-        if (!checked && log_rows <= 18) {                     // a valid trace gives a composition polynomial of degree < n
-            auto coeffs = cm.columns[0].to_host();
-            for (size_t i = n; i < N; i++) if (coeffs[i] != 0) { printf("FAILED: composition coefficient %zu is not zero\n", i); return 1; }
-            bool any = false;
-            for (size_t i = 0; i < n; i++) any |= coeffs[i] != 0;
-            if (!any) { printf("FAILED: composition polynomial is identically zero\n"); return 1; }
-            checked = true;
-        }
-        Matrix<Fp> comp_polys;                                 // ce_blowup_factor = 1: one column of n coefficients
-        comp_polys.columns.emplace_back(pl, n);
-        check(ms_copy(pl.ctx(), comp_polys.columns[0].ptr(), cm.columns[0].ptr(), n * 8));
+        cm.into_polynomials(ce_dom);
+        Matrix<Fp> comp_polys = Matrix<Fp>::from_chunks(cm.columns[0], ce);
         Matrix<Fp> comp_lde = comp_polys.bit_reversed_evaluate(lde_dom);
         MerkleTree comp_tree = MerkleTree::from_matrix(comp_lde);
         auto comp_root = comp_tree.root();
@@ -127,39 +136,58 @@ int main(int argc, char** argv) {
         auto ood = composer.get_ood_evals();
         DeepCompositionCoeffs dc;
         for (size_t k = 0; k < args.size(); k++) dc.execution_trace.push_back({{splitmix(seed), 0, 0}});
-        dc.composition_trace.push_back({{splitmix(seed), 0, 0}});
+        for (unsigned k = 0; k < ce; k++) dc.composition_trace.push_back({{splitmix(seed), 0, 0}});
         dc.degree[0] = {{splitmix(seed), 0, 0}}; dc.degree[1] = {{splitmix(seed), 0, 0}};
         Matrix<Fp> deep;
         deep.columns.push_back(composer.into_deep_poly(dc));
         Matrix<Fp> deep_lde = deep.bit_reversed_evaluate(lde_dom);
         ph[3] = ms_since(t); t = Clock::now();
-        // 5. FRI layers                                                              fri.rs:179-249
+        // 5. FRI layers + remainder                                                  fri.rs:179-249
+        std::vector<GpuVec<Fp>> layers;                       // FriLayer { merkle_tree, evaluations } (fri.rs:218-221)
+        std::vector<MerkleTree> trees;
         GpuVec<Fp> layer = std::move(deep_lde.columns[0]);
         std::array<uint8_t, 32> last_root = comp_root;
-        unsigned nlayers = 0;
         while (layer.len() > (size_t)max_remainder << log_blowup) {
-            MerkleTree lt = MerkleTree::from_fri_layer(layer, fold);
-            last_root = lt.root();
+            trees.push_back(MerkleTree::from_fri_layer(layer, fold));
+            last_root = trees.back().root();
             const std::vector<uint64_t> alpha{gl::to_mont(splitmix(seed))};
-            layer = apply_drp(layer, alpha, fold, 1);
-            nlayers++;
+            GpuVec<Fp> next_layer = apply_drp(layer, alpha, fold, 1);
+            layers.push_back(std::move(layer));
+            layer = std::move(next_layer);
         }
-        pl.sync();
+        // set_remainder (fri.rs:232-248): bit_reverse, iNTT over the subgroup of the remainder's size, the first len / blowup coefficients
+        Matrix<Fp> rem;
+        rem.columns.push_back(layer.clone());
+        rem.bit_reverse_rows();
+        rem.into_polynomials(Radix2EvaluationDomain(layer.len()));
+        auto remainder = rem.columns[0].to_host();
+        if (log_rows <= 18)                                   // fri.rs:244: a valid trace leaves nothing above len / blowup
+            for (size_t i = layer.len() >> log_blowup; i < remainder.size(); i++) if (remainder[i] != 0) { printf("FAILED: FRI remainder coefficient %zu is not zero\n", i); return 1; }
+        remainder.resize(std::max<size_t>(layer.len() >> log_blowup, 1));
         ph[4] = ms_since(t); t = Clock::now();
-        // 6. proof of work, queries                                                  prover.rs:160-173
+        // 6. proof of work, queries, FRI openings                                    prover.rs:160-173
         const uint64_t nonce = grind_proof_of_work(pl, last_root, grinding_bits);
         std::vector<size_t> positions(num_queries);
         for (auto& p : positions) p = (size_t)(splitmix(seed) % N);
         Queries<Fp> q(base_lde, nullptr, comp_lde, base_tree, nullptr, comp_tree, positions);
+        std::set<size_t> uniq(positions.begin(), positions.end());
+        std::vector<size_t> pos(uniq.begin(), uniq.end());
+        size_t opened = 0;
+        for (size_t l = 0; l < layers.size(); l++) {          // fri_prover.into_proof(&query_positions): fri.rs:148-165
+            pos = fold_positions(pos, fold);
+            auto rows = fri_layer_rows(layers[l], fold, pos);
+            auto view = trees[l].prove(pos);
+            opened += rows.size() / fold + view.nodes.size();
+        }
         ph[5] = ms_since(t);
         ph[6] = ms_since(all);
-        if (q.base_trace_values.size() != positions.size() * 8 || ood.first.size() != args.size()) { printf("FAILED: query / OOD shapes\n"); return 1; }
+        if (q.base_trace_values.size() != positions.size() * 8 || ood.first.size() != args.size() || opened == 0) { printf("FAILED: query / OOD shapes\n"); return 1; }
         if (rep == 0) {
-            printf("roots: base %02x%02x%02x%02x.. composition %02x%02x%02x%02x..  FRI layers %u  remainder %zu  nonce %llu\n", base_root[0], base_root[1], base_root[2],
-                   base_root[3], comp_root[0], comp_root[1], comp_root[2], comp_root[3], nlayers, layer.len(), (unsigned long long)nonce);
+            printf("roots: base %02x%02x%02x%02x.. composition %02x%02x%02x%02x..  FRI layers %zu  remainder %zu coefficients  nonce %llu\n", base_root[0], base_root[1], base_root[2],
+                   base_root[3], comp_root[0], comp_root[1], comp_root[2], comp_root[3], layers.size(), remainder.size(), (unsigned long long)nonce);
             continue;
         }
-        printf("rep %d: base LDE+commit %.2f | evaluation %.2f | composition %.2f | DEEP %.2f | FRI %.2f | PoW+queries %.2f | total %.2f ms\n", rep, ph[0], ph[1], ph[2],
+        printf("rep %d: base LDE+commit %.2f | evaluation %.2f | composition %.2f | DEEP %.2f | FRI %.2f | PoW+queries+openings %.2f | total %.2f ms\n", rep, ph[0], ph[1], ph[2],
                ph[3], ph[4], ph[5], ph[6]);
     }
     printf("fib prover pipeline ok\n");

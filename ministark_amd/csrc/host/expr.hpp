@@ -175,6 +175,51 @@ inline Program compile_expr(const E& root_expr, unsigned num_base_columns, bool 
     return prog;
 }
 
+// `Constraint::degree` (src/constraints.rs:32-41, 152-158, 407-455): an upper bound (numerator, denominator) on the degree in X,
+// with the reference's own (loose) arithmetic.
+inline std::pair<size_t, size_t> degree(const E& e, size_t trace_degree) {
+    switch (e->kind) {
+    case K_CONST_P: case K_CONST_Q: case K_CHALLENGE: case K_HINT: return {0, 0};
+    case K_TRACE: return {trace_degree, 0};
+    case K_X: return {1, 0};
+    case K_PERIODIC: return {(e->coeffs.size() - 1) * ((trace_degree + 1) / e->idx), 0};      // PeriodicColumn::degree (:135-141)
+    case K_NEG: return degree(e->a, trace_degree);
+    case K_POW: { auto d = degree(e->a, trace_degree); return {d.first * e->idx, d.second * e->idx}; }
+    default: break;
+    }
+    const auto a = degree(e->a, trace_degree), b = degree(e->b, trace_degree);
+    if (e->kind == K_ADD) return {std::max(a.first + b.second, b.first + a.second), a.second + b.second};
+    if (e->kind == K_MUL) return {a.first + b.first, a.second + b.second};
+    return {a.first + b.second, a.second + b.first};                                           // K_DIV
+}
+inline size_t ceil_power_of_two(size_t v) {                                                    // src/utils.rs:76-82
+    if (v == 0) return 1;
+    if ((v & (v - 1)) == 0) return v;
+    size_t r = 1; while (r <= v) r <<= 1; return r;
+}
+// `Constraint::blowup_factor` (src/constraints.rs:162-166, 340-347) -- note the division by trace_len - 1
+inline size_t constraint_blowup_factor(const E& c, size_t trace_len) {
+    const auto d = degree(c, trace_len - 1);
+    return ceil_power_of_two(d.first > d.second ? d.first - d.second : 0) / (trace_len - 1);
+}
+// `AirConfig::composition_constraint` (src/air.rs:50-82): sum_i c_i (X^adj_i alpha_i + beta_i) with
+// adj_i = (trace_len ce_blowup - 1) - (deg num_i - deg den_i); CompositionCoeff(i) = (Challenge(2 i), Challenge(2 i + 1)).
+struct Composition { E expr; unsigned ce_blowup_factor; unsigned num_coeffs; };
+inline Composition composition_constraint(size_t trace_len, const std::vector<E>& constraints) {
+    size_t ce = 0;
+    for (auto& c : constraints) ce = std::max(ce, constraint_blowup_factor(c, trace_len));
+    const size_t composition_degree = trace_len * ce - 1;
+    E comp;
+    for (size_t i = 0; i < constraints.size(); i++) {
+        const auto d = degree(constraints[i], trace_len - 1);
+        const size_t ev = d.first > d.second ? d.first - d.second : 0;
+        if (ev > composition_degree) throw std::invalid_argument("constraint degree exceeds the composition degree");
+        E term = constraints[i] * (pow(X(), (uint32_t)(composition_degree - ev)) * Challenge((uint32_t)(2 * i)) + Challenge((uint32_t)(2 * i + 1)));
+        comp = comp ? comp + term : term;
+    }
+    return {comp, (unsigned)ce, (unsigned)(2 * constraints.size())};
+}
+
 // eval_periodic_column (src/eval_cpu.rs:233-256): evaluations of the column's polynomial on
 // coset(interval_size * blowup, offset^(trace_len / interval_size))
 inline GpuVec<Fp> periodic_lde(Planner& pl, const std::vector<uint64_t>& coeffs, uint32_t interval, uint64_t domain_offset, size_t trace_len, unsigned lde_step) {

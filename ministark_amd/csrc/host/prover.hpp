@@ -55,6 +55,37 @@ inline GpuVec<F> scan_affine(const GpuVec<F>* a, const GpuVec<F>* b, const std::
 }
 template <class F> inline GpuVec<F> running_product(const GpuVec<F>& factors, const std::vector<uint64_t>& init) { return scan_affine<F>(&factors, nullptr, init); }
 
+// `fold_positions` (src/fri.rs:615-622): strictly increasing positions -> their cosets, deduplicated
+inline std::vector<size_t> fold_positions(const std::vector<size_t>& positions, unsigned folding_factor) {
+    std::vector<size_t> out;
+    for (size_t p : positions) if (out.empty() || out.back() != p / folding_factor) out.push_back(p / folding_factor);
+    return out;
+}
+// rows `positions` of Matrix::from_arrays(evaluations.as_chunks::<N>()) (src/fri.rs:213-215): N consecutive evaluations each,
+// gathered on the device as 32-byte records (FriProver::into_proof, src/fri.rs:148-165)
+template <class F>
+inline std::vector<uint64_t> fri_layer_rows(const GpuVec<F>& layer, unsigned folding_factor, const std::vector<size_t>& positions) {
+    const size_t words = (size_t)folding_factor * F::words;
+    std::vector<uint64_t> out(positions.size() * words);
+    if (out.empty()) return out;
+    Planner& pl = layer.planner();
+    if (words % 4) {                                       // rows shorter than a record: tiny layers only
+        const auto all = layer.to_host();
+        for (size_t i = 0; i < positions.size(); i++) memcpy(&out[i * words], &all[positions[i] * words], words * 8);
+        return out;
+    }
+    const size_t per = words / 4;
+    std::vector<uint64_t> ids;
+    for (size_t p : positions) for (size_t k = 0; k < per; k++) ids.push_back(p * per + k);
+    void* d = nullptr;
+    check(ms_alloc(pl.ctx(), out.size() * 8, &d));
+    int rc = ms_gather_digests(pl.ctx(), layer.len() * F::words / 4, layer.ptr(), ids.data(), ids.size(), d);
+    if (rc == MS_OK) rc = ms_download(pl.ctx(), out.data(), d, out.size() * 8);
+    ms_free(pl.ctx(), d);
+    check(rc);
+    return out;
+}
+
 // Queries::new: rows of the three LDE matrices at the query positions + batched openings of the three trees
 template <class FqT>
 struct Queries {

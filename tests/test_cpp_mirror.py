@@ -51,6 +51,22 @@ def test_fib_prover_example_compiles():
     assert os.path.exists(_build_example())
 
 
+def test_fib_prover_example_under_the_simulator():
+    # the same program linked against the simulator build of the library (tests/emu): the valid 2^12-row trace must give a
+    # composition polynomial of degree < n over the whole LDE coset and a FRI remainder without high coefficients (fri.rs:244)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    so = build_emu.build()
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "fib_prover_emu")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", EXAMPLE, "-o", exe, so, "-Wl,-rpath," + os.path.dirname(so)])
+    for log_rows in ("10", "12"):
+        out = subprocess.run([exe, log_rows, "1"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "fib prover pipeline ok" in out.stdout, out.stdout + out.stderr
+        assert "ce_blowup_factor 1 -> 197 instructions" in out.stdout, out.stdout       # the same program as pipeline.fib_constraints
+
+
 @pytest.mark.gpu
 def test_fib_prover_example_on_gpu():
     # examples/fib on the device end to end: 2^14 rows here (the composition polynomial of the valid trace must have
