@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_sha -o sha --output-format csv -- python scripts/bench_commit.py 23 32 1 > $OUT/pmc_sha.log 2>&1
 python scripts/bench_configs.py > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
 [ -x scripts/ubench8 ] && ./scripts/ubench8 > $OUT/ubench8.txt 2>&1
-python scripts/c2_sweep.py > $OUT/c2_sweep.json 2>/dev/null
+python scripts/c2_sweep.py --all > $OUT/c2_sweep.json 2>/dev/null; python scripts/c2_sweep.py --all --inverse >> $OUT/c2_sweep.json 2>/dev/null
 NCOLS=32 ./scripts/sq_probe.sh lde python scripts/lde_probe.py > /dev/null 2>&1; cp $R/gpurun_out/sq_lde.txt $OUT/lde_sq_counters.txt
 python bench.py --mode lde-commit --steps 3 --warmup 1 > $OUT/bench_lde_commit_n1.json 2>/dev/null
 python scripts/bench_commit.py 23 32 3 > $OUT/bench_commit.json 2>&1
