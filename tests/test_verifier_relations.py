@@ -1,0 +1,139 @@
+"""The two algebraic relations the reference's VERIFIER checks on a proof, evaluated here with big-int arithmetic on the output of
+the device pipeline run on a VALID trace (the reference's own fib example, examples/fib/main.rs:175-224):
+
+  1. out-of-domain consistency (src/verifier.rs:82-95, 205-236): the composition constraint, evaluated at X = z on the execution
+     trace's out-of-domain evaluations, equals  sum_k z^k H_k(z^ce)  from the composition trace's out-of-domain evaluations;
+  2. DEEP composition at the query positions (src/verifier.rs:162-171, 238-300): recomputed from the OPENED rows of the base /
+     composition LDEs and the out-of-domain evaluations, it equals the first FRI layer at those positions;
+  plus fri.rs:244: the remainder polynomial of a valid trace has no coefficient above len / blowup.
+
+None of this goes through oracle/c: it pins interpolation, LDE, the fused constraint evaluator, the composition split, the Horner
+OOD evaluation, the DEEP quotients, the bit-reversed query layout and the FRI folds to the mathematics they implement -- an
+invalid step anywhere breaks an identity that holds for every z (Schwartz-Zippel).  `emu`: 2^10 rows on the simulator; `hip`: 2^16.
+"""
+import numpy as np
+import pytest
+
+from tests import backends
+from ministark_amd import GOLDILOCKS_FP as FP, Matrix, Radix2EvaluationDomain, pipeline
+from ministark_amd.api import GL_P as P, gl_from_mont, gl_to_mont
+
+BACKENDS = [pytest.param("emu", 10, id="emu"), pytest.param("hip", 16, id="hip", marks=pytest.mark.gpu)]
+
+
+def fib_trace(n):
+    """gen_trace (examples/fib/main.rs:175-224): 8 columns, each row continues the multiplicative Fibonacci sequence."""
+    cols = [[0] * n for _ in range(8)]
+    v = [1, 2]
+    for k in range(2, 8):
+        v.append(v[k - 2] * v[k - 1] % P)
+    for r in range(n):
+        for k in range(8):
+            cols[k][r] = v[k]
+        w = [v[6] * v[7] % P]
+        w.append(v[7] * w[0] % P)
+        for k in range(2, 8):
+            w.append(w[k - 2] * w[k - 1] % P)
+        v = w
+    return cols
+
+
+def eval_at(expr, x, trace_at, challenges, hints):
+    """`ood_constraint_evaluation` (src/verifier.rs:205-236) for an Fq = Fp AIR without periodic columns: the expression DAG at one
+    point, Trace(c, o) taken from the out-of-domain evaluation map.  x / y = x y^-1 (no zero divisor occurs off the domain)."""
+    memo = {}
+
+    def ev(e):
+        if id(e) in memo:
+            return memo[id(e)]
+        k, a = e.kind, e.args
+        if k == "x":
+            r = x
+        elif k == "const":
+            r = a[1] % P
+        elif k == "challenge":
+            r = challenges[a[0]]
+        elif k == "hint":
+            r = hints[a[0]]
+        elif k == "trace":
+            r = trace_at[(a[0], a[1])]
+        elif k == "neg":
+            r = -ev(a[0]) % P
+        elif k == "add":
+            r = (ev(a[0]) + ev(a[1])) % P
+        elif k == "mul":
+            r = ev(a[0]) * ev(a[1]) % P
+        elif k == "div":
+            r = ev(a[0]) * pow(ev(a[1]), -1, P) % P
+        elif k == "pow":
+            r = pow(ev(a[0]), a[1], P)
+        else:
+            raise ValueError(k)
+        memo[id(e)] = r
+        return r
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    return ev(expr)
+
+
+def _prove(kind, log_t, seed=77):
+    pl = backends.planner(kind)
+    n, blowup, folding = 1 << log_t, 4, 8
+    cols = fib_trace(n)
+    trace = Matrix.from_numpy(pl, [np.array([gl_to_mont(v) for v in c], dtype=np.uint64) for c in cols], FP)
+    comp, ce, nch = pipeline.fib_constraints(n, 8)
+    draws = pipeline.Draws(seed, 8, nch, ce, 32, n * blowup, pipeline.fri_num_layers(n * blowup, blowup, folding, 64))
+    draws.hints = [cols[7][n - 1]]                                   # FibClaim: the last value of the sequence
+    out = pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, keep=True, ce_blowup=ce)
+    return n, blowup, comp, ce, draws, out
+
+
+@pytest.mark.parametrize("kind,log_t", BACKENDS)
+def test_out_of_domain_constraint_evaluation_matches_the_composition_trace(kind, log_t):
+    n, blowup, comp, ce, draws, out = _prove(kind, log_t)
+    execution, composition = ([int(v) for v in out["ood"][0]], [int(v) for v in out["ood"][1]])
+    trace_at = dict(zip(draws.trace_args, execution))                 # trace_ood_eval_map (src/verifier.rs:77-81)
+    calculated = eval_at(comp, draws.z, trace_at, draws.challenges, draws.hints)
+    provided = sum(h * pow(draws.z, k, P) for k, h in enumerate(composition)) % P          # horner_evaluate(ood evals, z), :91
+    assert calculated == provided
+    # ... and the identity is not vacuous: with a wrong claim it fails
+    assert eval_at(comp, draws.z, trace_at, draws.challenges, [(draws.hints[0] + 1) % P]) != provided
+
+
+@pytest.mark.parametrize("kind,log_t", BACKENDS)
+def test_deep_composition_at_the_query_positions_matches_the_first_fri_layer(kind, log_t):
+    n, blowup, comp, ce, draws, out = _prove(kind, log_t, seed=78)
+    N = n * blowup
+    log_N = N.bit_length() - 1
+    dom_t, dom_l = Radix2EvaluationDomain(n), Radix2EvaluationDomain(N, 7)
+    g = dom_t.group_gen
+    execution, composition = ([int(v) for v in out["ood"][0]], [int(v) for v in out["ood"][1]])
+    z, z_n = draws.z, pow(draws.z, ce, P)
+    q = out["queries"]
+    layer0 = out["deep_lde"].columns[0].to_numpy()                    # the first FRI layer: bit-reversed evaluations of the DEEP polynomial
+    alpha_d, beta_d = draws.deep.degree
+    for i, pos in enumerate(draws.positions):
+        rev = int(format(pos, f"0{log_N}b")[::-1], 2)
+        x = 7 * pow(dom_l.group_gen, rev, P) % P                      # lde_domain.element(bit_reverse_index(N, pos)), :253-256
+        acc = 0
+        for j, ((col, off), ood) in enumerate(zip(draws.trace_args, execution)):
+            value = gl_from_mont(int(q.base_trace_values[i][col]))
+            shift = pow(g, off, P) if off >= 0 else pow(g, -off * (n - 1), P)
+            acc += draws.deep.execution_trace[j] * (value - ood) * pow((x - z * shift) % P, -1, P)
+        for j, ood in enumerate(composition):
+            value = gl_from_mont(int(q.composition_trace_values[i][j]))
+            acc += draws.deep.composition_trace[j] * (value - ood) * pow((x - z_n) % P, -1, P)
+        expect = acc % P * ((alpha_d + beta_d * x) % P) % P
+        assert gl_from_mont(int(layer0[pos])) == expect, f"query {i} at position {pos}"
+
+
+@pytest.mark.parametrize("kind,log_t", BACKENDS)
+def test_fri_remainder_of_a_valid_trace_has_low_degree(kind, log_t):
+    n, blowup, comp, ce, draws, out = _prove(kind, log_t, seed=79)
+    rem = out["remainder"].to_numpy()
+    from ministark_amd import GpuVec
+    pl = backends.planner(kind)
+    m = len(rem)
+    coeffs = Matrix([GpuVec.from_numpy(pl, rem.copy(), FP)]).bit_reverse_rows().into_polynomials(Radix2EvaluationDomain(m)).columns[0].to_numpy()
+    assert not coeffs[m // blowup:].any() and coeffs[: m // blowup].any()                    # fri.rs:244
+    assert np.array_equal(out["remainder_coeffs"], coeffs[: m // blowup])
