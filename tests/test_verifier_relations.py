@@ -137,3 +137,130 @@ def test_fri_remainder_of_a_valid_trace_has_low_degree(kind, log_t):
     coeffs = Matrix([GpuVec.from_numpy(pl, rem.copy(), FP)]).bit_reverse_rows().into_polynomials(Radix2EvaluationDomain(m)).columns[0].to_numpy()
     assert not coeffs[m // blowup:].any() and coeffs[: m // blowup].any()                    # fri.rs:244
     assert np.array_equal(out["remainder_coeffs"], coeffs[: m // blowup])
+
+
+# ---- an AIR with an extension column (Fq = the cubic extension): permutation argument by running product --------------------
+# base columns a, b = a shifted by one row, c = a a b; extension column p, p_0 = 1, p_(i+1) = p_i (alpha - a_i) / (alpha - b_i)
+# (b is a cyclic shift of a, so the product closes: every transition holds on ALL rows, wrap-around included).  Constraints:
+#   (b - next(a)) / (X^n - 1),  (c - a a b) / (X^n - 1)  [degree 3: ce_blowup_factor 2, two composition columns],
+#   (next(p) (alpha - b) - p (alpha - a)) / (X^n - 1)  [Fq],  (p - 1) / (X - 1).
+def _ext_air(n, alpha_index):
+    from ministark_amd import expr as E
+    x = E.X()
+    a, b, c, p = (lambda o=0: E.Trace(0, o)), (lambda o=0: E.Trace(1, o)), (lambda o=0: E.Trace(2, o)), (lambda o=0: E.Trace(3, o))
+    alpha = E.Challenge(alpha_index)
+    zer = x ** n - E.Constant(1)
+    return [(b() - a(1)) / zer, (c() - a() * a() * b()) / zer, (p(1) * (alpha - b()) - p() * (alpha - a())) / zer,
+            (p() - E.Constant(1)) / (x - E.Constant(1))]
+
+
+def _q_eval_at(expr, x, trace_at, challenges):
+    """ood_constraint_evaluation (src/verifier.rs:205-236) over the cubic extension: every value a 3-tuple."""
+    from oracle.pyref.fields import FQ3 as Q
+    memo = {}
+
+    def ev(e):
+        if id(e) in memo:
+            return memo[id(e)]
+        k, a = e.kind, e.args
+        if k == "x":
+            r = x
+        elif k == "const":
+            r = Q.embed(a[1] % P)
+        elif k == "challenge":
+            r = challenges[a[0]]
+        elif k == "trace":
+            r = trace_at[(a[0], a[1])]
+        elif k == "neg":
+            r = Q.neg(ev(a[0]))
+        elif k == "add":
+            r = Q.add(ev(a[0]), ev(a[1]))
+        elif k == "mul":
+            r = Q.mul(ev(a[0]), ev(a[1]))
+        elif k == "div":
+            r = Q.mul(ev(a[0]), Q.inv(ev(a[1])))
+        elif k == "pow":
+            r = Q.pow(ev(a[0]), a[1])
+        else:
+            raise ValueError(k)
+        memo[id(e)] = r
+        return r
+    return ev(expr)
+
+
+@pytest.mark.parametrize("kind,log_t", [pytest.param("emu", 8, id="emu"), pytest.param("hip", 14, id="hip", marks=pytest.mark.gpu)])
+def test_verifier_relations_with_an_extension_column(kind, log_t):
+    from oracle.pyref.fields import FQ3 as Q
+    from ministark_amd import GOLDILOCKS_FQ3 as FQ, GpuVec, MerkleTree, Queries, expr as E
+    from ministark_amd.composer import DeepCompositionCoeffs, DeepPolyComposer
+    pl = backends.planner(kind)
+    n, blowup = 1 << log_t, 4
+    N = n * blowup
+    rng = np.random.default_rng(500 + log_t)
+    rq = lambda: tuple(int(v) for v in rng.integers(1, P, size=3, dtype=np.uint64))
+    # ---- the valid trace
+    a = [int(v) for v in rng.integers(1, P, size=n, dtype=np.uint64)]
+    b = a[1:] + a[:1]
+    c = [x * x % P * y % P for x, y in zip(a, b)]
+    ncons = 4
+    alpha = rq()                                                     # the AIR's own challenge: index after the 2 * 4 composition coefficients
+    p, cur = [], Q.one()
+    for ai, bi in zip(a, b):
+        p.append(cur)
+        cur = Q.mul(cur, Q.mul(Q.sub(alpha, Q.embed(ai)), Q.inv(Q.sub(alpha, Q.embed(bi)))))
+    assert cur == Q.one()
+    constraints = _ext_air(n, 2 * ncons)
+    comp, ce, ncoef = pipeline.composition_constraint(n, constraints)
+    assert ce == 2 and ncoef == 2 * ncons
+    challenges = [rq() for _ in range(ncoef)] + [alpha]
+    mont = lambda vals: np.array([gl_to_mont(v) for v in vals], dtype=np.uint64)
+    qwords = lambda vals: np.array([gl_to_mont(w) for v in vals for w in v], dtype=np.uint64)
+    base = Matrix.from_numpy(pl, [mont(a), mont(b), mont(c)], FP)
+    ext = Matrix.from_numpy(pl, [qwords(p)], FQ)
+    trace_dom, lde_dom, ce_dom = Radix2EvaluationDomain(n), Radix2EvaluationDomain(N, 7), Radix2EvaluationDomain(n * ce, 7)
+    # ---- default_prove's data-parallel chain with an extension trace (src/prover.rs:50-173)
+    base_polys, ext_polys = base.interpolate(trace_dom), ext.interpolate(trace_dom)
+    base_lde, ext_lde = base_polys.bit_reversed_evaluate(lde_dom), ext_polys.bit_reversed_evaluate(lde_dom)
+    base_tree, ext_tree = MerkleTree.from_matrix(base_lde), MerkleTree.from_matrix(ext_lde)
+    prog = E.compile_expr(comp, 3, True)
+    ch = qwords(challenges).reshape(-1, 3)
+    evals = E.eval(prog, pl, ch, np.zeros((0, 3), dtype=np.uint64), ce, 7, n * ce, base_lde.columns, ext_lde.columns, bit_reversed=True)
+    comp_poly = Matrix([evals]).bit_reverse_rows().into_polynomials(ce_dom).columns[0]
+    comp_polys = Matrix.from_chunks(comp_poly, ce)
+    comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)
+    comp_tree = MerkleTree.from_matrix(comp_lde)
+    args = sorted({(0, 0), (0, 1), (1, 0), (2, 0), (3, 0), (3, 1)})
+    z = rq()
+    composer = DeepPolyComposer(args, n, z, base_polys, ext_polys, comp_polys)
+    execution, composition = composer.get_ood_evals()
+    coeffs = DeepCompositionCoeffs([rq() for _ in args], [rq() for _ in range(ce)], (rq(), rq()))
+    deep_lde = Matrix([composer.into_deep_poly(coeffs)]).into_bit_reversed_evaluations(lde_dom).columns[0].to_numpy().reshape(-1, 3)
+    positions = [int(v) for v in rng.integers(0, N, size=32)]
+    q = Queries(base_lde, ext_lde, comp_lde, base_tree, ext_tree, comp_tree, positions)
+    # ---- 1. out-of-domain consistency (src/verifier.rs:82-95)
+    execution = [tuple(int(w) for w in v) for v in execution]
+    composition = [tuple(int(w) for w in v) for v in composition]
+    trace_at = dict(zip(args, execution))
+    calculated = _q_eval_at(comp, z, trace_at, challenges)
+    provided, zk = Q.zero(), Q.one()
+    for h in composition:
+        provided, zk = Q.add(provided, Q.mul(h, zk)), Q.mul(zk, z)
+    assert calculated == provided
+    # ---- 2. DEEP composition at the query positions (src/verifier.rs:238-300)
+    g = trace_dom.group_gen
+    z_n = Q.pow(z, ce)
+    from_words = lambda row, k: tuple(gl_from_mont(int(w)) for w in row[3 * k: 3 * k + 3])
+    log_N = N.bit_length() - 1
+    for i, pos in enumerate(positions):
+        xv = 7 * pow(lde_dom.group_gen, int(format(pos, f"0{log_N}b")[::-1], 2), P) % P
+        x = Q.embed(xv)
+        acc = Q.zero()
+        for j, ((col, off), ood) in enumerate(zip(args, execution)):
+            value = Q.embed(gl_from_mont(int(q.base_trace_values[i][col]))) if col < 3 else from_words(q.extension_trace_values[i], col - 3)
+            shift = pow(g, off, P)
+            acc = Q.add(acc, Q.mul(Q.mul(coeffs.execution_trace[j], Q.sub(value, ood)), Q.inv(Q.sub(x, Q.mul_base(z, shift)))))
+        for j, ood in enumerate(composition):
+            value = from_words(q.composition_trace_values[i], j)
+            acc = Q.add(acc, Q.mul(Q.mul(coeffs.composition_trace[j], Q.sub(value, ood)), Q.inv(Q.sub(x, z_n))))
+        expect = Q.mul(acc, Q.add(coeffs.degree[0], Q.mul_base(coeffs.degree[1], xv)))
+        assert tuple(gl_from_mont(int(w)) for w in deep_lde[pos]) == expect, f"query {i} at position {pos}"
