@@ -264,3 +264,57 @@ def test_verifier_relations_with_an_extension_column(kind, log_t):
             acc = Q.add(acc, Q.mul(Q.mul(coeffs.composition_trace[j], Q.sub(value, ood)), Q.inv(Q.sub(x, z_n))))
         expect = Q.mul(acc, Q.add(coeffs.degree[0], Q.mul_base(coeffs.degree[1], xv)))
         assert tuple(gl_from_mont(int(w)) for w in deep_lde[pos]) == expect, f"query {i} at position {pos}"
+
+
+# ---- the fib AIR over the 252-bit field (src/eval_gpu.rs:1054-1082 runs the reference's evaluator there): Fq = Fp, 4-word elements ----
+@pytest.mark.parametrize("kind,log_t", [pytest.param("emu", 7, id="emu"), pytest.param("hip", 12, id="hip", marks=pytest.mark.gpu)])
+def test_verifier_relations_over_the_252_bit_field(kind, log_t):
+    from ministark_amd import STARK252_FP as F, MerkleTree, Queries, expr as E
+    from ministark_amd.api import F252_P as p, f252_from_mont_limbs, f252_to_mont_limbs
+    from ministark_amd.composer import DeepCompositionCoeffs, DeepPolyComposer
+    global P
+    pl = backends.planner(kind)
+    n, blowup = 1 << log_t, 4
+    N = n * blowup
+    rng = np.random.default_rng(252 + log_t)
+    r = lambda: int.from_bytes(rng.bytes(40), "little") % (p - 1) + 1
+    saved, P = P, p                                                  # fib_trace / eval_at work modulo the module-level P
+    try:
+        cols = fib_trace(n)
+        limbs = lambda vals: np.concatenate([f252_to_mont_limbs(v) for v in vals]).astype(np.uint64)
+        value = lambda words: f252_from_mont_limbs(np.asarray(words, dtype=np.uint64))
+        trace = Matrix.from_numpy(pl, [limbs(c) for c in cols], F)
+        comp, ce, nch = pipeline.fib_constraints(n, 8, F)
+        assert ce == 1
+        challenges, hints = [r() for _ in range(nch)], [cols[7][n - 1]]
+        trace_dom, lde_dom, ce_dom = Radix2EvaluationDomain(n, 1, F), Radix2EvaluationDomain(N, 3, F), Radix2EvaluationDomain(n * ce, 3, F)
+        base_polys = trace.interpolate(trace_dom)
+        base_lde = base_polys.bit_reversed_evaluate(lde_dom)
+        base_tree = MerkleTree.from_matrix(base_lde)
+        prog = E.compile_expr(comp, 8, False, F)
+        evals = E.eval(prog, pl, limbs(challenges).reshape(-1, 4), limbs(hints).reshape(-1, 4), ce, 3, n * ce, base_lde.columns, bit_reversed=True)
+        comp_polys = Matrix([Matrix([evals]).bit_reverse_rows().into_polynomials(ce_dom).columns[0]])
+        comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)
+        comp_tree = MerkleTree.from_matrix(comp_lde)
+        args = [(c, o) for c in range(8) for o in (0, 1)]
+        z = r()
+        composer = DeepPolyComposer(args, n, z, base_polys, None, comp_polys)
+        execution, composition = composer.get_ood_evals()
+        execution, composition = [int(v) for v in execution], [int(v) for v in composition]
+        coeffs = DeepCompositionCoeffs([r() for _ in args], [r()], (r(), r()))
+        deep_lde = Matrix([composer.into_deep_poly(coeffs)]).into_bit_reversed_evaluations(lde_dom).columns[0].to_numpy().reshape(-1, 4)
+        positions = [int(v) for v in rng.integers(0, N, size=16)]
+        q = Queries(base_lde, None, comp_lde, base_tree, None, comp_tree, positions)
+        # 1. out-of-domain consistency
+        assert eval_at(comp, z, dict(zip(args, execution)), challenges, hints) == composition[0]
+        # 2. DEEP composition at the query positions
+        g, log_N = trace_dom.group_gen, N.bit_length() - 1
+        for i, pos in enumerate(positions):
+            x = 3 * pow(lde_dom.group_gen, int(format(pos, f"0{log_N}b")[::-1], 2), p) % p
+            acc = 0
+            for j, ((col, off), ood) in enumerate(zip(args, execution)):
+                acc += coeffs.execution_trace[j] * (value(q.base_trace_values[i][4 * col: 4 * col + 4]) - ood) * pow((x - z * pow(g, off, p)) % p, -1, p)
+            acc += coeffs.composition_trace[0] * (value(q.composition_trace_values[i][:4]) - composition[0]) * pow((x - z) % p, -1, p)
+            assert value(deep_lde[pos]) == acc % p * ((coeffs.degree[0] + coeffs.degree[1] * x) % p) % p, f"query {i} at position {pos}"
+    finally:
+        P = saved
