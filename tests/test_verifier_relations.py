@@ -5,9 +5,12 @@ the device pipeline run on a VALID trace (the reference's own fib example, examp
      trace's out-of-domain evaluations, equals  sum_k z^k H_k(z^ce)  from the composition trace's out-of-domain evaluations;
   2. DEEP composition at the query positions (src/verifier.rs:162-171, 238-300): recomputed from the OPENED rows of the base /
      composition LDEs and the out-of-domain evaluations, it equals the first FRI layer at those positions;
-  plus fri.rs:244: the remainder polynomial of a valid trace has no coefficient above len / blowup.
+  3. fri.rs:244: the remainder polynomial of a valid trace has no coefficient above len / blowup;
+  4. FriVerifier::verify_generic + verify_remainder (src/fri.rs:346-490) on the FRI layer openings;
+  5. verify_rows (src/merkle.rs:208-293): opened rows -> leaves (hashlib) -> committed roots.
+Together these are `verify` (src/verifier.rs:28-196) minus the channel.  The same for an AIR with an Fq3 column and over the 252-bit field.
 
-None of this goes through oracle/c: it pins interpolation, LDE, the fused constraint evaluator, the composition split, the Horner
+None of this goes through oracle/c (5 uses oracle/pyref's restatement of MerkleTreeImpl::verify over hashlib): it pins interpolation, LDE, the fused constraint evaluator, the composition split, the Horner
 OOD evaluation, the DEEP quotients, the bit-reversed query layout and the FRI folds to the mathematics they implement -- an
 invalid step anywhere breaks an identity that holds for every z (Schwartz-Zippel).  `emu`: 2^10 rows on the simulator; `hip`: 2^16.
 """
@@ -318,3 +321,60 @@ def test_verifier_relations_over_the_252_bit_field(kind, log_t):
             assert value(deep_lde[pos]) == acc % p * ((coeffs.degree[0] + coeffs.degree[1] * x) % p) % p, f"query {i} at position {pos}"
     finally:
         P = saved
+
+
+# ---- FriVerifier::verify_generic (src/fri.rs:346-440) + verify_remainder (:456-490) on the layer openings of a valid trace ----
+@pytest.mark.parametrize("kind,log_t", BACKENDS)
+def test_fri_layer_openings_fold_into_each_other_and_into_the_remainder(kind, log_t):
+    n, blowup, comp, ce, draws, out = _prove(kind, log_t, seed=80)
+    N, folding = n * blowup, 8
+    rev = lambda v, bits: int(format(v, f"0{bits}b")[::-1], 2) if bits else 0
+    gen = Radix2EvaluationDomain(N).group_gen                          # the FRI domain is taken without its offset (fri.rs:227: F::FftField::ONE)
+    w8 = Radix2EvaluationDomain(folding).group_gen                     # folding_domain
+    layer0 = out["deep_lde"].columns[0].to_numpy()
+    positions = sorted(set(draws.positions))
+    evaluations = [gl_from_mont(int(layer0[p])) for p in positions]    # what relation 2 hands to the FRI verifier
+    size = N
+    assert len(out["fri_openings"]) == len(draws.fri_alphas) >= 1
+    for opening, alpha in zip(out["fri_openings"], draws.fri_alphas):
+        folded = pipeline.fold_positions(positions, folding)
+        assert opening["positions"] == folded
+        rows = [[gl_from_mont(int(w)) for w in row] for row in opening["rows"]]
+        # get_query_values: the queried evaluation sits at column position % N of its coset's row
+        assert [rows[folded.index(p // folding)][p % folding] for p in positions] == evaluations
+        nxt = []
+        for row, fp in zip(rows, folded):
+            offset = pow(gen, rev(fp, (size // folding).bit_length() - 1), P)
+            vals = [row[rev(k, 3)] for k in range(folding)]            # bit_reverse(&mut chunk)
+            # domain.ifft over the coset offset <w8>, coefficients times N (fri.rs:404-409): c_j = sum_k v_k (offset w8^k)^-j
+            coeffs = [sum(v * pow(offset * pow(w8, k, P) % P, -j, P) for k, v in enumerate(vals)) % P for j in range(folding)]
+            nxt.append(sum(c * pow(alpha, j, P) for j, c in enumerate(coeffs)) % P)
+        evaluations, positions, gen, size = nxt, folded, pow(gen, folding, P), size // folding
+    rem = [gl_from_mont(int(w)) for w in out["remainder_coeffs"]]
+    assert len(rem) == max(size // blowup, 1)                          # degree <= domain_size / blowup - 1
+    for p, want in zip(positions, evaluations):
+        x = pow(gen, rev(p, size.bit_length() - 1), P)
+        assert sum(c * pow(x, j, P) for j, c in enumerate(rem)) % P == want
+
+
+# ---- verify_rows (src/merkle.rs:208-293, 329-349): the opened rows hash (hashlib) to the opening's leaves, which lead to the committed root ----
+@pytest.mark.parametrize("kind,log_t", BACKENDS)
+def test_opened_rows_verify_against_the_committed_roots(kind, log_t):
+    import hashlib
+    from oracle.pyref import merkle as omerkle                         # MerkleTreeImpl::verify restated over hashlib
+    n, blowup, comp, ce, draws, out = _prove(kind, log_t, seed=81)
+    q = out["queries"]
+    uniq = sorted(set(draws.positions))
+    first = {p: draws.positions.index(p) for p in uniq}
+    row_bytes = lambda row: b"".join(gl_from_mont(int(w)).to_bytes(8, "little") for w in row)       # canonical little-endian elements
+    for rows, proof, root in ((q.base_trace_values, q.base_trace_proof, out["base_root"]),
+                              (q.composition_trace_values, q.composition_trace_proof, out["composition_root"])):
+        assert [hashlib.sha256(row_bytes(rows[first[p]])).digest() for p in uniq] == list(proof["initial_leaves"])
+        assert omerkle.verify(root, proof, uniq)
+    positions = uniq
+    for opening, root in zip(out["fri_openings"], out["fri_roots"]):
+        positions = pipeline.fold_positions(positions, 8)
+        assert [hashlib.sha256(row_bytes(r)).digest() for r in opening["rows"]] == list(opening["proof"]["initial_leaves"])
+        assert omerkle.verify(root, opening["proof"], positions)
+        bad = dict(opening["proof"], initial_leaves=[bytes(32)] + list(opening["proof"]["initial_leaves"])[1:])
+        assert not omerkle.verify(root, bad, positions)
