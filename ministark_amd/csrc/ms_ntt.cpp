@@ -200,14 +200,11 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         p->npass = 1 + extra;
         p->lr[0] = 8;
         for (int i = 0; i < extra; i++) p->lr[1 + i] = rest / extra + ((unsigned)i < rest % extra ? 1 : 0);
-        // three passes: prefer (8, 8, rest - 8) to an even split whenever the last radix is still >= 16 -- two of the
-        // three passes are then limb-form radix-256 passes (ntt2_kernels.h), e.g. 2^20 = 256 * 256 * 16 instead of 256 * 64 * 64
-        if (extra == 2 && rest >= 12 && rest <= 16) { p->lr[1] = 8; p->lr[2] = rest - 8; }
-        // 2^17..2^20 points: (256, R, 256) with R = 2..16 -- the middle pass holds its whole network in registers
-        // (ntt2_small_mid_pass) and both outer passes are the limb-form radix-256 kernels with the uniform inter-pass factor
-        // 2^21..2^23: (256, 16 T2, 256) -- the middle pass is ntt2_mid_pass_r; the last pass is then always the limb-form radix-256
-        // kernel (incl. the scale of an inverse coset transform and the fused bit-reversed store)
-        if (rest >= 9 && rest <= 15) { p->npass = 3; p->lr[1] = rest - 8; p->lr[2] = 8; }
+        // three passes (2^17..2^24): (256, R, 256) with R = n / 2^16 -- both outer passes are the limb-form radix-256 kernels with
+        // the uniform inter-pass factor (ntt2_kernels.h), so the last pass always has its limb-form variants (scale of an inverse
+        // coset transform, fused bit-reversed store); the small radix sits in the middle: R <= 16 holds its whole network in
+        // registers (ntt2_small_mid_pass), R = 32..128 is ntt2_mid_pass_r, R = 256 ntt2_mid_pass
+        if (rest >= 9 && rest <= 16) { p->npass = 3; p->lr[1] = rest - 8; p->lr[2] = 8; }
         unsigned acc = 0;
         for (int q = 0; q < p->npass; q++) { p->log_s[q] = acc; acc += p->lr[q]; }
         // digit fields.  pass 1 maps j' = (j2..jm) [jm least significant] to layout (jm..j2) [j2 least]
