@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libministark_hip.so")
 SOURCES = ["ms_core.cpp", "ms_ntt.cpp", "ms_stage.cpp", "ms_hash.cpp", "ms_eval.cpp", "ms_deep.cpp", "ms_comm.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function"]
 OBJDIR = os.path.join(HERE, "_obj")
 
 

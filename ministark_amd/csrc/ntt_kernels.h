@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(NT, INV ? MS_NTT_WAVES - 1 : MS_NTT_WAVES) ntt
 // (src/matrix.rs:352-354) fused into the transform: the tile is transposed through LDS so that
 // each wave still writes runs of R consecutive elements.
 template <int RB, bool INV, bool LAST, int SCALE, bool BITREV = false>
-__global__ void __launch_bounds__(NT, SCALE == 2 ? 5 : MS_NTT_WAVES) ntt_mid_pass(PassParams P) {   // SCALE 2 carries a table walk per output
+__global__ void __launch_bounds__(NT, BITREV ? 4 : SCALE == 2 ? 5 : MS_NTT_WAVES) ntt_mid_pass(PassParams P) {   // SCALE 2 carries a table walk per output; BITREV holds a whole tile in LDS
     constexpr int R = 16 * RB, T = 256 / RB, G = 16 / RB;
     constexpr int LOGR = (RB == 1) ? 4 : (RB == 2) ? 5 : (RB == 4) ? 6 : (RB == 8) ? 7 : 8;
     static_assert(!BITREV || LAST, "bit-reversed store only exists for the last pass");
