@@ -272,11 +272,8 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
             const bool small_mid = p->uni && q == 1 && p->lr[q] < 8;       // ntt2_small_mid_pass / ntt2_mid_pass_r: [U][k2], k2 < R
             if (p->lr[q] != 8 && !small_mid) continue;
             if (!small_mid) { powers(t, 256, gl::pow(w, (uint64_t)n >> 8)); off_wr4[q] = append4(t); has_wr4[q] = true; }
-            else if (p->lr[q] > 4) {                                       // ntt2_mid_pass_r: rt4[b][a'] = w_R^(a' b), R = 16 T2, b < T2
-                const unsigned T2 = 1u << (p->lr[q] - 4);
-                const uint64_t wR = gl::pow(w, (uint64_t)n >> p->lr[q]);
-                t.resize((size_t)T2 * 16);
-                for (unsigned b = 0; b < T2; b++) for (unsigned a = 0; a < 16; a++) t[b * 16 + a] = gl::pow(wR, (uint64_t)a * b);
+            else if (p->lr[q] > 4) {                                       // ntt2_mid_pass_r: w_R^e, e < R = 16 T2 (it needs e = a' b < 16 T2)
+                powers(t, (size_t)1 << p->lr[q], gl::pow(w, (uint64_t)n >> p->lr[q]));
                 off_wr4[q] = append4(t); has_wr4[q] = true;
             }
             if (q >= 1 && q < p->npass - 1) {
@@ -627,7 +624,6 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
                                             else hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, LOGT2, false>), g2, b2, 0, st, Q); } \
                           else { if (perm) hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, LOGT2, true>), g2, b2, 0, st, Q); \
                                  else hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, LOGT2, false>), g2, b2, 0, st, Q); } } while (0)
-                    Q.tin4 = p->d_wr4[q];       // ntt2_mid_pass_r: the factor between its networks (unused by the small pass)
                     switch (p->lr[q]) {
                     case 1: MS_SM(1); break; case 2: MS_SM(2); break; case 3: MS_SM(3); break; case 4: MS_SM(4); break;
                     case 5: MS_MR(1); break; case 6: MS_MR(2); break; default: MS_MR(3); break;

@@ -136,6 +136,21 @@ __device__ __forceinline__ void wave_lockstep() { __builtin_amdgcn_wave_barrier(
 inline void wave_lockstep() { __syncthreads(); }
 #endif
 
+// run index g of a middle pass (log_s = 8) -> block U of R rows and the run q of 64 words inside a row of 256 V words.  PERM kernels
+// are V = 1 (four runs per row): shifts; otherwise one uniform division by the run count 4 V
+template <bool PERM>
+__device__ __forceinline__ void run_of(unsigned g, unsigned runs_per_u, unsigned& U, unsigned& q) {
+    if constexpr (PERM) { U = g >> 2; q = g & 3; (void)runs_per_u; }
+    else { U = g / runs_per_u; q = g - U * runs_per_u; }
+}
+
+// hide a wave-uniform value's origin from the optimiser (so that what is derived from it is recomputed, not kept in registers)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void opaque(unsigned& v) { asm volatile("" : "+s"(v)); }
+#else
+MS_HD void opaque(unsigned&) {}
+#endif
+
 // three of the four copies of a table slot, for a product on the way into a network (wave-uniform: scalar registers)
 __device__ __forceinline__ glimb::Q3 q3_at(const uint64_t* t, unsigned slot) {
     const glimb::W4 w = w4_at(t, slot);
@@ -345,7 +360,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
     auto factor_words = [&](int c) {
         #pragma unroll
         for (int i = 0; i < CH; i++) {
-            const unsigned U = (g0 + c * CH + i) / runs_per_u, q = (g0 + c * CH + i) % runs_per_u;
+            unsigned U, q; run_of<PERM>(g0 + c * CH + i, runs_per_u, U, q);
             const unsigned k1 = (q * TW + lane) / P.V;
             const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
             qlo[i] = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
@@ -355,7 +370,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
     factor_words(0);
     #pragma unroll
     for (int i = 0; i < NNET; i++) {
-        const unsigned U = (g0 + i) / runs_per_u, q = (g0 + i) % runs_per_u;
+        unsigned U, q; run_of<PERM>(g0 + i, runs_per_u, U, q);
         const uint64_t* p = src + (size_t)U * R * sw + (size_t)q * TW + pl;
         #pragma unroll
         for (int a = 0; a < R; a++) { x[i][a] = *p; p += sw; }
@@ -370,7 +385,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
         #pragma unroll
         for (int ii = 0; ii < CH; ii++) {
             const int i = c * CH + ii;
-            const unsigned U = (g0 + i) / runs_per_u, q = (g0 + i) % runs_per_u;
+            unsigned U, q; run_of<PERM>(g0 + i, runs_per_u, U, q);
             const glimb::Q3 qpl = glimb::q3_from(gld::mmul(qm[ii], 1), gld::mmul(qm[ii], (uint64_t)1 << 24), gld::mmul(qm[ii], (uint64_t)1 << 48));
             glimb::L4 v[R];
             #pragma unroll
@@ -394,7 +409,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
 // ---- middle pass of a three-pass plan (256, R, 256) with R = 16 T2, T2 = 2, 4, 8 (columns of 2^21..2^23 points) ------------
 // Rows of sw = 256 V words, a block U = R rows, row j2 = a T2 + b.  A workgroup takes 16 / T2 runs of 64 words; a slot
 // (wave, h) = (run s, b) holds the 16 rows a of its b in registers: first network over a (ntt2_mid_pass's, with LOADQ's
-// per-lane factor on the loads), times w_R^(a' b) (wave-uniform, table rt4[b][a']), exchange through LDS in which every word
+// per-lane factor on the loads), times w_R^(a' b) (wave-uniform: wr4 holds the powers of w_R for this pass), exchange through LDS in which every word
 // stays in its lane and slot (s, c) collects the outputs a' = c mod T2 of all b, radix-T2 networks over b, times the
 // wave-uniform w_U^k2 (twu4[U][k2], k2 = a' + 16 b') on the stores.  PERM as in ntt2_mid_pass (in place).
 template <bool INV, int LOGT2, bool PERM>
@@ -405,7 +420,8 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
     uint64_t* __restrict__ dst = P.dst[blockIdx.y];
     const unsigned lane = threadIdx.x & 63;
-    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned w_in = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned w = w_in;
     const size_t sw = ((size_t)1 << P.log_s) * P.V;
     const unsigned runs_per_u = (unsigned)(sw / TW);
     const unsigned pl = PERM ? ((lane >> 5) & 1) * 32 + ((lane >> 3) & 1) * 16 + (lane & 7) * 2 + ((lane >> 4) & 1) : lane;
@@ -415,7 +431,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
     #pragma unroll
     for (int h = 0; h < 2; h++) {                            // the factors' table words first (see ntt2_mid_pass)
         const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2;
-        const unsigned U = g / runs_per_u, q = g % runs_per_u;
+        unsigned U, q; run_of<PERM>(g, runs_per_u, U, q);
         const unsigned k1 = (q * TW + lane) / P.V;
         const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
         qlo[h] = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
@@ -424,7 +440,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
     #pragma unroll
     for (int h = 0; h < 2; h++) {
         const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2, b = (w + 8 * h) % T2;
-        const unsigned U = g / runs_per_u, q = g % runs_per_u;
+        unsigned U, q; run_of<PERM>(g, runs_per_u, U, q);
         const uint64_t* p = src + (size_t)U * R * sw + (size_t)b * sw + (size_t)q * TW + pl;
         #pragma unroll
         for (int a = 0; a < 16; a++) { x[h][a] = *p; p += T2 * sw; }
@@ -434,7 +450,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
         const unsigned b = (w + 8 * h) % T2;
         const uint64_t qm = gld::mmul(qlo[h], qhi[h]);
         const glimb::Q3 qpl = glimb::q3_from(gld::mmul(qm, 1), gld::mmul(qm, (uint64_t)1 << 24), gld::mmul(qm, (uint64_t)1 << 48));
-        net1<INV, 16, 2, true>(x[h], P, 0, qpl, b * 16);      // the factor after the network: tin4 = rt4, slot 16 b + a'
+        net1<INV, 16, 2>(x[h], P, b, qpl);                    // the factor after the network: wr4 = w_R^e here, slot a' b < R
         #pragma unroll
         for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][j];
         __builtin_amdgcn_sched_barrier(0);
@@ -442,6 +458,10 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
     #pragma unroll
     for (int r = 0; r < 2; r++) {
         __syncthreads();
+        // (the slot's scalars are derived afresh in every round instead of being kept alive across the networks above, where
+        // 64 scalar registers hold twiddles: they would be spilled into vector lanes)
+        unsigned w = w_in;
+        opaque(w);
         uint64_t y[2][NM][T2];
         #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -461,7 +481,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
         #pragma unroll
         for (int h = 0; h < 2; h++) {
             const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2, c = (w + 8 * h) % T2;
-            const unsigned U = g / runs_per_u, q = g % runs_per_u;
+            unsigned U, q; run_of<PERM>(g, runs_per_u, U, q);
             uint64_t* const o = dst + (size_t)U * R * sw + (size_t)q * TW + lane;
             #pragma unroll
             for (int m = 0; m < NM; m++) {

@@ -52,12 +52,12 @@ def main():
     dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
     rows = [r + (d,) for r, d in zip(rows, dem)]
     rows.sort(key=lambda r: (-r[0], -r[1], r[3]))
-    print(f"# {len(rows)} kernels; columns: unit  vgpr  sgpr  vgpr-spills  scratch-bytes  lds-bytes | static VALU  global/buffer  scratch_*  ds_* instructions | kernel")
+    print(f"# {len(rows)} kernels; columns: unit  vgpr  sgpr  vgpr-spills  sgpr-spills  scratch-bytes  lds-bytes | static VALU  global/buffer  scratch_*  ds_* instructions | kernel")
     for scratch, vg, unit, name, m, valu, vmem, scr, lds, d in rows:
         d = d.split("(")[0].replace("void ", "")
-        print(f"{unit:13s} {vg:4d} {m.get('sgpr_count', 0):4d} {m.get('vgpr_spill_count', 0):5d} {scratch:6d} {m.get('group_segment_fixed_size', 0):7d} | {valu:6d} {vmem:5d} {scr:5d} {lds:5d} | {d}")
+        print(f"{unit:13s} {vg:4d} {m.get('sgpr_count', 0):4d} {m.get('vgpr_spill_count', 0):5d} {m.get('sgpr_spill_count', 0):5d} {scratch:6d} {m.get('group_segment_fixed_size', 0):7d} | {valu:6d} {vmem:5d} {scr:5d} {lds:5d} | {d}")
     spilled = [r for r in rows if r[0] > 0]
-    print(f"# kernels with scratch: {len(spilled)} of {len(rows)}")
+    print(f"# kernels with scratch: {len(spilled)} of {len(rows)}; with scalar registers spilled into vector lanes: {sum(1 for r in rows if r[4].get('sgpr_spill_count', 0))}")
 
 
 if __name__ == "__main__":
