@@ -425,6 +425,10 @@ class Matrix:
 
     def __init__(self, columns):
         self.columns = list(columns)
+        # Matrix::new (src/matrix.rs:32-38) asserts that every column has the length of the first; so do the kernels, which
+        # take one row count for the whole matrix
+        if any(len(c) != len(self.columns[0]) or c.field != self.columns[0].field for c in self.columns[1:]):
+            raise ValueError("all columns of a matrix must have the same length and field")
 
     @classmethod
     def from_numpy(cls, planner, cols, field=GOLDILOCKS_FP):
@@ -548,6 +552,8 @@ class Matrix:
         (src/prover.rs:50-51) in one call; returns a new Matrix, self is preserved."""
         L = self.planner.lib
         n = self.num_rows()
+        if n & (n - 1) or blowup < 1 or blowup & (blowup - 1):
+            raise ValueError("the number of rows and the blow-up factor must be powers of two")
         log_n, log_b = n.bit_length() - 1, blowup.bit_length() - 1
         outs = [GpuVec(self.planner, n * blowup, self.field) for _ in self.columns]
         off = _offset_words(self.field, offset)

@@ -121,7 +121,9 @@ public:
     std::vector<GpuVec<F>> columns;
     Matrix() = default;
     explicit Matrix(std::vector<GpuVec<F>>&& cols) : columns(std::move(cols)) {}
-    size_t num_rows() const { return columns.empty() ? 0 : columns[0].len(); }
+    // Matrix::new (src/matrix.rs:32-38): every column has the length of the first -- the kernels take ONE row count per matrix
+    void assert_rectangular() const { for (auto& c : columns) if (c.len() != columns[0].len()) throw std::invalid_argument("all columns of a matrix must have the same length"); }
+    size_t num_rows() const { assert_rectangular(); return columns.empty() ? 0 : columns[0].len(); }
     size_t num_cols() const { return columns.size(); }
     Planner& planner() const { return columns.at(0).planner(); }
     Matrix clone() const { Matrix m; for (auto& c : columns) m.columns.push_back(c.clone()); return m; }
