@@ -509,6 +509,8 @@ class Matrix:
         """`composition_poly.chunks(k)` spread over k columns (src/prover.rs:113-121): column c holds
         coefficients c, c + k, c + 2k, ... of `poly` (a GpuVec)."""
         pl = poly.planner
+        if k < 1 or len(poly) % k:
+            raise ValueError(f"{len(poly)} coefficients do not split into {k} columns")
         n_out = len(poly) // k
         outs = [GpuVec(pl, n_out, poly.field) for _ in range(k)]
         pl.lib.check(pl.lib.ms_deinterleave(pl.handle, poly.field, n_out, k, poly.ptr, _ptr_array(outs)))

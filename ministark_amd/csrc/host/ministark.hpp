@@ -157,6 +157,7 @@ public:
     Matrix bit_reversed_evaluate(const Radix2EvaluationDomain& d) const { return evaluate(d, true); }
     // composition_poly.chunks(k) spread over k columns (src/prover.rs:113-121)
     static Matrix from_chunks(const GpuVec<F>& poly, unsigned k) {
+        if (k == 0 || poly.len() % k) throw std::invalid_argument("the coefficients do not split into that many columns");
         Matrix out;
         for (unsigned c = 0; c < k; c++) out.columns.emplace_back(poly.planner(), poly.len() / k);
         auto o = out.ptrs();

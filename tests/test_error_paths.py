@@ -56,6 +56,8 @@ def test_matrix_shapes(pl):
     m = Matrix([_vec(pl), _vec(pl)])
     with pytest.raises(ValueError, match="powers of two"):
         m.lde(3)
+    with pytest.raises(ValueError, match="do not split into 3 columns"):
+        Matrix.from_chunks(_vec(pl), 3)
     with pytest.raises(MsError, match="row 99 out of range"):
         m.get_rows([99])
     with pytest.raises(IndexError, match="leaf index 16 out of bounds"):       # Error::LeafIndexOutOfBounds, src/merkle.rs:154-158
