@@ -142,7 +142,7 @@ struct ms_ntt_plan {
     uint64_t* d_wr4[4] = {nullptr, nullptr, nullptr, nullptr};    // radix-256 passes: w_256^e
     uint64_t* d_twu4[4] = {nullptr, nullptr, nullptr, nullptr};   // middle passes: per-tile factor [U][k]
     uint64_t *d_sc4 = nullptr, *d_g4 = nullptr, *d_scu4 = nullptr;
-    // three-pass plans with a last radix >= 64: pass 1's inter-pass factor from wave-uniform tables, the per-lane
+    // three-pass plans (last radix 256 since round 3): pass 1's inter-pass factor from wave-uniform tables, the per-lane
     // remainder applied by pass 2 on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
     bool uni = false;
     uint64_t *d_tin4 = nullptr, *d_tout4 = nullptr;

@@ -573,7 +573,7 @@ static __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) 
 // the low output digit a' = c3 + 8 r -- one second network per lane and round, every lane busy in both rounds.
 // A wave then stores 8 runs of 8 consecutive k1 at the digit-reversed position of its 8 words (the two rounds
 // fill the two halves of each 128-byte line), the layout ntt_first_pass writes.
-// UNI (three-pass plans whose last radix R3 is >= 64, so that a tile of 64 words has one j2 = j' / R3): the inter-pass
+// UNI (three-pass plans; their last radix R3 is 256 -- it has to be >= 64 so that a tile of 64 words has one j2 = j' / R3): the inter-pass
 // factor (h w_n^k1)^j', j' = R3 j2 + j3, k1 = a' + 16 b', is split into
 //     w_n^(a' R3 j2)            merged into the factor between the two networks (a' is a register index there),
 //     h^(R3 j2) w_n^(16 b' R3 j2)  after the second network (b' is the register index),
