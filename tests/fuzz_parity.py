@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run of the library against the C oracle (oracle/c) on the GPU:
     python tests/fuzz_parity.py [seconds] [seed]
-Random sizes (2^0 .. 2^18), fields, directions, coset offsets, blow-ups, folding factors, shifts and column
+Random sizes (2^0 .. 2^21: every plan family incl. the (256, R, 256) ones), fields, directions, coset offsets, blow-ups, folding factors, shifts and column
 counts; values are a mix of uniform elements and edge values (0, 1, p-1, 2^32-1, 2^32, p-2^32 ...).
 Complements tests/ (fixed shapes): any mismatch prints the failing case and exits non-zero."""
 import sys
@@ -40,7 +40,7 @@ def offset():
 
 
 def case_ntt():
-    log_n, V, inv, off = int(rng.integers(0, 19)), int(rng.choice([1, 3])), bool(rng.integers(0, 2)), offset()
+    log_n, V, inv, off = int(rng.integers(0, 22)), int(rng.choice([1, 3])), bool(rng.integers(0, 2)), offset()
     field = FQ3 if V == 3 else FP
     x = values((1 << log_n) * V)
     v = GpuVec.from_numpy(pl, x, field)
@@ -50,7 +50,7 @@ def case_ntt():
 
 
 def case_lde():
-    log_n, log_b, V, off, br = int(rng.integers(0, 15)), int(rng.integers(0, 6)), int(rng.choice([1, 3])), offset(), bool(rng.integers(0, 2))
+    log_n, log_b, V, off, br = int(rng.integers(0, 18)), int(rng.integers(0, 6)), int(rng.choice([1, 3])), offset(), bool(rng.integers(0, 2))
     field = FQ3 if V == 3 else FP
     cols = [values((1 << log_n) * V) for _ in range(int(rng.integers(1, 4)))]
     out = Matrix.from_numpy(pl, cols, field).lde(1 << log_b, off, br).to_numpy()
