@@ -28,7 +28,7 @@ __device__ __forceinline__ uint64_t fold_co(uint32_t a0, uint64_t H) {
     asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(c01) : "s"(cm));
     return (uint64_t)c01 * 0xFFFFFFFFull + z;
 }
-__device__ __forceinline__ uint64_t mul_fold_co(const L4& x, const W4& w) {
+__device__ __forceinline__ uint64_t mul_fold_co_probe(const L4& x, const W4& w) {
     uint64_t alo = (uint64_t)x.l[0] * w.lo[0];
     #pragma unroll
     for (int i = 1; i < 4; i++) alo += (uint64_t)x.l[i] * w.lo[i];
@@ -52,23 +52,7 @@ __device__ __forceinline__ uint64_t mul_fold_c128(const L4& x, const W4& w) {
     return (uint64_t)c * 0xFFFFFFFFull + z;
 }
 
-// u64 (any residue) times a factor given as three pre-shifted copies Q_i = q 2^(24 i): limbs out (|l| < 2^24 + small)
-struct Q3 { uint32_t lo[3], hi[3]; };
-__device__ __forceinline__ L4 mul3_to_limbs(uint64_t x, const Q3& q) {
-    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    const uint32_t l0 = lo & M24, l1 = perm(hi, lo, SEL_345), l2 = hi >> 16;
-    uint64_t alo = (uint64_t)l0 * q.lo[0] + (uint64_t)l1 * q.lo[1] + (uint64_t)l2 * q.lo[2];
-    uint64_t H = (uint64_t)l0 * q.hi[0] + (alo >> 32);
-    H += (uint64_t)l1 * q.hi[1];
-    H += (uint64_t)l2 * q.hi[2];
-    const uint32_t a0 = (uint32_t)alo, h0 = (uint32_t)H, h1 = (uint32_t)(H >> 32);
-    L4 r;
-    r.l[0] = a0 & M24;
-    r.l[1] = perm(h0, a0, SEL_345);
-    r.l[2] = perm(h1, h0, SEL_234);
-    r.l[3] = h1 >> 8;
-    return r;
-}
+// (the three-copy product on loads is gl_limb.h's mul3_to_limbs / Q3 since round 3)
 
 // ---- kernels ------------------------------------------------------------------------------------------
 struct Args { const uint64_t* src; uint64_t* dst; const uint64_t* tab; const uint64_t* qtab; unsigned n; };
@@ -102,7 +86,7 @@ __global__ void __launch_bounds__(256, 4) k_level(Args A) {
         uint64_t r;
         if (MODE == 0) r = mul_fold<false>(v[a], w);
         else if (MODE == 2) r = mul_fold_c128(v[a], w);
-        else r = mul_fold_co(v[a], w);
+        else r = mul_fold_co_probe(v[a], w);
         A.dst[i + (size_t)a * A.n] = r;
     }
 }

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     unsigned* sync; CK(hipMalloc(&sync, 4 * SYNCW * 4)); CK(hipMemset(sync, 0, 4 * SYNCW * 4));     // one area per stream
 
     msntt2::Params Q; memset(&Q, 0, sizeof Q);
-    Q.wr4 = wr4; Q.twu4 = twu4; Q.sc4 = sc4; Q.g_plain = gp; Q.tw_lo = tw_lo; Q.tw_hi = tw_hi; Q.aux_lo = aux_lo; Q.aux_hi = aux_hi;
+    Q.wr4 = wr4; Q.twu4 = twu4; Q.sc4 = sc4; Q.g4 = gp; Q.tw_lo = tw_lo; Q.tw_hi = tw_hi; Q.aux_lo = aux_lo; Q.aux_hi = aux_hi;
     Q.log_n = log_n; Q.V = 1; Q.valid_rows = 256; Q.lo_bits = 12; Q.tin4 = tin4; Q.tout4 = tout4; Q.r3 = 8; Q.sync = sync;
     const msntt::DigitField f1[2] = {{0, 8, 255}, {8, 0, 255}};
     const dim3 b2(msntt2::NT);

@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
 
     msntt2::Params Q; memset(&Q, 0, sizeof Q);
     msntt::PassParams P; memset(&P, 0, sizeof P);
-    Q.wr4 = wr4; Q.twu4 = twu4; Q.sc4 = sc4; Q.g_plain = gp; Q.tw_lo = tw_lo; Q.tw_hi = tw_hi; Q.aux_lo = aux_lo; Q.aux_hi = aux_hi;
+    Q.wr4 = wr4; Q.twu4 = twu4; Q.sc4 = sc4; Q.g4 = gp; Q.tw_lo = tw_lo; Q.tw_hi = tw_hi; Q.aux_lo = aux_lo; Q.aux_hi = aux_hi;
     Q.log_n = log_n; Q.V = 1; Q.valid_rows = 256; Q.lo_bits = 12; Q.tin4 = tin4; Q.tout4 = tout4; Q.r3 = 8;
     P.tw_lo = tw_lo; P.tw_hi = tw_hi; P.wr = wr; P.aux_lo = aux_lo; P.aux_hi = aux_hi; P.gtab = gtab; P.log_n = log_n; P.V = 1; P.valid_rows = 256; P.lo_bits = 12;
     // pass 1 of an (8, 8, 8) plan: j' = (j2, j3) -> layout (j3, j2)
