@@ -79,6 +79,16 @@ int main(int argc, char** argv) {
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true>), g2, b2, 0, 0, Q); });   printf("limb    pass 2 (per-lane load factor)     %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, false, 0>), g1, b1, 0, 0, P); }); printf("round-1 pass 2           %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0>), g2, b2, 0, 0, Q); });   printf("limb    pass 2           %7.1f us/column\n", t / NC);
+    // the middle passes of the (256, R, 256) plans (2^17 .. 2^23 points), run here over the same 2^24 words per "column" (blocks of
+    // R rows of 256 words; in place on permuted rows, as in the plans): time per 2^24 words
+    set_pass(1);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 1, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 2   (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 2, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 4   (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 3, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 8   (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 4, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 16  (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, 1, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 32  (16 x 2, one exchange)  %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, 2, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 64  (16 x 4, one exchange)  %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, 3, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 128 (16 x 8, one exchange)  %5.1f us per 2^24 words\n", t / NC);
     set_pass(2);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, true, 0>), g1, b1, 0, 0, P); });  printf("round-1 pass 3           %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, 0, Q); });    printf("limb    pass 3           %7.1f us/column\n", t / NC);
