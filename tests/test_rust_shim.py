@@ -135,7 +135,7 @@ def test_shim_serves_every_call_the_reference_makes():
 
 def test_shim_only_calls_declared_entry_points_with_the_right_arity():
     externs = _rust_externs()
-    for name in ("plan.rs", "stage.rs", "utils.rs"):
+    for name in ("plan.rs", "stage.rs", "utils.rs", "../../../src/eval_hip.rs"):
         text = open(os.path.join(ROOT, "rust", "gpu", "src", "hip", name)).read()
         for m in re.finditer(r"sys::(ms_\w+)\(", text):
             fn = m.group(1)
@@ -153,8 +153,29 @@ def test_shim_only_calls_declared_entry_points_with_the_right_arity():
                 if depth and not ch.isspace():
                     nonempty = True
                 i += 1
+            if text[:i - 1].rstrip().endswith(","):            # rustfmt's trailing comma
+                commas -= 1
             nargs = commas + 1 if nonempty else 0
             assert nargs == len(externs[fn][0]), f"{name}: {fn} called with {nargs} arguments, declared with {len(externs[fn][0])}"
+
+
+def test_evaluator_arm_uses_the_opcodes_of_the_header_and_the_signature_of_eval_cpu():
+    """rust/src/eval_hip.rs (-> src/eval_hip.rs of the reference): its opcode constants are the header's, its `eval` has the
+    parameter list of eval_cpu::eval (src/eval_cpu.rs:33-42; fixture: the same list, so that src/air.rs can switch with a cfg)."""
+    text = open(os.path.join(ROOT, "rust", "src", "eval_hip.rs")).read()
+    header = open(os.path.join(ROOT, "include", "ministark_hip.h")).read()
+    doc = dict((name, int(num)) for num, name in re.findall(r"\b(\d+) ([A-Z]+_[PQ]{1,2}|EMBED)\b", header))
+    for name, value in re.findall(r"const ([A-Z_]+): u32 = (\d+);", text):
+        assert doc[name] == int(value), (name, value, doc.get(name))
+    sig = re.search(r"pub fn eval<Fp: GpuFftField<FftField = Fp> \+ FftField, Fq: StarkExtensionOf<Fp>>\((.*?)\) -> Matrix<Fq>", text, re.S).group(1)
+    params = [p.strip() for p in sig.strip().rstrip(",").split(",\n")]
+    assert params == ["expr: &Expr<AlgebraicItem<FieldVariant<Fp, Fq>>>", "challenges: &[Fq]", "hints: &[Fq]", "lde_step: usize",
+                      "domain_offset: Fp", "x_lde: &[Fp]", "base_trace_lde_cols: &[&[Fp]]", "extension_trace_lde_cols: Option<&[&[Fq]]>"]
+    if os.path.isdir("/root/reference"):                                 # ... which is eval_cpu::eval's, word for word
+        ref = open("/root/reference/src/eval_cpu.rs").read()
+        rsig = re.search(r"pub fn eval<Fp: GpuFftField<FftField = Fp> \+ FftField, Fq: StarkExtensionOf<Fp>>\((.*?)\) -> Matrix<Fq>", ref, re.S).group(1)
+        assert [p.strip() for p in rsig.strip().rstrip(",").split(",\n")] == params
+    assert {"src_air.rs.patch", "src_lib.rs.patch"} <= set(os.listdir(os.path.join(ROOT, "rust", "patches")))
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
