@@ -67,7 +67,6 @@ struct Node {
 struct Builder {
     nodes: Vec<Node>,
     consts: Vec<u64>, // Montgomery limbs, as the elements lie in memory
-    fq_is_ext: bool,
 }
 
 impl Builder {
@@ -219,6 +218,7 @@ pub fn eval<Fp: GpuFftField<FftField = Fp> + FftField, Fq: StarkExtensionOf<Fp>>
     use AlgebraicItem::*;
     let n = x_lde.len();
     assert!(n.is_power_of_two());
+    debug_assert!(x_lde[0] == domain_offset, "x_lde is lde_domain.elements() (src/prover.rs:93-96)");
     let fq_is_ext = core::mem::size_of::<Fq>() != core::mem::size_of::<Fp>();
     let num_base_columns = base_trace_lde_cols.len();
     let num_extension_columns = extension_trace_lde_cols.map_or(0, <[_]>::len);
@@ -236,7 +236,7 @@ pub fn eval<Fp: GpuFftField<FftField = Fp> + FftField, Fq: StarkExtensionOf<Fp>>
     }
 
     // ---- the graph -> SSA nodes (graph_eval caches shared nodes: every node is recorded once)
-    let builder = Rc::new(RefCell::new(Builder { fq_is_ext, ..Builder::default() }));
+    let builder = Rc::new(RefCell::new(Builder::default()));
     let leaf = |op: u32, q: bool, imm0: u32, imm1: i32| {
         let id = builder.borrow_mut().emit(op, q, None, None, imm0, imm1);
         Val { b: Rc::clone(&builder), id }
