@@ -135,7 +135,7 @@ def test_shim_serves_every_call_the_reference_makes():
 
 def test_shim_only_calls_declared_entry_points_with_the_right_arity():
     externs = _rust_externs()
-    for name in ("plan.rs", "stage.rs", "utils.rs", "../../../src/eval_hip.rs"):
+    for name in ("plan.rs", "stage.rs", "utils.rs", "../../../src/eval_hip.rs", "../../../src/composer_hip.rs"):
         text = open(os.path.join(ROOT, "rust", "gpu", "src", "hip", name)).read()
         for m in re.finditer(r"sys::(ms_\w+)\(", text):
             fn = m.group(1)
@@ -175,7 +175,7 @@ def test_evaluator_arm_uses_the_opcodes_of_the_header_and_the_signature_of_eval_
         ref = open("/root/reference/src/eval_cpu.rs").read()
         rsig = re.search(r"pub fn eval<Fp: GpuFftField<FftField = Fp> \+ FftField, Fq: StarkExtensionOf<Fp>>\((.*?)\) -> Matrix<Fq>", ref, re.S).group(1)
         assert [p.strip() for p in rsig.strip().rstrip(",").split(",\n")] == params
-    assert {"src_air.rs.patch", "src_lib.rs.patch"} <= set(os.listdir(os.path.join(ROOT, "rust", "patches")))
+    assert {"src_air.rs.patch", "src_lib.rs.patch", "src_composer.rs.patch"} <= set(os.listdir(os.path.join(ROOT, "rust", "patches")))
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
