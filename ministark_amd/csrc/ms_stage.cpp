@@ -267,10 +267,13 @@ static void scan_launch_per(ms_ctx* ctx, const msscan::ScanParams& P) {
     { ProfScope ps(ctx, "scan_apply", 8.0 * P.n * F::V * (1 + (HAS_A ? 1 : 0) + (HAS_B ? 1 : 0)));
       hipLaunchKernelGGL((scan_apply<F, HAS_A, HAS_B, PER>), dim3(P.nblocks), dim3(NT), 0, ctx->stream, P); }
 }
-static unsigned scan_rows_per_lane(size_t n) { return n < ((size_t)1 << 20) ? 4 : 16; }
+// rows per lane: the block's rows cross LDS once (NT * PER elements), so wide elements take fewer
+static unsigned scan_rows_per_lane(size_t n, unsigned V) { return (n < ((size_t)1 << 20) || V == 4) ? 4 : V == 1 ? 16 : 8; }
 template <class F, bool HAS_A, bool HAS_B>
 static void scan_launch(ms_ctx* ctx, const msscan::ScanParams& P) {
-    if (scan_rows_per_lane(P.n) == 4) scan_launch_per<F, HAS_A, HAS_B, 4>(ctx, P); else scan_launch_per<F, HAS_A, HAS_B, 16>(ctx, P);
+    if constexpr (F::V == 4) scan_launch_per<F, HAS_A, HAS_B, 4>(ctx, P);        // 32-byte elements: 4 rows per lane at every length
+    else if (scan_rows_per_lane(P.n, F::V) == 4) scan_launch_per<F, HAS_A, HAS_B, 4>(ctx, P);
+    else scan_launch_per<F, HAS_A, HAS_B, F::V == 1 ? 16 : 8>(ctx, P);
 }
 extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a, const void* d_b, const void* h_init, int inclusive, void* d_out) {
     if (!ctx || !d_out || !h_init) return fail(MS_ERR_INVALID, "ms_scan_affine: null argument");
@@ -278,7 +281,7 @@ extern "C" int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a,
     unsigned V = 0;
     MSCHK(field_words(field, &V));
     if (n == 0) return MS_OK;
-    const size_t tile = (size_t)msscan::NT * scan_rows_per_lane(n);
+    const size_t tile = (size_t)msscan::NT * scan_rows_per_lane(n, V);
     if ((n + tile - 1) / tile > 0xFFFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "column too long");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));

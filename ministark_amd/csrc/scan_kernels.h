@@ -22,8 +22,8 @@
 namespace msscan {
 
 static constexpr int NT = 256;
-// rows per lane: 16 for long columns, 4 below 2^20 rows (four times the workgroups, a quarter of the serial chain per
-// lane: a 2^16-row column is latency-bound, not throughput-bound)
+// rows per lane: 16 (Fp) / 8 (wider elements) for long columns, 4 below 2^20 rows (four times the workgroups, a quarter of the
+// serial chain per lane: a 2^16-row column is latency-bound, not throughput-bound)
 
 struct ScanParams {
     const uint64_t* a;       // multipliers (nullptr: all one)
@@ -89,12 +89,75 @@ __device__ __forceinline__ Map<F> wg_scan(Map<F> m, Map<F>* sh, Map<F>* excl) {
     return m;
 }
 
+// ---- the block's rows, read and written coalesced ----------------------------------------------------------------------
+// A lane composes PER CONSECUTIVE rows, so reading them where they lie would make a wave touch 64 different lines per load
+// (measured: 0.5 TB/s on a 2^22-row column).  Instead the NT * PER elements of a block cross LDS once: lanes run along the WORDS
+// of the block (coalesced, whatever the element width), then every lane picks up its run.  One pad word per Q = lowbit(PER V)
+// words makes the run stride odd, i.e. conflict-free.
+template <int S> __device__ __forceinline__ unsigned tile_slot(unsigned p) { constexpr unsigned Q = S & (0u - S); return p + p / Q; }
+template <class F, int PER> struct Tile { static constexpr int S = PER * F::V; static constexpr unsigned WORDS = NT * S + NT * S / (S & (0u - S)) + 1; };
+
+template <class F, int PER>
+__device__ __forceinline__ void load_runs(const uint64_t* __restrict__ src, size_t e0, size_t n, uint64_t* tile, typename F::T* out, const typename F::T& fill) {
+    constexpr int V = F::V, S = PER * V;
+    const unsigned t = threadIdx.x;
+    const size_t w0 = e0 * V, wn = n * V;
+    #pragma unroll
+    for (int j = 0; j < S; j++) {
+        const size_t w = w0 + (size_t)j * NT + t;
+        tile[tile_slot<S>(j * NT + t)] = w < wn ? src[w] : 0;
+    }
+    __syncthreads();
+    #pragma unroll
+    for (int j = 0; j < PER; j++) {
+        uint64_t words[V];
+        #pragma unroll
+        for (int v = 0; v < V; v++) words[v] = tile[tile_slot<S>((t * PER + j) * V + v)];
+        out[j] = e0 + (size_t)t * PER + j < n ? F::load(words, 0) : fill;
+    }
+    __syncthreads();
+}
+template <class F, int PER>
+__device__ __forceinline__ void store_runs(uint64_t* __restrict__ dst, size_t e0, size_t n, uint64_t* tile, const typename F::T* vals) {
+    constexpr int V = F::V, S = PER * V;
+    const unsigned t = threadIdx.x;
+    #pragma unroll
+    for (int j = 0; j < PER; j++) {
+        uint64_t words[V];
+        F::store(words, 0, vals[j]);
+        #pragma unroll
+        for (int v = 0; v < V; v++) tile[tile_slot<S>((t * PER + j) * V + v)] = words[v];
+    }
+    __syncthreads();
+    const size_t w0 = e0 * V, wn = n * V;
+    #pragma unroll
+    for (int j = 0; j < S; j++) {
+        const size_t w = w0 + (size_t)j * NT + t;
+        if (w < wn) dst[w] = tile[tile_slot<S>(j * NT + t)];
+    }
+}
+// the PER maps of this lane -> (a[], b[]) in registers and their in-order composition
+template <class F, bool HAS_A, bool HAS_B, int PER>
+__device__ __forceinline__ Map<F> lane_maps(const ScanParams& P, size_t e0, uint64_t* tile, typename F::T* a, typename F::T* b) {
+    if constexpr (HAS_A) load_runs<F, PER>(P.a, e0, P.n, tile, a, F::one());
+    if constexpr (HAS_B) load_runs<F, PER>(P.b, e0, P.n, tile, b, f_zero<F>());
+    Map<F> m = identity<F>();
+    #pragma unroll
+    for (int j = 0; j < PER; j++) {
+        Map<F> mj = identity<F>();
+        if constexpr (HAS_A) mj.a = a[j];
+        if constexpr (HAS_B) mj.b = b[j];
+        m = j ? compose<F, HAS_A, HAS_B>(m, mj) : mj;
+    }
+    return m;
+}
+
 template <class F, bool HAS_A, bool HAS_B, int PER>
 __global__ void __launch_bounds__(NT) scan_reduce(ScanParams P) {
     __shared__ Map<F> sh[NT];
-    const size_t i0 = (size_t)blockIdx.x * (NT * PER) + (size_t)threadIdx.x * PER;
-    Map<F> m = load_map<F, HAS_A, HAS_B>(P, i0);
-    for (int j = 1; j < PER; j++) m = compose<F, HAS_A, HAS_B>(m, load_map<F, HAS_A, HAS_B>(P, i0 + j));
+    __shared__ uint64_t tile[Tile<F, PER>::WORDS];
+    typename F::T a[HAS_A ? PER : 1], b[HAS_B ? PER : 1];
+    Map<F> m = lane_maps<F, HAS_A, HAS_B, PER>(P, (size_t)blockIdx.x * (NT * PER), tile, a, b);
     Map<F> excl;
     m = wg_scan<F, HAS_A, HAS_B>(m, sh, &excl);
     if (threadIdx.x == NT - 1) {
@@ -128,20 +191,24 @@ __global__ void __launch_bounds__(NT) scan_blocks(ScanParams P) {
 template <class F, bool HAS_A, bool HAS_B, int PER>
 __global__ void __launch_bounds__(NT) scan_apply(ScanParams P) {
     __shared__ Map<F> sh[NT];
-    const size_t i0 = (size_t)blockIdx.x * (NT * PER) + (size_t)threadIdx.x * PER;
-    Map<F> m = load_map<F, HAS_A, HAS_B>(P, i0);
-    for (int j = 1; j < PER; j++) m = compose<F, HAS_A, HAS_B>(m, load_map<F, HAS_A, HAS_B>(P, i0 + j));
+    __shared__ uint64_t tile[Tile<F, PER>::WORDS];
+    const size_t e0 = (size_t)blockIdx.x * (NT * PER);
+    typename F::T a[HAS_A ? PER : 1], b[HAS_B ? PER : 1];
+    Map<F> m = lane_maps<F, HAS_A, HAS_B, PER>(P, e0, tile, a, b);   // the maps stay in registers: no second read of the column
     Map<F> excl;
     wg_scan<F, HAS_A, HAS_B>(m, sh, &excl);
     typename F::T s = apply<F, HAS_A, HAS_B>(excl, F::load(P.block_state, blockIdx.x));
+    typename F::T out[PER];
+    #pragma unroll
     for (int j = 0; j < PER; j++) {
-        const size_t i = i0 + j;
-        if (i >= P.n) break;
-        const Map<F> mj = load_map<F, HAS_A, HAS_B>(P, i);      // second read (cache-resident); element i is read before it is written: in place is fine
-        if (!P.inclusive) F::store(P.out, i, s);
+        Map<F> mj = identity<F>();
+        if constexpr (HAS_A) mj.a = a[j];
+        if constexpr (HAS_B) mj.b = b[j];
+        if (!P.inclusive) out[j] = s;
         s = apply<F, HAS_A, HAS_B>(mj, s);
-        if (P.inclusive) F::store(P.out, i, s);
+        if (P.inclusive) out[j] = s;
     }
+    store_runs<F, PER>(P.out, e0, P.n, tile, out);                  // in place is fine: the block's inputs were read above
 }
 
 // ---- gathers ---------------------------------------------------------------------------------

@@ -230,3 +230,64 @@ def c1():
 wall, k = timed(c1, reps=2)
 emit("C1-shaped pipeline at scale: 2^16 rows, 17 Fp + 9 Fq3 columns (extension columns built on the device), blow-up 16, FRI fold 16, 32 queries", wall, k,
      phases_ms={kk: round(v * 1e3, 2) for kk, v in phase1.items()})
+
+
+# ---- SURVEY.md 8(f), the "next" rows, each on its own at the C5 shape (2^22 rows x 8 columns, blow-up 4) ---------------------------
+# Bounds: DEEP / scans / gathers are streaming (HBM, algorithmic bytes = every input column once + the output once); RPO-256,
+# SHA-256 and the proof-of-work search are integer-ALU work (rates in hashes per second, no byte roofline).
+HBM = 8000.0
+n5, N5 = 1 << 22, 1 << 24
+polys5 = Matrix.from_numpy(pl, [rand(n5) for _ in range(8)], FP)
+comp5 = Matrix.from_numpy(pl, [rand(n5)], FP)
+args5 = [(c, o) for c in range(8) for o in (0, 1)]
+r1 = lambda: int(rng.integers(1, P, dtype=np.uint64))
+coeffs5 = DeepCompositionCoeffs([r1() for _ in args5], [r1()], (r1(), r1()))
+z5 = r1()
+
+
+def deep5():
+    c = DeepPolyComposer(args5, n5, z5, polys5, None, comp5)
+    c.get_ood_evals()
+    c.into_deep_poly(coeffs5)
+
+
+wall, k = timed(deep5)
+alg = (8 + 1) * n5 * 8 * 2 + n5 * 8                       # Horner pass over the 9 polynomials, composition pass over them again, one output
+emit("f1 DEEP composition: 17 out-of-domain evaluations (Horner) + into_deep_poly, 8 + 1 polynomials of 2^22 coefficients", wall, k,
+     algorithmic_bytes=alg, algorithmic_GBps=round(alg / (sum(k.values()) * 1e-6) / 1e9, 1), hbm_frac=round(alg / (sum(k.values()) * 1e-6) / 1e9 / HBM, 4),
+     bound="hbm (streams every coefficient twice; 16 Horner points per base column share one pass)")
+
+rows5 = Matrix.from_numpy(pl, [rand(1 << 20) for _ in range(8)], FP)
+for h in ("sha256", "rpo256"):
+    wall, k = timed(lambda: MerkleTree.from_matrix(rows5, h).root())
+    hashes = (1 << 20) + (1 << 20) - 1                    # one leaf per row (8 elements = one rate block / one 64-byte message) + the tree
+    emit(f"f2 commitment of 2^20 rows x 8 Fp columns with {h}: rows + Merkle tree", wall, k,
+         hashes_per_s=round(hashes / (sum(k.values()) * 1e-6) / 1e9, 2), unit="G leaf-or-node hashes / s",
+         bound="integer ALU (SHA-256: 2 compressions per leaf and per node; RPO-256: one 7-round permutation of 12 Goldilocks elements each, x^7 and x^(1/7) S-boxes)")
+
+seed5 = bytes(range(32))
+for bits in (16, 20):
+    t0 = time.perf_counter()
+    nonce = grind_proof_of_work(pl, seed5, bits)
+    dt = time.perf_counter() - t0
+    emit(f"f3 proof-of-work grinding, {bits} bits (src/random.rs:48-58)", dt, {}, nonce=nonce, tries_per_s=round(nonce / dt / 1e9, 3), unit="G SHA-256(seed || nonce) / s incl. launch and read-back",
+         bound="integer ALU; latency-bound below ~2^24 tries (one launch wave finds the nonce)")
+
+for field, V, name in ((FP, 1, "Fp"), (FQ3, 3, "Fq3")):
+    fac = GpuVec.from_numpy(pl, rand(n5 * V), field)
+    one = np.array([0xFFFFFFFF] + [0] * (V - 1), dtype=np.uint64)          # Montgomery 1
+    wall, k = timed(lambda: running_product(fac, one))
+    alg = 2 * n5 * V * 8
+    emit(f"f4 running product over 2^22 {name} elements (extension-column scan, examples/brainfuck/trace.rs:131-145)", wall, k,
+         algorithmic_bytes=alg, algorithmic_GBps=round(alg / (sum(k.values()) * 1e-6) / 1e9, 1), hbm_frac=round(alg / (sum(k.values()) * 1e-6) / 1e9 / HBM, 4),
+         bound="hbm for the two streaming passes + a serial walk over the block aggregates (latency)" if V == 1 else
+               "integer ALU: three to four Fq3 products (nine Goldilocks products each) per element")
+
+lde5 = Matrix.from_numpy(pl, [rand(N5) for _ in range(8)], FP)
+tree5 = MerkleTree.from_matrix(lde5)
+clde5 = Matrix.from_numpy(pl, [rand(N5)], FP)
+ctree5 = MerkleTree.from_matrix(clde5)
+pos5 = [int(v) for v in rng.integers(0, N5, size=32)]
+wall, k = timed(lambda: Queries(lde5, None, clde5, tree5, None, ctree5, pos5))
+emit("f4 query extraction: 32 positions, rows of the 8-column and the 1-column LDE (2^24 rows) + both Merkle openings", wall, k,
+     bound="latency (a few hundred 32-byte gathers and two host round trips)")

@@ -36,17 +36,39 @@ def kernels(path):
 
 
 def meta(path):
+    """Per-kernel metadata of the code object notes.  The keys of a kernel's block are sorted alphabetically
+    (.group_segment_fixed_size comes BEFORE .name), so a block is collected whole and then filed under its name."""
     out = {}
     cur = None
+    inside = False
+
+    def flush():
+        if cur and ".name" in cur:
+            out[cur[".name"]] = {k[1:]: v for k, v in cur.items() if k != ".name"}
     for line in open(path):
-        m = re.match(r"\s*\.name:\s*(\S+)", line)
+        if line.startswith("amdhsa.kernels:"):
+            inside = True
+            continue
+        if not inside:
+            continue
+        if re.match(r"^[A-Za-z]", line):                      # next top-level key: the kernel list is over
+            flush()
+            cur, inside = None, False
+            continue
+        if line.startswith("  - "):                            # a new kernel block
+            flush()
+            cur = {}
+            line = "    " + line[4:]
+        if cur is None:
+            continue
+        m = re.match(r"^    (\.\w+):\s*(\S+)\s*$", line)
         if m:
-            cur = m.group(1)
-            out.setdefault(cur, {})
-        for key in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"):
-            m = re.match(r"\s*\.%s:\s*(\d+)" % key, line)
-            if m and cur:
-                out[cur][key] = int(m.group(1))
+            key, val = m.group(1), m.group(2)
+            if key == ".name":
+                cur[key] = val
+            elif key in (".vgpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size", ".group_segment_fixed_size"):
+                cur[key] = int(val)
+    flush()
     return out
 
 
