@@ -103,6 +103,14 @@ extern "C" int ms_unary(ms_ctx* ctx, int op, int field, size_t n, void* d_dst, c
     dim3 g(stream_grid(n)), b(msstage::NT);
     ProfScope ps(ctx, op == MS_NEG ? "stage_neg" : op == MS_INV ? "stage_inverse" : "stage_exp", 16.0 * n * V);
     using namespace msstage;
+    if (op == MS_INV && n >= 4096) {          // long columns: batch inversion (k_batch_inverse), K elements per lane
+        auto blocks = [&](unsigned K) { return dim3((unsigned)std::min<size_t>((n + (size_t)NT * K - 1) / ((size_t)NT * K), 0x7FFFFFFFu)); };
+        if (V == 1) hipLaunchKernelGGL((k_batch_inverse<FpT, 16>), blocks(16), b, 0, ctx->stream, dst, src, n);
+        else if (V == 3) hipLaunchKernelGGL((k_batch_inverse<Fq3T, 8>), blocks(8), b, 0, ctx->stream, dst, src, n);
+        else hipLaunchKernelGGL((k_batch_inverse<Fp252T, 8>), blocks(8), b, 0, ctx->stream, dst, src, n);
+        HIPCHK(hipGetLastError());
+        return MS_OK;
+    }
     if (V == 4) {
         if (op == MS_NEG) hipLaunchKernelGGL((k_unary<Fp252T, 0>), g, b, 0, ctx->stream, dst, src, n, exponent);
         else if (op == MS_INV) hipLaunchKernelGGL((k_unary<Fp252T, 1>), g, b, 0, ctx->stream, dst, src, n, exponent);

@@ -140,6 +140,36 @@ __global__ void __launch_bounds__(NT) k_unary(uint64_t* dst, const uint64_t* src
         F::store(dst, i, OP == 0 ? F::neg(a) : OP == 1 ? F::inv(a) : powu<F>(a, e));
     }
 }
+// InverseInto / InverseInPlace stages (gpu/src/stage.rs:808-853, 949-997) on long columns: Montgomery's trick over the K elements of a
+// lane (elements tid + j * stride: coalesced) -- K - 1 products forward, ONE Fermat inverse, 2 (K - 1) products backward: three
+// multiplications and 1/K of an inversion per element instead of 72 (Fp) / ~370 (Fp252).  Inverses are unique and every product is
+// canonical, so the result is what the per-element stage writes, 0^-1 = 0 included.  dst may be src.
+template <class T> __device__ __forceinline__ bool is_zero(const T& v);
+template <> __device__ __forceinline__ bool is_zero<uint64_t>(const uint64_t& v) { return v == 0; }
+template <> __device__ __forceinline__ bool is_zero<gl::Fq3>(const gl::Fq3& v) { return (v.c0 | v.c1 | v.c2) == 0; }
+template <> __device__ __forceinline__ bool is_zero<f252::E>(const f252::E& v) { return (v.l[0] | v.l[1] | v.l[2] | v.l[3]) == 0; }
+template <class F, int K>
+__global__ void __launch_bounds__(NT) k_batch_inverse(uint64_t* dst, const uint64_t* src, size_t n) {
+    using T = typename F::T;
+    const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;
+    T val[K], pre[K];
+    T acc = F::one();
+    #pragma unroll
+    for (int j = 0; j < K; j++) {
+        const size_t i = tid + (size_t)j * stride;
+        pre[j] = acc;
+        if (i < n) { val[j] = F::load(src, i); if (!is_zero<T>(val[j])) acc = F::mul(acc, val[j]); }
+    }
+    T inv = F::inv(acc);
+    #pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        const size_t i = tid + (size_t)j * stride;
+        if (i < n) {
+            if (is_zero<T>(val[j])) F::store(dst, i, val[j]);
+            else { F::store(dst, i, F::mul(inv, pre[j])); inv = F::mul(inv, val[j]); }
+        }
+    }
+}
 static __global__ void __launch_bounds__(NT) k_convert_fp_fq3(uint64_t* dst, const uint64_t* src, size_t n) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
         const uint64_t x = src[i];

@@ -90,6 +90,21 @@ def test_stages_252(kind):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+def test_inverse_stage_on_a_long_column_252(kind):
+    # from 4096 elements: Montgomery's trick (k_batch_inverse), zeros included, into another buffer and in place
+    pl = backends.planner(kind)
+    n = 4096
+    a = _rand_canon(n, 7)
+    a[5] = a[n - 1] = a[1000] = 0
+    want = [0 if x == 0 else pow(x, -1, P) for x in a]
+    A, D = _to_dev(pl, a), GpuVec(pl, n, STARK252_FP)
+    S.InverseIntoStage(pl, n, STARK252_FP).encode(D, A)
+    assert _from_dev(D) == want and _from_dev(A) == a
+    S.InverseInPlaceStage(pl, n, STARK252_FP).encode(A)
+    assert _from_dev(A) == want
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_hash_rows_252(kind):
     pl = backends.planner(kind)
     n = 16

@@ -91,6 +91,26 @@ def test_unary_stages(kind, field):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("field", [FP, FQ3])
+def test_inverse_stages_on_long_columns(kind, field):
+    # from 4096 elements the inverse stages run Montgomery's trick (k_batch_inverse): zeros sprinkled in (0^-1 = 0),
+    # into another buffer and in place -- the same words as the per-element Fermat inverse
+    pl = backends.planner(kind)
+    n = 1 << 16 if kind == "hip" else 8192
+    a = _vals(n * V[field], 16).reshape(n, V[field])
+    a[::97] = 0
+    a[-1] = 0
+    a = np.ascontiguousarray(a.reshape(-1))
+    want = cref.unary(S.INV, V[field], a, 0)
+    s, d = GpuVec.from_numpy(pl, a, field), GpuVec(pl, n, field)
+    S.InverseIntoStage(pl, n, field).encode(d, s)
+    assert np.array_equal(d.to_numpy(), want)
+    assert np.array_equal(s.to_numpy(), a)
+    S.InverseInPlaceStage(pl, n, field).encode(s)
+    assert np.array_equal(s.to_numpy(), want)
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_convert_fill_sum(kind):
     pl = backends.planner(kind)
     n = 512
