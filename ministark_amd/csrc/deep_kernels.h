@@ -114,46 +114,75 @@ struct DeepParams {
     uint64_t h_mont;
     size_t n;
     unsigned nbase, nterms, npoints, lo_bits, xshift;
+    unsigned term_start[MAXPOINTS + 1];   // terms are sorted by point: those of point k are [term_start[k], term_start[k + 1])
 };
-template <int PW>
+// PTS points per lane (points i, i + NT, ... of the workgroup's NT * PTS: coalesced): their PTS * npoints denominators x - z_k
+// share ONE inversion (Montgomery's trick: 72 products for Fp, more for Fq3, against 3 per denominator), and the terms arrive
+// sorted by point so that a point's quotient factor multiplies the SUM of its terms:
+//     sum_t alpha_t (P_ct(x) - ood_t) / (x - z_pt)  =  sum_k 1/(x - z_k)  sum_{t: pt = k} alpha_t (P_ct(x) - ood_t)
+// -- nterms + npoints products per point instead of 2 nterms.  Exact field arithmetic: the same value.
+template <int PW, int PTS, int MP>       // MP: the most distinct points this instantiation serves (array sizes)
 __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= P.n) return;
-    const size_t e = i << P.xshift;
-    uint64_t xs = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
-    if (e >> P.lo_bits) xs = gld::mmul(xs, P.tw_hi[e >> P.lo_bits]);
-    xs = gld::mmul(xs, P.h_mont);
-    const Q x = {{xs, 0, 0}};
-    // 1 / (x - z_k) for every point: one inversion (Montgomery's trick)
-    Q d[MAXPOINTS], pre[MAXPOINTS];
+    const size_t i0 = (size_t)blockIdx.x * (NT * PTS) + threadIdx.x;
+    Q d[PTS][MP], pre[PTS][MP];
     Q run = {{gl::ONE_MONT, 0, 0}};
     #pragma unroll
-    for (int k = 0; k < MAXPOINTS; k++) if (k < (int)P.npoints) {
-        d[k] = q_sub<PW>(x, Q{{P.points[k][0], P.points[k][1], P.points[k][2]}});
-        pre[k] = run;
-        run = q_mul<PW>(run, d[k]);
+    for (int j = 0; j < PTS; j++) {
+        const size_t i = i0 + (size_t)j * NT;
+        const size_t e = (i < P.n ? i : 0) << P.xshift;
+        uint64_t xs = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+        if (e >> P.lo_bits) xs = gld::mmul(xs, P.tw_hi[e >> P.lo_bits]);
+        xs = gld::mmul(xs, P.h_mont);
+        const Q x = {{xs, 0, 0}};
+        #pragma unroll
+        for (int k = 0; k < MP; k++) if (k < (int)P.npoints) {
+            d[j][k] = q_sub<PW>(x, Q{{P.points[k][0], P.points[k][1], P.points[k][2]}});
+            pre[j][k] = run;
+            run = q_mul<PW>(run, d[j][k]);
+        }
     }
     Q inv = q_inv<PW>(run);
     #pragma unroll
-    for (int k = MAXPOINTS - 1; k >= 0; k--) if (k < (int)P.npoints) {
-        const Q dk = d[k];
-        d[k] = q_mul<PW>(inv, pre[k]);        // now 1 / (x - z_k)
-        inv = q_mul<PW>(inv, dk);
-    }
-    Q acc = q_zero<PW>();
-    for (unsigned t = 0; t < P.nterms; t++) {
-        const Term T = P.terms[t];
-        Q v;
-        if (T.col < P.nbase) v = q_load<1>(P.base[T.col], i);
-        else { if constexpr (PW == 3) v = q_load<3>(P.ext[T.col - P.nbase], i); else v = q_zero<PW>(); }
-        v = q_sub<PW>(v, Q{{T.ood[0], T.ood[1], T.ood[2]}});
-        Q dk = d[0];
+    for (int j = PTS - 1; j >= 0; j--) {
         #pragma unroll
-        for (int k = 1; k < MAXPOINTS; k++) if ((int)T.point == k) dk = d[k];
-        acc = q_add<PW>(acc, q_mul<PW>(q_mul<PW>(v, dk), Q{{T.alpha[0], T.alpha[1], T.alpha[2]}}));
+        for (int k = MP - 1; k >= 0; k--) if (k < (int)P.npoints) {
+            const Q dk = d[j][k];
+            d[j][k] = q_mul<PW>(inv, pre[j][k]);          // now 1 / (x_j - z_k)
+            inv = q_mul<PW>(inv, dk);
+        }
+    }
+    // terms outermost, the lane's PTS points innermost: PTS independent loads per term
+    Q acc[PTS];
+    #pragma unroll
+    for (int j = 0; j < PTS; j++) acc[j] = q_zero<PW>();
+    #pragma unroll
+    for (int k = 0; k < MP; k++) if (k < (int)P.npoints) {
+        Q sum[PTS];
+        #pragma unroll
+        for (int j = 0; j < PTS; j++) sum[j] = q_zero<PW>();
+        for (unsigned t = P.term_start[k]; t < P.term_start[k + 1]; t++) {          // wave-uniform bounds and terms
+            const Term T = P.terms[t];
+            const Q ood = {{T.ood[0], T.ood[1], T.ood[2]}}, alpha = {{T.alpha[0], T.alpha[1], T.alpha[2]}};
+            Q v[PTS];
+            #pragma unroll
+            for (int j = 0; j < PTS; j++) {
+                const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
+                if (T.col < P.nbase) v[j] = q_load<1>(P.base[T.col], i);
+                else { if constexpr (PW == 3) v[j] = q_load<3>(P.ext[T.col - P.nbase], i); else v[j] = q_zero<PW>(); }
+            }
+            #pragma unroll
+            for (int j = 0; j < PTS; j++) sum[j] = q_add<PW>(sum[j], q_mul<PW>(q_sub<PW>(v[j], ood), alpha));
+        }
+        #pragma unroll
+        for (int j = 0; j < PTS; j++) acc[j] = q_add<PW>(acc[j], q_mul<PW>(sum[j], d[j][k]));
     }
     #pragma unroll
-    for (int w = 0; w < PW; w++) P.out[PW * i + w] = acc.w[w];
+    for (int j = 0; j < PTS; j++) {
+        const size_t i = i0 + (size_t)j * NT;
+        if (i >= P.n) continue;
+        #pragma unroll
+        for (int w = 0; w < PW; w++) P.out[PW * i + w] = acc[j].w[w];
+    }
 }
 
 // out_i = alpha * c_i + beta * c_(i-1)   (c_-1 = 0), in place over a separate copy

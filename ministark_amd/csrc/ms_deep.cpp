@@ -209,19 +209,28 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
     for (unsigned c = 0; c < next; c++) MSCHK(pooled.alloc(n * 24, &ev[nbase + c]));
     MSCHK(pooled.alloc(std::max<size_t>(1, nterms) * sizeof(msdeep::Term), &d_terms));
     MSCHK(pooled.alloc(n * PW * 8, &d_q));
-    std::vector<msdeep::Term> terms(nterms);
-    for (unsigned t = 0; t < nterms; t++) {
-        memset(&terms[t], 0, sizeof(msdeep::Term));
-        terms[t].col = h_term_col[t]; terms[t].point = h_term_point[t];
-        memcpy(terms[t].alpha, (const uint64_t*)h_term_alpha + (size_t)t * PW, PW * 8);
-        memcpy(terms[t].ood, (const uint64_t*)h_term_ood + (size_t)t * PW, PW * 8);
+    // terms sorted by point (the kernel multiplies a point's quotient factor into the SUM of its terms; the order of an exact sum is free)
+    std::vector<msdeep::Term> terms;
+    terms.reserve(nterms);
+    unsigned term_start[msdeep::MAXPOINTS + 1];
+    for (unsigned k = 0; k < npoints; k++) {
+        term_start[k] = (unsigned)terms.size();
+        for (unsigned t = 0; t < nterms; t++) {
+            if (h_term_point[t] != k) continue;
+            msdeep::Term T;
+            memset(&T, 0, sizeof T);
+            T.col = h_term_col[t]; T.point = k;
+            memcpy(T.alpha, (const uint64_t*)h_term_alpha + (size_t)t * PW, PW * 8);
+            memcpy(T.ood, (const uint64_t*)h_term_ood + (size_t)t * PW, PW * 8);
+            terms.push_back(T);
+        }
     }
+    for (unsigned k = npoints; k <= (unsigned)msdeep::MAXPOINTS; k++) term_start[k] = (unsigned)terms.size();
     int rc = MS_OK;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIPCHK(hipSetDevice(ctx->device));
-        if (nterms) HIPCHK(hipMemcpyAsync(d_terms, terms.data(), nterms * sizeof(msdeep::Term), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));            // `terms` is a host temporary
+        if (nterms) MSCHK(stage_upload(ctx, d_terms, terms.data(), nterms * sizeof(msdeep::Term)));     // through the pinned ring: no stream drain
         ms_ntt_plan *f1 = nullptr, *f3 = nullptr, *inv = nullptr, *tw = nullptr;
         if (nbase) { MSCHK(ctx_plan(ctx, 1, log_n, false, h, &f1)); rc = plan_run(f1, d_base_polys, ev.data(), nbase, 256); }
         if (rc == MS_OK && next) { MSCHK(ctx_plan(ctx, 3, log_n, false, h, &f3)); rc = plan_run(f3, d_ext_polys, ev.data() + nbase, next, 256); }
@@ -235,11 +244,19 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
         D.terms = (const msdeep::Term*)d_terms; D.tw_lo = tw->d_tw_lo; D.tw_hi = tw->d_tw_hi; D.lo_bits = tw->lo_bits; D.xshift = tl - log_n;
         for (unsigned k = 0; k < npoints; k++) memcpy(D.points[k], (const uint64_t*)h_points + (size_t)k * PW, PW * 8);
         D.out = (uint64_t*)d_q; D.h_mont = gl::to_mont(h); D.n = n; D.nbase = nbase; D.nterms = nterms; D.npoints = npoints;
+        memcpy(D.term_start, term_start, sizeof term_start);
         dim3 g((unsigned)((n + msdeep::NT - 1) / msdeep::NT));
         {
+            // points per lane: as many as keep the shared inversion's operands in registers (4 x <= 3 points over Fp, 2 x <= 4 over Fq3)
             ProfScope ps(ctx, "deep_points", 8.0 * n * (nbase + 3.0 * next + PW));
-            if (PW == 1) hipLaunchKernelGGL((msdeep::deep_points<1>), g, dim3(msdeep::NT), 0, ctx->stream, D);
-            else hipLaunchKernelGGL((msdeep::deep_points<3>), g, dim3(msdeep::NT), 0, ctx->stream, D);
+            auto blocks = [&](unsigned pts) { return dim3((unsigned)((n + (size_t)msdeep::NT * pts - 1) / ((size_t)msdeep::NT * pts))); };
+            if (PW == 1) {
+                if (npoints <= 3 && n >= 4096) hipLaunchKernelGGL((msdeep::deep_points<1, 4, 3>), blocks(4), dim3(msdeep::NT), 0, ctx->stream, D);
+                else hipLaunchKernelGGL((msdeep::deep_points<1, 1, msdeep::MAXPOINTS>), blocks(1), dim3(msdeep::NT), 0, ctx->stream, D);
+            } else {
+                if (npoints <= 4 && n >= 4096) hipLaunchKernelGGL((msdeep::deep_points<3, 2, 4>), blocks(2), dim3(msdeep::NT), 0, ctx->stream, D);
+                else hipLaunchKernelGGL((msdeep::deep_points<3, 1, msdeep::MAXPOINTS>), blocks(1), dim3(msdeep::NT), 0, ctx->stream, D);
+            }
         }
         HIPCHK(hipGetLastError());
         MSCHK(ctx_plan(ctx, PW, log_n, true, h, &inv));

@@ -61,6 +61,30 @@ def test_deep_matches_composer(kind, log_n, ext, beta_zero):
     assert _canon_col(out, ext) == want
 
 
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("ext", [False, True])
+def test_deep_points_share_one_inversion_across_points(kind, ext):
+    # n >= 4096 with at most three (Fp) / four (Fq3) distinct out-of-domain points: deep_points takes 4 / 2 points per lane, whose
+    # denominators share one inversion, and multiplies each point's quotient factor into the sum of its terms
+    pl = backends.planner(kind)
+    rng = np.random.default_rng(40 + ext)
+    n = 1 << 12
+    nbase, next_, ncomp = 2, (1 if ext else 0), 1
+    base = [[int(x) for x in rng.integers(0, P, size=n, dtype=np.uint64)] for _ in range(nbase)]
+    extp = [[_rq(rng, True) for _ in range(n)] for _ in range(next_)]
+    comp = [[_rq(rng, ext) for _ in range(n)] for _ in range(ncomp)]
+    args = [(0, 0), (0, 1), (1, 0), (1, 1)] + ([(2, 0), (2, 1)] if ext else [])          # points z, z g and z^1: three
+    z = _rq(rng, ext)
+    d = Radix2EvaluationDomain(n)
+    g, g_inv = d.group_gen, d.group_gen_inv
+    composer = DeepPolyComposer(args, n, z, _mat(pl, base, FP), _mat(pl, extp, FQ3) if ext else None, _mat(pl, comp, FQ3 if ext else FP))
+    composer.get_ood_evals()
+    ea, ca = [_rq(rng, ext) for _ in args], [_rq(rng, ext) for _ in range(ncomp)]
+    degree = (_rq(rng, ext), _rq(rng, ext))
+    out = composer.into_deep_poly(DeepCompositionCoeffs(ea, ca, degree))
+    assert _canon_col(out, ext) == pydeep.into_deep_poly(z, g, g_inv, args, base, extp, comp, ea, ca, degree)
+
+
 @pytest.mark.gpu
 def test_horner_large_hip():
     # 2^20 coefficients: multi-block reduction + host combine
