@@ -59,46 +59,61 @@ struct HornerParams {
     const uint64_t* qpoint;    // device: 3 words per query (Montgomery)
     uint64_t* partial;         // device: [nq][nblocks][3]
     size_t n;
-    unsigned nblocks;
+    unsigned nblocks, ngroups;
+    const uint32_t* group;     // device: [ngroups][2] = first query, number of queries (<= GQ, same column, adjacent)
 };
 // CW: words per coefficient (1 Fp, 3 Fq3); PW: words of the point field (PW >= CW)
 // Lane t of block b takes coefficients b*4096 + t + 256*k, k < 16 (a wave reads 64 consecutive
 // coefficients per load): Horner in y = x^256 gives A_t = sum_k c[t + 256k] y^k, and the block value
 // sum_t A_t x^t is folded pairwise through LDS with x^(2^l) at level l.
-template <int CW, int PW>
+// GQ: up to GQ queries on the SAME column (adjacent in the query list) form a group: the workgroup reads its 4096 coefficients once
+// and runs one Horner chain per query (independent chains, one load).
+template <int CW, int PW, int GQ>
 __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
     __shared__ uint64_t sh[NT * 3];
-    const unsigned q = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
-    const uint64_t* col = P.cols[P.qcol[q]];
-    const Q x = {{P.qpoint[3 * q], P.qpoint[3 * q + 1], P.qpoint[3 * q + 2]}};
-    Q xp[9];                                   // x^(2^l), l = 0..8 (wave-uniform)
-    xp[0] = x;
+    const unsigned g = blockIdx.x % P.ngroups, b = blockIdx.x / P.ngroups, t = threadIdx.x;
+    const unsigned q0 = P.group[2 * g], cnt = P.group[2 * g + 1];          // wave-uniform
+    const uint64_t* col = P.cols[P.qcol[q0]];
+    Q x[GQ], y[GQ], acc[GQ];                   // x, y = x^256 (wave-uniform values), the lane's running sums
     #pragma unroll
-    for (int l = 1; l <= 8; l++) xp[l] = q_mul<PW>(xp[l - 1], xp[l - 1]);
+    for (int j = 0; j < GQ; j++) {
+        const unsigned q = q0 + (j < (int)cnt ? j : 0);
+        x[j] = {{P.qpoint[3 * q], P.qpoint[3 * q + 1], P.qpoint[3 * q + 2]}};
+        y[j] = x[j];
+        #pragma unroll
+        for (int l = 0; l < 8; l++) y[j] = q_mul<PW>(y[j], y[j]);
+        acc[j] = q_zero<PW>();
+    }
     const size_t start = (size_t)b * 4096 + t;
-    Q acc = q_zero<PW>();
     #pragma unroll 4
     for (int k = 15; k >= 0; k--) {
         const size_t i = start + (size_t)k * NT;
         Q c = q_zero<PW>();
         if (i < P.n) c = q_load<CW>(col, i);
-        acc = q_add<PW>(q_mul<PW>(acc, xp[8]), c);
+        #pragma unroll
+        for (int j = 0; j < GQ; j++) acc[j] = q_add<PW>(q_mul<PW>(acc[j], y[j]), c);
     }
-    // combine: sum_t A_t x^t, pairwise: A_t += A_(t+step) * x^step
+    // combine per query: sum_t A_t x^t, pairwise: A_t += A_(t+step) * x^step
     #pragma unroll
-    for (unsigned l = 0; l < 8; l++) {
-        sh[3 * t] = acc.w[0]; sh[3 * t + 1] = acc.w[1]; sh[3 * t + 2] = acc.w[2];
-        __syncthreads();
-        const unsigned step = 1u << l;
-        if ((t & (2 * step - 1)) == 0) {
-            const Q other = {{sh[3 * (t + step)], sh[3 * (t + step) + 1], sh[3 * (t + step) + 2]}};
-            acc = q_add<PW>(acc, q_mul<PW>(other, xp[l]));
+    for (int j = 0; j < GQ; j++) {
+        if (j >= (int)cnt) break;
+        Q a = acc[j], xs = x[j];
+        #pragma unroll
+        for (unsigned l = 0; l < 8; l++) {
+            sh[3 * t] = a.w[0]; sh[3 * t + 1] = a.w[1]; sh[3 * t + 2] = a.w[2];
+            __syncthreads();
+            const unsigned step = 1u << l;
+            if ((t & (2 * step - 1)) == 0) {
+                const Q other = {{sh[3 * (t + step)], sh[3 * (t + step) + 1], sh[3 * (t + step) + 2]}};
+                a = q_add<PW>(a, q_mul<PW>(other, xs));
+            }
+            xs = q_mul<PW>(xs, xs);
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (t == 0) {
-        uint64_t* o = P.partial + ((size_t)q * P.nblocks + b) * 3;
-        o[0] = acc.w[0]; o[1] = acc.w[1]; o[2] = acc.w[2];
+        if (t == 0) {
+            uint64_t* o = P.partial + ((size_t)(q0 + j) * P.nblocks + b) * 3;
+            o[0] = a.w[0]; o[1] = a.w[1]; o[2] = a.w[2];
+        }
     }
 }
 

@@ -135,27 +135,39 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
     // device staging: qcol (u32), qpoints (3 words), partials
     std::vector<uint64_t> pts((size_t)nq * 3, 0);
     for (unsigned q = 0; q < nq; q++) memcpy(&pts[3 * q], (const uint64_t*)h_qpoints + (size_t)q * PW, PW * 8);
-    void *d_qcol = nullptr, *d_pts = nullptr, *d_part = nullptr;
+    // queries on the same column that follow one another (the callers list them per column) share one pass over the coefficients
+    constexpr unsigned GQ = 2;
+    std::vector<uint32_t> groups;
+    for (unsigned q = 0; q < nq; q++) {
+        if (!groups.empty() && groups[groups.size() - 1] < GQ && h_qcol[q] == h_qcol[q - 1]) groups[groups.size() - 1]++;
+        else { groups.push_back(q); groups.push_back(1); }
+    }
+    const unsigned ngroups = (unsigned)(groups.size() / 2);
+    void *d_qcol = nullptr, *d_pts = nullptr, *d_part = nullptr, *d_groups = nullptr;
     PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
     MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
+    MSCHK(pooled.alloc((size_t)ngroups * 8, &d_groups));
     MSCHK(pooled.alloc((size_t)nq * 24, &d_pts));
     MSCHK(pooled.alloc((size_t)nq * nblocks * 24, &d_part));
     std::vector<uint64_t> part((size_t)nq * nblocks * 3);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIPCHK(hipSetDevice(ctx->device));
-        HIPCHK(hipMemcpyAsync(d_qcol, h_qcol, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(d_pts, pts.data(), (size_t)nq * 24, hipMemcpyHostToDevice, ctx->stream));
+        MSCHK(stage_upload(ctx, d_qcol, h_qcol, (size_t)nq * 4));
+        MSCHK(stage_upload(ctx, d_groups, groups.data(), (size_t)ngroups * 8));
+        MSCHK(stage_upload(ctx, d_pts, pts.data(), (size_t)nq * 24));
         msdeep::HornerParams H;
         memset(&H, 0, sizeof H);
         for (unsigned c = 0; c < ncols; c++) H.cols[c] = (const uint64_t*)d_cols[c];
-        H.qcol = (const uint32_t*)d_qcol; H.qpoint = (const uint64_t*)d_pts; H.partial = (uint64_t*)d_part; H.n = n; H.nblocks = nblocks;
-        dim3 g(nblocks, nq);
+        H.qcol = (const uint32_t*)d_qcol; H.qpoint = (const uint64_t*)d_pts; H.partial = (uint64_t*)d_part; H.n = n; H.nblocks = nblocks; H.ngroups = ngroups;
+        H.group = (const uint32_t*)d_groups;
+        if ((uint64_t)nblocks * ngroups > 0x7FFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "too many (block, query group) pairs for one launch");
+        dim3 g(nblocks * ngroups);
         {
             ProfScope ps(ctx, "horner_blocks", 8.0 * CW * n * nq);
-            if (CW == 1 && PW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 1>), g, dim3(msdeep::NT), 0, ctx->stream, H);
-            else if (CW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 3>), g, dim3(msdeep::NT), 0, ctx->stream, H);
-            else hipLaunchKernelGGL((msdeep::horner_blocks<3, 3>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+            if (CW == 1 && PW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 1, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+            else if (CW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 3, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+            else hipLaunchKernelGGL((msdeep::horner_blocks<3, 3, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));

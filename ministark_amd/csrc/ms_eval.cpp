@@ -111,17 +111,18 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     // ---- program(s) + constants -> device
     const size_t mbytes = (size_t)main_n * sizeof(Instr), pbytes = (size_t)pro_n * sizeof(Instr), dbytes = (size_t)den_n * sizeof(Instr), cbytes = consts.size() * 8;
     const size_t poff = (mbytes + 15) & ~(size_t)15, doff = (poff + pbytes + 15) & ~(size_t)15, coff = (doff + dbytes + 15) & ~(size_t)15, total = coff + cbytes + 64;
-    HIPCHK(hipStreamSynchronize(ctx->stream));               // a previous evaluation may still read the buffer
     if (ctx->prog_bytes < total) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));           // a previous evaluation may still read the buffer that is about to go
         if (ctx->prog_buf) HIPCHK(hipFree(ctx->prog_buf));
         ctx->prog_buf = nullptr; ctx->prog_bytes = 0;
         if (hipMalloc(&ctx->prog_buf, total) != hipSuccess) return fail(MS_ERR_NOMEM, "program buffer");
         ctx->prog_bytes = total;
     }
-    HIPCHK(hipMemcpy(ctx->prog_buf, main_prog, mbytes, hipMemcpyHostToDevice));
-    if (pbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + poff, split.prologue.data(), pbytes, hipMemcpyHostToDevice));
-    if (dbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + doff, isplit.denom.data(), dbytes, hipMemcpyHostToDevice));
-    if (cbytes) HIPCHK(hipMemcpy((char*)ctx->prog_buf + coff, consts.data(), cbytes, hipMemcpyHostToDevice));
+    // stream-ordered copies out of the pinned ring: they queue behind a previous evaluation that still reads the buffer, no drain
+    MSCHK(stage_upload(ctx, ctx->prog_buf, main_prog, mbytes));
+    if (pbytes) MSCHK(stage_upload(ctx, (char*)ctx->prog_buf + poff, split.prologue.data(), pbytes));
+    if (dbytes) MSCHK(stage_upload(ctx, (char*)ctx->prog_buf + doff, isplit.denom.data(), dbytes));
+    if (cbytes) MSCHK(stage_upload(ctx, (char*)ctx->prog_buf + coff, consts.data(), cbytes));
     EvalParams E;
     memset(&E, 0, sizeof E);
     E.consts = (const uint64_t*)((char*)ctx->prog_buf + coff);
