@@ -268,8 +268,9 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         for (size_t t = 0; t < isplit.table_words.size(); t++) {
             const unsigned w = isplit.table_words[t];
             ProfScope ps(ctx, "eval_batch_inverse", 16.0 * w * n);
-            if (w == 1) hipLaunchKernelGGL((batch_inverse<msstage::FpT, 16>), dim3((unsigned)((n + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, tp, n);
-            else if (w == 3) hipLaunchKernelGGL((batch_inverse<msstage::Fq3T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
+            // Fp / Fq3: the stage's kernel, in place (it keeps the K values in registers: one read and one write of the table)
+            if (w == 1) hipLaunchKernelGGL((msstage::k_batch_inverse<msstage::FpT, 16>), dim3((unsigned)((n + msstage::NT * 16 - 1) / (msstage::NT * 16))), dim3(msstage::NT), 0, ctx->stream, tp, (const uint64_t*)tp, n);
+            else if (w == 3) hipLaunchKernelGGL((msstage::k_batch_inverse<msstage::Fq3T, 8>), dim3((unsigned)((n + msstage::NT * 8 - 1) / (msstage::NT * 8))), dim3(msstage::NT), 0, ctx->stream, tp, (const uint64_t*)tp, n);
             else if (n < ((size_t)1 << 16)) hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
             else {                                             // two levels: one 252-bit Fermat inverse per 64 elements
                 const unsigned blocks = (unsigned)(n / (NT * 8));
