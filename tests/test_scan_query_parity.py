@@ -84,6 +84,15 @@ def test_scan_rejects_bad_arguments_emu():
     assert L.ms_scan_affine(pl.handle, FP, 0, v.ptr, None, init.ctypes.data, 0, v.ptr) == 0
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_long_fp_column_takes_sixteen_rows_per_lane(kind):
+    # from 2^20 rows an Fp scan composes 16 consecutive rows per lane (the block's 4096 rows cross LDS once, coalesced both ways);
+    # ragged length, multipliers and addends, exclusive and inclusive
+    n = (1 << 20) + 4097
+    for inclusive in ((False, True) if kind == "hip" else (False,)):
+        _scan_case(kind, n, False, True, True, inclusive, seed=31 + inclusive, mask_every=5)
+
+
 @pytest.mark.gpu
 def test_running_product_2_22_hip():
     pl = backends.planner("hip")
