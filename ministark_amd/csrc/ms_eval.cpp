@@ -272,13 +272,13 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
             if (w == 1) hipLaunchKernelGGL((msstage::k_batch_inverse<msstage::FpT, 16>), dim3((unsigned)((n + msstage::NT * 16 - 1) / (msstage::NT * 16))), dim3(msstage::NT), 0, ctx->stream, tp, (const uint64_t*)tp, n);
             else if (w == 3) hipLaunchKernelGGL((msstage::k_batch_inverse<msstage::Fq3T, 8>), dim3((unsigned)((n + msstage::NT * 8 - 1) / (msstage::NT * 8))), dim3(msstage::NT), 0, ctx->stream, tp, (const uint64_t*)tp, n);
             else if (n < ((size_t)1 << 16)) hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
-            else {                                             // two levels: one 252-bit Fermat inverse per 64 elements
+            else {                                             // two levels: one 252-bit Fermat inverse per 128 elements
                 const unsigned blocks = (unsigned)(n / (NT * 8));
                 const size_t m = (size_t)blocks * NT;          // lanes of the sweep = entries of the product array
                 void* prod = nullptr;
                 MSCHK(pooled.alloc(m * 32, &prod));
                 hipLaunchKernelGGL((batch_inverse_up<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, n, (uint64_t*)prod);
-                hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((m + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
+                hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 16>), dim3((unsigned)((m + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);   // one Fermat inverse per 128 elements
                 hipLaunchKernelGGL((batch_inverse_down<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, n, (const uint64_t*)prod);
             }
             tp += (size_t)w * n;
