@@ -197,6 +197,22 @@ def fri_num_layers(n_lde, blowup, folding, max_remainder_coeffs):
     return layers
 
 
+_LOWERED = {}
+
+
+def _lowered(comp_expr, ncols):
+    """The register program of an AIR's composition constraint, lowered once per expression object (an AIR's constraints are fixed; the
+    C++ example compiles its program outside the proof loop as well).  Keyed by identity: the expression is kept alive by the entry."""
+    key = (id(comp_expr), ncols)
+    hit = _LOWERED.get(key)
+    if hit is None or hit[0] is not comp_expr:
+        if len(_LOWERED) > 16:
+            _LOWERED.clear()
+        hit = (comp_expr, E.compile_expr(comp_expr, ncols, False))
+        _LOWERED[key] = hit
+    return hit[1]
+
+
 def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_remainder_coeffs=64, grinding_bits=8, hash="sha256",
                  keep=False, ce_blowup=None):
     """trace: Matrix of Fp columns (2^k rows).  ce_blowup: the AIR's ce_blowup_factor (src/air.rs:55-59; the constraint
@@ -210,7 +226,7 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
     assert ce_blowup <= blowup                                                 # src/air.rs:149
     n_ce = n_t * ce_blowup
     trace_dom, lde_dom, ce_dom = Radix2EvaluationDomain(n_t), Radix2EvaluationDomain(n_lde, 7), Radix2EvaluationDomain(n_ce, 7)
-    prog = E.compile_expr(comp_expr, trace.num_cols(), False)
+    prog = _lowered(comp_expr, trace.num_cols())
     ch = np.array([gl_to_mont(c) for c in draws.challenges], dtype=np.uint64).reshape(-1, 1)
     hints = np.array([gl_to_mont(c) for c in draws.hints], dtype=np.uint64).reshape(-1, 1)
     out, phase = {}, {}
