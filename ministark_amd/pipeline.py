@@ -18,7 +18,8 @@ intermediate commitment can be compared (tests/test_pipeline_parity.py):
 What differs from a real run, on purpose: (i) the draws are fixed, so the proof-of-work seed is the last FRI root instead
 of the channel's running digest (the same SHA-256 search either way); (ii) traces are random columns, not valid executions
 (the data-parallel work does not depend on validity), so fri.rs:244's assertion that the remainder's high coefficients
-vanish is not made.  Proof serialisation and the channel's hashing of a few digests stay on the host in the reference too.
+vanish is not made; (iii) the composition constraint is lowered to its register program once per expression object, not once per proof
+(an AIR's constraints are fixed; `_lowered`).  Proof serialisation and the channel's hashing of a few digests stay on the host in the reference too.
 """
 import time
 
