@@ -28,9 +28,8 @@ extern "C" int ms_cols_to_rows_schedule(unsigned nranks, unsigned rank, unsigned
     return MS_OK;
 }
 
-#ifndef MS_EMU
 #include <dlfcn.h>
-#if __has_include(<rccl/rccl.h>)
+#if !defined(MS_EMU) && __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
 #else
 // A build host without the RCCL development headers (a single-GPU box) still builds the library: the few types and
@@ -61,10 +60,20 @@ std::mutex g_rccl_mu;
 int rccl_load() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.lib) return MS_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // MS_RCCL_LIB: a library exporting the same nine entry points (test hook: tests/emu/fake_rccl.cpp runs them between CPU
+    // processes over shared memory, so that the code below executes with more than one rank in the GPU-less container)
     void* h = nullptr;
-    for (const char* nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
-    if (!h) return fail(MS_ERR_UNSUPPORTED, "librccl.so.1 not found: %s", dlerror());
+    if (const char* override_path = getenv("MS_RCCL_LIB")) {
+        if (!(h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL))) return fail(MS_ERR_UNSUPPORTED, "MS_RCCL_LIB=%s: %s", override_path, dlerror());
+    } else {
+#ifdef MS_EMU
+        return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build (MS_RCCL_LIB names a stand-in)");
+#else
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!h) return fail(MS_ERR_UNSUPPORTED, "librccl.so.1 not found: %s", dlerror());
+#endif
+    }
     RcclApi a;
     a.lib = h;
 #define MS_SYM(field, name) do { *(void**)(&a.field) = dlsym(h, name); if (!a.field) return fail(MS_ERR_UNSUPPORTED, "librccl: missing symbol %s", name); } while (0)
@@ -187,12 +196,4 @@ extern "C" int ms_allgather_digests(ms_ctx* ctx, const void* d_my_digest32, void
     NCCLCHK(g_rccl.AllGather(d_my_digest32, d_all_digests, 32, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));
     return MS_OK;
 }
-#else   // the execution-model simulator of tests/emu has no RCCL: the exchange is exercised there through the mirror's test hook
-extern "C" int ms_comm_unique_id(void*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
-extern "C" int ms_comm_init(ms_ctx*, int, int, const void*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
-extern "C" int ms_comm_destroy(ms_ctx*) { return MS_OK; }
-extern "C" int ms_comm_rank(ms_ctx* ctx, int* rank, int* nranks) { if (rank) *rank = 0; if (nranks) *nranks = 1; (void)ctx; return MS_OK; }
-extern "C" int ms_cols_to_rows_alltoall(ms_ctx*, int, size_t, const void* const*, unsigned, unsigned, void* const*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
-extern "C" int ms_allgather_digests(ms_ctx*, const void*, void*) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
-extern "C" int ms_p2p_batch(ms_ctx*, const ms_p2p_op*, size_t) { return fail(MS_ERR_UNSUPPORTED, "RCCL is not part of the simulator build"); }
-#endif
+

@@ -13,7 +13,7 @@ import torch.distributed as dist  # noqa: E402
 def main():
     rank, world, port, kind, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo" if kind == "emu" else "nccl", rank=rank, world_size=world)
+    dist.init_process_group("nccl" if kind == "hip" else "gloo", rank=rank, world_size=world)
     from oracle import cref
     from tests import backends
     from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3
@@ -22,6 +22,10 @@ def main():
         from tests.gloo_comm import GlooComm
         pl = backends.planner("emu")
         comm = GlooComm(pl)
+    elif kind == "emu-rccl":                            # the PRODUCT's RcclComm / ms_comm_* / ms_cols_to_rows_alltoall / ms_p2p_batch /
+        pl = backends.planner("emu")                    # ms_allgather_digests on the simulator, NCCL stood in for by tests/emu/fake_rccl.cpp
+        assert os.environ.get("MS_RCCL_LIB"), "the launcher sets MS_RCCL_LIB"
+        comm = RcclComm.from_torch_distributed(pl)      # the communicator id travels over the gloo group
     else:                                               # one GPU per rank: the planner lives on LOCAL_RANK's device
         local = int(os.environ.get("LOCAL_RANK", rank))
         torch.cuda.set_device(local)

@@ -24,9 +24,21 @@ def build(force=False):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
-           "-Wno-unknown-pragmas", "-DMS_NO_JIT"] + srcs + ["-o", SO]
+           "-Wno-unknown-pragmas", "-DMS_NO_JIT"] + srcs + ["-o", SO, "-ldl"]
     subprocess.check_call(cmd)
     return SO
+
+
+def build_fake_rccl():
+    """tests/emu/fake_rccl.cpp -> _build/libfake_rccl.so: the NCCL entry points ms_comm.cpp binds, between CPU processes over
+    shared memory (MS_RCCL_LIB points the library at it)."""
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    so = os.path.join(HERE, "_build", "libfake_rccl.so")
+    if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
+        return so
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", so, "-lrt", "-pthread"])
+    return so
 
 
 if __name__ == "__main__":

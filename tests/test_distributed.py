@@ -37,6 +37,30 @@ def test_sharded_commit_matches_single_device_gloo(tmp_path, world):
         assert open(f).read().split("\n") == want
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_product_exchange_entry_points_with_more_than_one_rank(tmp_path, world):
+    """The same worker, but through the product's own communicator code: RcclComm -> ms_comm_init, ms_cols_to_rows_alltoall (the
+    schedule-driven send / receive group and the local copies), ms_p2p_batch (the shard exchange of the row-sharded evaluator) and
+    ms_allgather_digests, built into the simulator library and bound with dlsym exactly as on a GPU box -- only the nine NCCL entry
+    points themselves are a stand-in (tests/emu/fake_rccl.cpp: byte FIFOs between the processes, NCCL's matching and group rules)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    fake = build_emu.build_fake_rccl()
+    port = str(30100 + (os.getpid() % 400) + world)
+    procs, files = [], []
+    for r in range(world):
+        f = str(tmp_path / f"r{r}.txt")
+        files.append(f)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world), port, "emu-rccl", f],
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, MS_RCCL_LIB=fake)))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode()[-2000:]
+    want = _expected() + ["eval_ok"]
+    for f in files:
+        assert open(f).read().split("\n") == want
+
+
 @pytest.mark.gpu
 def test_rccl_entry_points_world1_hip():
     """The RCCL leg on the single-GPU lease, through the C ABI without torch: ncclGetUniqueId / ncclCommInitRank,
