@@ -10,14 +10,18 @@
 // (src/air.rs:50-82: degree adjustment X^adj alpha + beta per constraint; ce_blowup_factor = 1 for this AIR), evaluated on the
 // constraint-evaluation coset = the first n rows of the committed bit-reversed LDE; FRI ends with set_remainder and the layer
 // openings of into_proof.  Self-check (rows <= 2^18): over the whole 4n-point LDE coset the composition polynomial of a valid
-// trace has degree < n -- its upper 3n coefficients must vanish.
+// trace has degree < n -- its upper 3n coefficients must vanish.  At every size and on every repetition the two relations the
+// verifier enforces on the opened values are recomputed with host scalars: the constraints at z against the composition trace
+// at z^ce, and the DEEP composition at the 32 query positions against the first FRI layer.  `tamper` as the third argument
+// alters one opened value (ood = one out-of-domain evaluation, row = one queried trace cell) first: the run must then FAIL.
 //   build: g++ -O2 -std=c++17 examples/fib_prover.cpp ministark_amd/libministark_hip.so -Wl,-rpath,$PWD/ministark_amd -o fib_prover
-//   run:   ./fib_prover [log2(rows) = 21] [repetitions = 3]
+//   run:   ./fib_prover [log2(rows) = 21] [repetitions = 3] [tamper-ood | tamper-row]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <set>
+#include <string>
 #include "../ministark_amd/csrc/host/ministark.hpp"
 #include "../ministark_amd/csrc/host/stages.hpp"
 #include "../ministark_amd/csrc/host/expr.hpp"
@@ -32,6 +36,7 @@ static uint64_t splitmix(uint64_t& s) { s += 0x9E3779B97F4A7C15ull; uint64_t z =
 int main(int argc, char** argv) {
     const unsigned log_rows = argc > 1 ? (unsigned)atoi(argv[1]) : 21;
     const int reps = argc > 2 ? atoi(argv[2]) : 3;
+    const std::string tamper = argc > 3 ? argv[3] : "";
     const unsigned log_blowup = 2, fold = 8, num_queries = 32, grinding_bits = 8, max_remainder = 64;
     const size_t n = (size_t)1 << log_rows, N = n << log_blowup;
     Planner& pl = get_planner();
@@ -173,15 +178,49 @@ int main(int argc, char** argv) {
         std::set<size_t> uniq(positions.begin(), positions.end());
         std::vector<size_t> pos(uniq.begin(), uniq.end());
         size_t opened = 0;
+        std::vector<size_t> pos0; std::vector<uint64_t> rows0;
         for (size_t l = 0; l < layers.size(); l++) {          // fri_prover.into_proof(&query_positions): fri.rs:148-165
             pos = fold_positions(pos, fold);
             auto rows = fri_layer_rows(layers[l], fold, pos);
             auto view = trees[l].prove(pos);
             opened += rows.size() / fold + view.nodes.size();
+            if (l == 0) { pos0 = pos; rows0 = std::move(rows); }
         }
         ph[5] = ms_since(t);
         ph[6] = ms_since(all);
         if (q.base_trace_values.size() != positions.size() * 8 || ood.first.size() != args.size() || opened == 0) { printf("FAILED: query / OOD shapes\n"); return 1; }
+        // 7. what the verifier checks with these values, at every size and on every repetition (host scalars, outside the clock)
+        {
+            if (tamper == "tamper-ood") ood.first[5].c[0] = gl::add(ood.first[5].c[0], 1);
+            if (tamper == "tamper-row") q.base_trace_values[17 * 8 + 2] = gl::add(q.base_trace_values[17 * 8 + 2], 1);
+            // (i) the composition constraint at z from the opened trace values == sum_k z^k C_k(z^ce)          verifier.rs:106-128
+            std::vector<uint64_t> ch;
+            for (auto c : challenges) ch.push_back(gl::from_mont(c));
+            auto trace_at = [&](unsigned col, int off) { for (size_t k = 0; k < args.size(); k++) if (args[k].first == col && args[k].second == off) return ood.first[k].c[0]; throw std::runtime_error("trace argument not opened"); };
+            const uint64_t lhs = eval_at_point(comp.expr, z.c[0], n, trace_at, ch, {gl::from_mont(claimed)});
+            uint64_t rhs = 0;
+            for (unsigned k = ce; k-- > 0;) rhs = gl::add(gl::mul(rhs, z.c[0]), ood.second[k].c[0]);
+            if (lhs != rhs) { printf("FAILED: out-of-domain consistency (constraints at z vs composition trace at z^%u)\n", ce); return 1; }
+            // (ii) the DEEP composition at the query positions from the opened rows == the first FRI layer there   verifier.rs:146-190, composer.rs:201-258
+            const uint64_t w = lde_dom.group_gen, g = trace_dom.group_gen, z_n = gl::pow(z.c[0], ce);
+            for (size_t i = 0; i < positions.size(); i++) {
+                size_t p = positions[i], nat = 0;
+                for (unsigned b = 0; b < log_rows + log_blowup; b++) nat |= ((p >> b) & 1) << (log_rows + log_blowup - 1 - b);
+                const uint64_t x = gl::mul(7, gl::pow(w, nat));
+                uint64_t acc = 0;
+                for (size_t k = 0; k < args.size(); k++) {
+                    const uint64_t v = gl::from_mont(q.base_trace_values[i * 8 + args[k].first]), pt = gl::mul(z.c[0], gl::pow(g, (uint64_t)args[k].second));
+                    acc = gl::add(acc, gl::mul(dc.execution_trace[k].c[0], gl::mul(gl::sub(v, ood.first[k].c[0]), gl::inv(gl::sub(x, pt)))));
+                }
+                for (unsigned k = 0; k < ce; k++) {
+                    const uint64_t v = gl::from_mont(q.composition_trace_values[i * ce + k]);
+                    acc = gl::add(acc, gl::mul(dc.composition_trace[k].c[0], gl::mul(gl::sub(v, ood.second[k].c[0]), gl::inv(gl::sub(x, z_n)))));
+                }
+                acc = gl::mul(acc, gl::add(dc.degree[0].c[0], gl::mul(dc.degree[1].c[0], x)));
+                const size_t slot = std::lower_bound(pos0.begin(), pos0.end(), p / fold) - pos0.begin();
+                if (slot >= pos0.size() || pos0[slot] != p / fold || gl::from_mont(rows0[slot * fold + p % fold]) != acc) { printf("FAILED: DEEP composition at query %zu (position %zu)\n", i, p); return 1; }
+            }
+        }
         if (rep == 0) {
             printf("roots: base %02x%02x%02x%02x.. composition %02x%02x%02x%02x..  FRI layers %zu  remainder %zu coefficients  nonce %llu\n", base_root[0], base_root[1], base_root[2],
                    base_root[3], comp_root[0], comp_root[1], comp_root[2], comp_root[3], layers.size(), remainder.size(), (unsigned long long)nonce);

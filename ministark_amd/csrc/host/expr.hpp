@@ -220,6 +220,47 @@ inline Composition composition_constraint(size_t trace_len, const std::vector<E>
     return {comp, (unsigned)ce, (unsigned)(2 * constraints.size())};
 }
 
+// The verifier's side of the same DAG (src/verifier.rs:106-116: composition_constraint.graph_eval at the out-of-domain
+// point with the opened trace values): one scalar per node, host arithmetic, Fq = Fp AIRs.  All values canonical integers.
+// `trace_at(column, offset)` returns T_column(x g^offset).  Twenty lines of bookkeeping over gl::, so the C++ example can
+// check what the device produced against the relation the verifier enforces.
+template <class TraceAt>
+inline uint64_t eval_at_point(const E& root_expr, uint64_t x, size_t trace_len, TraceAt trace_at, const std::vector<uint64_t>& challenges, const std::vector<uint64_t>& hints) {
+    std::map<const Node*, uint64_t> val;
+    std::vector<std::pair<const Node*, bool>> stack{{root_expr.get(), false}};
+    while (!stack.empty()) {
+        auto [e, ready] = stack.back();
+        stack.pop_back();
+        if (val.count(e)) continue;
+        const Node* ka = e->a.get();
+        const Node* kb = e->b.get();
+        if (!ready && (ka || kb)) {
+            stack.push_back({e, true});
+            if (kb && !val.count(kb)) stack.push_back({kb, false});
+            if (ka && !val.count(ka)) stack.push_back({ka, false});
+            continue;
+        }
+        const uint64_t a = ka ? val.at(ka) : 0, b = kb ? val.at(kb) : 0;
+        uint64_t v = 0;
+        switch (e->kind) {
+        case K_X: v = x; break;
+        case K_CONST_P: v = e->v[0]; break;
+        case K_CHALLENGE: v = challenges.at(e->idx); break;
+        case K_HINT: v = hints.at(e->idx); break;
+        case K_TRACE: v = trace_at(e->idx, e->off); break;
+        case K_PERIODIC: { const uint64_t y = gl::pow(x, trace_len / e->idx); for (size_t i = e->coeffs.size(); i-- > 0;) v = gl::add(gl::mul(v, y), e->coeffs[i]); break; }
+        case K_NEG: v = gl::neg(a); break;
+        case K_ADD: v = gl::add(a, b); break;
+        case K_MUL: v = gl::mul(a, b); break;
+        case K_DIV: v = gl::mul(a, gl::inv(b)); break;
+        case K_POW: v = gl::pow(a, e->idx); break;
+        default: throw std::invalid_argument("eval_at_point: extension-field leaf in an Fq = Fp expression");
+        }
+        val[e] = v;
+    }
+    return val.at(root_expr.get());
+}
+
 // eval_periodic_column (src/eval_cpu.rs:233-256): evaluations of the column's polynomial on
 // coset(interval_size * blowup, offset^(trace_len / interval_size))
 inline GpuVec<Fp> periodic_lde(Planner& pl, const std::vector<uint64_t>& coeffs, uint32_t interval, uint64_t domain_offset, size_t trace_len, unsigned lde_step) {

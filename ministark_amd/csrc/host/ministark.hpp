@@ -39,6 +39,11 @@ constexpr uint64_t P = 0xFFFFFFFF00000001ull;
 inline uint64_t mul(uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % P); }
 inline uint64_t pow(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = mul(r, a); a = mul(a, a); e >>= 1; } return r; }
 inline uint64_t to_mont(uint64_t x) { return mul(x % P, 0xFFFFFFFFull); }
+inline uint64_t add(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % P); }
+inline uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+inline uint64_t sub(uint64_t a, uint64_t b) { return add(a, neg(b)); }
+inline uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+inline uint64_t from_mont(uint64_t m) { return mul(m, 0xFFFFFFFE00000001ull); }        // 2^-64 mod p
 }  // namespace gl
 
 class Planner {

@@ -65,6 +65,10 @@ def test_fib_prover_example_under_the_simulator():
         out = subprocess.run([exe, log_rows, "1"], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "fib prover pipeline ok" in out.stdout, out.stdout + out.stderr
         assert "ce_blowup_factor 1 -> 197 instructions" in out.stdout, out.stdout       # the same program as pipeline.fib_constraints
+    # the verifier relations recomputed inside the example are not vacuous: one altered opened value and the run fails
+    for how, what in (("tamper-ood", "out-of-domain consistency"), ("tamper-row", "DEEP composition at query 17")):
+        out = subprocess.run([exe, "10", "1", how], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 1 and "FAILED: " + what in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu
