@@ -4,7 +4,7 @@
 //
 //  * horner_blocks: out-of-domain evaluations P_c(x) for (column, point) queries.  One workgroup per
 //    4096 coefficients and query: lane t runs Horner in x^256 over coefficients t, t+256, ... (coalesced
-//    loads), the workgroup folds sum_t A_t x^t in LDS; the <= n/4096 block values are combined on the host.
+//    loads), the workgroup folds sum_t A_t x^t in LDS; the block values are combined on the host.
 //  * deep_points: the reference builds  Q(X) = sum_t alpha_t (P_ct(X) - P_ct(z_t)) / (X - z_t)  by synthetic
 //    division in coefficient space.  Q has degree <= n-2, so it is determined by its values on any n
 //    points: this kernel evaluates the sum at the n points of the coset offset*<w_n> from coset
@@ -56,11 +56,11 @@ template <int CW> __device__ __forceinline__ Q q_load(const uint64_t* col, size_
 struct HornerParams {
     const uint64_t* cols[MAXCOLS];
     const uint32_t* qcol;      // device: column of each query
-    const uint64_t* qpoint;    // device: 3 words per query (Montgomery)
     uint64_t* partial;         // device: [nq][nblocks][3]
     size_t n;
     unsigned nblocks, ngroups;
     const uint32_t* group;     // device: [ngroups][2] = first query, number of queries (<= GQ, same column, adjacent)
+    const uint64_t* qpow;      // device: [nq][9][3] = x^(2^l), l = 0..8, per query (the same for every lane: read, not recomputed)
 };
 // CW: words per coefficient (1 Fp, 3 Fq3); PW: words of the point field (PW >= CW)
 // Lane t of block b takes coefficients b*4096 + t + 256*k, k < 16 (a wave reads 64 consecutive
@@ -74,14 +74,12 @@ __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
     const unsigned g = blockIdx.x % P.ngroups, b = blockIdx.x / P.ngroups, t = threadIdx.x;
     const unsigned q0 = P.group[2 * g], cnt = P.group[2 * g + 1];          // wave-uniform
     const uint64_t* col = P.cols[P.qcol[q0]];
-    Q x[GQ], y[GQ], acc[GQ];                   // x, y = x^256 (wave-uniform values), the lane's running sums
+    Q y[GQ], acc[GQ];                          // y = x^256 (wave-uniform), the lane's running sums
+    const uint64_t* pw[GQ];
     #pragma unroll
     for (int j = 0; j < GQ; j++) {
-        const unsigned q = q0 + (j < (int)cnt ? j : 0);
-        x[j] = {{P.qpoint[3 * q], P.qpoint[3 * q + 1], P.qpoint[3 * q + 2]}};
-        y[j] = x[j];
-        #pragma unroll
-        for (int l = 0; l < 8; l++) y[j] = q_mul<PW>(y[j], y[j]);
+        pw[j] = P.qpow + (size_t)(q0 + (j < (int)cnt ? j : 0)) * 27;
+        y[j] = {{pw[j][24], pw[j][25], pw[j][26]}};
         acc[j] = q_zero<PW>();
     }
     const size_t start = (size_t)b * 4096 + t;
@@ -97,18 +95,19 @@ __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
     #pragma unroll
     for (int j = 0; j < GQ; j++) {
         if (j >= (int)cnt) break;
-        Q a = acc[j], xs = x[j];
+        Q a = acc[j];
         #pragma unroll
         for (unsigned l = 0; l < 8; l++) {
+            // levels 0..5 pair lanes of one wave (t and t + step < 64 apart): no workgroup barrier needed for those
             sh[3 * t] = a.w[0]; sh[3 * t + 1] = a.w[1]; sh[3 * t + 2] = a.w[2];
-            __syncthreads();
+            if (l < 6) gld::wave_lockstep(); else __syncthreads();
             const unsigned step = 1u << l;
             if ((t & (2 * step - 1)) == 0) {
                 const Q other = {{sh[3 * (t + step)], sh[3 * (t + step) + 1], sh[3 * (t + step) + 2]}};
+                const Q xs = {{pw[j][3 * l], pw[j][3 * l + 1], pw[j][3 * l + 2]}};            // x^(2^l)
                 a = q_add<PW>(a, q_mul<PW>(other, xs));
             }
-            xs = q_mul<PW>(xs, xs);
-            __syncthreads();
+            if (l < 6) gld::wave_lockstep(); else __syncthreads();
         }
         if (t == 0) {
             uint64_t* o = P.partial + ((size_t)(q0 + j) * P.nblocks + b) * 3;

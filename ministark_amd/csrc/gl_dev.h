@@ -273,4 +273,14 @@ MS_HD void dft16_pruned(uint64_t* x) {
     }
 }
 
+// "Every lane of this wave has executed the accesses above before any lane executes those below."  On the hardware that holds by
+// construction (a wave issues each instruction for all its lanes, in order, and its LDS / memory instructions execute in order),
+// so this is only a fence for the compiler's scheduler; the simulator of tests/emu runs the lanes one after the other between
+// barriers and needs a real one.
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+__device__ __forceinline__ void wave_lockstep() { __builtin_amdgcn_wave_barrier(); }
+#else
+inline void wave_lockstep() { __syncthreads(); }
+#endif
+
 }  // namespace gld

@@ -131,8 +131,9 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
     if (ncols > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per call", msdeep::MAXCOLS);
     if (nq == 0) return MS_OK;
     for (unsigned q = 0; q < nq; q++) if (h_qcol[q] >= ncols) return fail(MS_ERR_INVALID, "query %u names column %u of %u", q, h_qcol[q], ncols);
-    const unsigned nblocks = (unsigned)std::max<size_t>(1, (n + 4095) / 4096);
-    // device staging: qcol (u32), qpoints (3 words), partials
+    const unsigned log_block = 12;                                      // coefficients per workgroup (deep_kernels.h)
+    const unsigned nblocks = (unsigned)std::max<size_t>(1, (n + ((size_t)1 << log_block) - 1) >> log_block);
+    // device staging: qcol (u32), powers of the points, partials
     std::vector<uint64_t> pts((size_t)nq * 3, 0);
     for (unsigned q = 0; q < nq; q++) memcpy(&pts[3 * q], (const uint64_t*)h_qpoints + (size_t)q * PW, PW * 8);
     // queries on the same column that follow one another (the callers list them per column) share one pass over the coefficients
@@ -143,11 +144,21 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
         else { groups.push_back(q); groups.push_back(1); }
     }
     const unsigned ngroups = (unsigned)(groups.size() / 2);
-    void *d_qcol = nullptr, *d_pts = nullptr, *d_part = nullptr, *d_groups = nullptr;
+    // x^(2^l), l = 0..8, per query: every lane of every workgroup needs the same nine values
+    std::vector<uint64_t> pows((size_t)nq * 27);
+    for (unsigned q = 0; q < nq; q++) {
+        gl::Fq3 x = q3_load(&pts[3 * q], 3);
+        for (unsigned l = 0; l < 9; l++) {
+            uint64_t* o = &pows[(size_t)q * 27 + 3 * l];
+            o[0] = x.c0; o[1] = x.c1; o[2] = x.c2;
+            x = gl::mont_mul(x, x);
+        }
+    }
+    void *d_qcol = nullptr, *d_part = nullptr, *d_groups = nullptr, *d_pow = nullptr;
     PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
+    MSCHK(pooled.alloc(pows.size() * 8, &d_pow));
     MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
     MSCHK(pooled.alloc((size_t)ngroups * 8, &d_groups));
-    MSCHK(pooled.alloc((size_t)nq * 24, &d_pts));
     MSCHK(pooled.alloc((size_t)nq * nblocks * 24, &d_part));
     std::vector<uint64_t> part((size_t)nq * nblocks * 3);
     {
@@ -155,12 +166,12 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
         HIPCHK(hipSetDevice(ctx->device));
         MSCHK(stage_upload(ctx, d_qcol, h_qcol, (size_t)nq * 4));
         MSCHK(stage_upload(ctx, d_groups, groups.data(), (size_t)ngroups * 8));
-        MSCHK(stage_upload(ctx, d_pts, pts.data(), (size_t)nq * 24));
+        MSCHK(stage_upload(ctx, d_pow, pows.data(), pows.size() * 8));
         msdeep::HornerParams H;
         memset(&H, 0, sizeof H);
         for (unsigned c = 0; c < ncols; c++) H.cols[c] = (const uint64_t*)d_cols[c];
-        H.qcol = (const uint32_t*)d_qcol; H.qpoint = (const uint64_t*)d_pts; H.partial = (uint64_t*)d_part; H.n = n; H.nblocks = nblocks; H.ngroups = ngroups;
-        H.group = (const uint32_t*)d_groups;
+        H.qcol = (const uint32_t*)d_qcol; H.partial = (uint64_t*)d_part; H.n = n; H.nblocks = nblocks; H.ngroups = ngroups;
+        H.group = (const uint32_t*)d_groups; H.qpow = (const uint64_t*)d_pow;
         if ((uint64_t)nblocks * ngroups > 0x7FFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "too many (block, query group) pairs for one launch");
         dim3 g(nblocks * ngroups);
         {
@@ -173,10 +184,10 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
         HIPCHK(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    // combine the block values on the host: sum_b E_b * (x^4096)^b
+    // combine the block values on the host: sum_b E_b * (x^block)^b
     for (unsigned q = 0; q < nq; q++) {
         gl::Fq3 x = q3_load(&pts[3 * q], 3), xb = x;
-        for (int sq = 0; sq < 12; sq++) xb = gl::mont_mul(xb, xb);
+        for (unsigned sq = 0; sq < log_block; sq++) xb = gl::mont_mul(xb, xb);
         gl::Fq3 acc = {0, 0, 0};
         for (unsigned b = nblocks; b-- > 0;) acc = gl::add(gl::mont_mul(acc, xb), q3_load(&part[((size_t)q * nblocks + b) * 3], 3));
         uint64_t* o = (uint64_t*)h_out + (size_t)q * PW;

@@ -125,7 +125,10 @@ extern "C" int ms_rpo256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leave
     for (size_t count = nleaves / 2; count >= 1; count >>= 1) {
         uint64_t* dst = nodes + count * 4;
         ProfScope ps(ctx, "rpo256_merkle_level", 96.0 * count);
-        hipLaunchKernelGGL(msrpo::rpo256_merge_level, dim3((unsigned)((count + msrpo::NT - 1) / msrpo::NT)), dim3(msrpo::NT), 0, ctx->stream, src, dst, count);
+        if (count <= ((size_t)1 << 15))      // few nodes: sixteen lanes per node (latency of one element's chains, not of twelve)
+            hipLaunchKernelGGL(msrpo::rpo256_merge_level_wide, dim3((unsigned)((count + 3) / 4)), dim3(msrpo::NTW), 0, ctx->stream, src, dst, count);
+        else
+            hipLaunchKernelGGL(msrpo::rpo256_merge_level, dim3((unsigned)((count + msrpo::NT - 1) / msrpo::NT)), dim3(msrpo::NT), 0, ctx->stream, src, dst, count);
         src = dst;
     }
     HIPCHK(hipGetLastError());

@@ -127,14 +127,7 @@ __device__ __forceinline__ uint64_t pin(uint64_t x) { asm volatile("" : "+v"(x))
 MS_HD uint64_t pin(uint64_t x) { return x; }
 #endif
 
-// "Every lane of this wave has executed the loads above before any lane executes the stores below."  On the hardware that holds
-// by construction (a wave issues each instruction for all its lanes, in order), so this is only a fence for the compiler's
-// scheduler; the simulator of tests/emu runs the lanes one after the other between barriers and needs a real one.
-#if defined(__HIPCC__)
-__device__ __forceinline__ void wave_lockstep() { __builtin_amdgcn_wave_barrier(); }
-#else
-inline void wave_lockstep() { __syncthreads(); }
-#endif
+using gld::wave_lockstep;
 
 // run index g of a middle pass (log_s = 8) -> block U of R rows and the run q of 64 words inside a row of 256 V words.  PERM kernels
 // are V = 1 (four runs per row): shifts; otherwise one uniform division by the run count 4 V

@@ -198,4 +198,40 @@ static __global__ void __launch_bounds__(NT) rpo256_merge_level(const uint64_t* 
     o[0] = st.s[4]; o[1] = st.s[5]; o[2] = st.s[6]; o[3] = st.s[7];
 }
 
+// The upper levels of a tree: a level of `count` nodes on one lane each takes one permutation's latency (~230 us: 7 rounds of
+// 76 dependent-chain steps on 12 elements) however few nodes it has -- the 16 levels of <= 2^15 nodes were 5 of the 12.5 ms of a
+// 2^20-leaf commitment.  Here SIXTEEN lanes share a node: lane j < 12 owns state element j, runs its S-box chains alone (76 products
+// per round instead of 12 x 76) and the two MDS products of a round gather the twelve elements through LDS (one 8-byte write, twelve
+// reads, the lane's own rotation of the circulant row in registers).  Same integer arithmetic per element as `permute`: same digests.
+static constexpr int NTW = 64;           // one wave: four nodes
+__device__ __forceinline__ uint64_t mds_wide(uint64_t s, uint64_t* sh, unsigned j, bool owner, const uint32_t* row) {
+    if (owner) sh[j] = s;
+    __syncthreads();
+    unsigned __int128 acc = 0;
+    #pragma unroll
+    for (int n = 0; n < 12; n++) acc += (unsigned __int128)sh[n] * row[n];
+    __syncthreads();
+    return gl::reduce128((uint64_t)acc, (uint64_t)(acc >> 64));
+}
+static __global__ void __launch_bounds__(NTW) rpo256_merge_level_wide(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t count) {
+    __shared__ uint64_t sh_all[NTW / 16][12];
+    const unsigned g = threadIdx.x / 16, j16 = threadIdx.x % 16;
+    const bool owner = j16 < 12;
+    const unsigned j = owner ? j16 : j16 - 12;                       // the four spare lanes shadow elements 0..3 (results unused)
+    const size_t i = (size_t)blockIdx.x * (NTW / 16) + g;
+    const bool live = i < count;
+    uint32_t row[12];
+    #pragma unroll
+    for (int n = 0; n < 12; n++) row[n] = MDS_ROW[(n + 12 - j) % 12];
+    uint64_t s = (live && j16 >= 4 && owner) ? src[8 * i + (j16 - 4)] : 0;
+    uint64_t* sh = sh_all[g];
+    for (int r = 0; r < 7; r++) {
+        s = mds_wide(s, sh, j, owner, row);
+        s = pow7(gl::add(s, RC0[r * 12 + j]));
+        s = mds_wide(s, sh, j, owner, row);
+        s = pow_inv7(gl::add(s, RC1[r * 12 + j]));
+    }
+    if (live && j16 >= 4 && j16 < 8) dst[4 * i + (j16 - 4)] = s;
+}
+
 }  // namespace msrpo

@@ -85,10 +85,10 @@ def test_deep_points_share_one_inversion_across_points(kind, ext):
     assert _canon_col(out, ext) == pydeep.into_deep_poly(z, g, g_inv, args, base, extp, comp, ea, ca, degree)
 
 
-@pytest.mark.gpu
-def test_horner_large_hip():
-    # 2^20 coefficients: multi-block reduction + host combine
-    pl = backends.planner("hip")
+@pytest.mark.parametrize("kind", KINDS)
+def test_horner_large(kind):
+    # 2^20 coefficients: blocks of 16384 coefficients (64 per lane), multi-block reduction + host combine
+    pl = backends.planner(kind)
     rng = np.random.default_rng(1)
     n = 1 << 20
     col = rng.integers(0, P, size=n, dtype=np.uint64)

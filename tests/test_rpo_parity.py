@@ -141,3 +141,28 @@ def test_fri_layer_commitment_over_rpo(kind):
     want_leaves = [pyrpo.hash_row([GL.from_mont(int(x)) for x in ev[r * ff * 3:(r + 1) * ff * 3]]) for r in range(rows)]
     want_nodes = pyrpo.merkle_nodes(want_leaves)
     assert _canon(np.frombuffer(tree.root(), dtype=np.uint64)) == want_nodes[1]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_tall_tree_uses_both_merge_kernels(kind):
+    """2^17 leaves: the levels of more than 2^15 nodes run one lane per node, the rest sixteen lanes per node (rpo_kernels.h);
+    every level is sampled against the oracle's merge of the two children the device holds, and the nodes above the level of 2^15
+    are rebuilt as a tree of their own -- same digests."""
+    pl = backends.planner(kind)
+    n = 1 << 17 if kind == "hip" else 64                    # (the simulator only checks the bookkeeping of this test)
+    leaves = GpuVec.from_numpy(pl, cref.random_elements(n * 4, 77))
+    nodes = gen_rpo_merkle_tree(leaves).to_numpy().reshape(n, 4)
+    lv = leaves.to_numpy().reshape(n, 4)
+    rng = np.random.default_rng(5)
+    count = n // 2
+    while count >= 1:
+        for i in set(int(x) for x in rng.integers(0, count, size=6)):
+            k = count + i                                   # node k = merge(children 2k, 2k + 1); the leaves sit under level n/2
+            left, right = (lv[2 * i], lv[2 * i + 1]) if count == n // 2 else (nodes[2 * k], nodes[2 * k + 1])
+            assert _canon(nodes[k]) == pyrpo.merge(_canon(left), _canon(right)), (count, i)
+        count //= 2
+    # the level of n/4 nodes as the leaves of a tree of its own: everything above it must come out the same
+    q = n // 4
+    sub = GpuVec.from_numpy(pl, nodes[q:2 * q].reshape(-1).copy())
+    sub_nodes = gen_rpo_merkle_tree(sub).to_numpy().reshape(q, 4)
+    assert np.array_equal(sub_nodes[1:], nodes[1:q])
