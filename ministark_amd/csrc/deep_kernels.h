@@ -60,57 +60,120 @@ struct HornerParams {
     size_t n;
     unsigned nblocks, ngroups;
     const uint32_t* group;     // device: [ngroups][2] = first query, number of queries (<= GQ, same column, adjacent)
-    const uint64_t* qpow;      // device: [nq][9][3] = x^(2^l), l = 0..8, per query (the same for every lane: read, not recomputed)
+    // host-built tables per query (the same for every lane of the launch: wave-uniform loads); Montgomery form, 3 words each
+    const uint64_t* ypow;      // [nq][16]: (x^256)^k          the factor of a lane's k-th coefficient
+    const uint32_t* ylimb;     // [nq][16][3 words][4]: 22 / 22 / 20-bit limbs of ypow's words (Fp coefficient columns)
+    const uint64_t* xlo;       // [nq][16]: x^i                 x^t = xlo[t & 15] xhi[t >> 4], the lane's weight in the block
+    const uint64_t* xhi;       // [nq][16]: x^(16 i)
+    // second level: the block values of the level below are the coefficients (3 words each), query q reads its own row of them
+    const uint64_t* self_src;  // [nq][self_nblocks][3] or null
+    unsigned self_nblocks;
 };
+// (ov 2^128 + hi 2^64 + lo) 2^-64 mod p, canonical: the Montgomery reduction of the low 128 bits (felt_u64.h.metal:165-177 as in
+// gl::mont_mul) with hi brought below p first, plus ov 2^64 = ov (2^32 - 1)
+__device__ __forceinline__ uint64_t reduce_132(uint64_t lo, uint64_t hi, uint32_t top) {
+    const uint64_t xl = lo, xh = hi >= gl::P ? hi - gl::P : hi;
+    const uint64_t s = xl + (xl << 32);
+    const uint64_t ov = s < xl;
+    const uint64_t bb = s - (s >> 32) - ov;
+    const uint64_t r = xh - bb;
+    return gl::add((xh < bb) ? r + gl::P : r, (uint64_t)top * 0xFFFFFFFFull);
+}
+// sum_k c_k Y_k for sixteen Fp coefficients and wave-uniform factors, without a single carry: c = c0 + 2^32 c1, Y = y0 + 2^22 y1 + 2^44 y2
+// (22 / 22 / 20 bits), six columns S[3 i + j] += c_i y_j of 54-bit products -- sixteen of them stay below 2^58 --, one
+// v_mad_u64_u32 each; the columns are put together (< 2^134) and reduced once.
+__device__ __forceinline__ void limb_mac(uint64_t* S, uint64_t c, const uint32_t* y) {
+    const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
+    S[0] += (uint64_t)c0 * y[0]; S[1] += (uint64_t)c0 * y[1]; S[2] += (uint64_t)c0 * y[2];
+    S[3] += (uint64_t)c1 * y[0]; S[4] += (uint64_t)c1 * y[1]; S[5] += (uint64_t)c1 * y[2];
+}
+__device__ __forceinline__ uint64_t limb_sum_reduce(const uint64_t* S) {
+    typedef unsigned __int128 u128;
+    const u128 low = (u128)S[0] + ((u128)S[1] << 22) + ((u128)S[2] << 44) + ((u128)S[3] << 32) + ((u128)S[4] << 54);   // < 2^113
+    const u128 top = (u128)(S[5] & ((1ull << 52) - 1)) << 76;
+    const u128 sum = low + top;
+    const uint32_t over = (uint32_t)(S[5] >> 52) + (sum < top ? 1u : 0u);
+    return reduce_132((uint64_t)sum, (uint64_t)(sum >> 64), over);
+}
 // CW: words per coefficient (1 Fp, 3 Fq3); PW: words of the point field (PW >= CW)
-// Lane t of block b takes coefficients b*4096 + t + 256*k, k < 16 (a wave reads 64 consecutive
-// coefficients per load): Horner in y = x^256 gives A_t = sum_k c[t + 256k] y^k, and the block value
-// sum_t A_t x^t is folded pairwise through LDS with x^(2^l) at level l.
-// GQ: up to GQ queries on the SAME column (adjacent in the query list) form a group: the workgroup reads its 4096 coefficients once
-// and runs one Horner chain per query (independent chains, one load).
+// Lane t of block b takes coefficients b*4096 + t + 256*k, k < 16 (a wave reads 64 consecutive coefficients per load):
+// A_t = sum_k c[t + 256k] y^k with y = x^256, and the block value is sum_t A_t x^t: every lane weights its A_t with x^t (two table
+// factors) and the 256 values are ADDED up through LDS (the last five levels inside one wave).
+// Fp coefficients (CW = 1): A_t per component of the point field is limb_mac / limb_sum_reduce above: 6 multiply-adds per coefficient,
+// component and query instead of a dependent modular product (nine for an Fq3 point).  Fq3 coefficients (the block values of the
+// level below, extension columns) run the Horner chain in y.
+// GQ: up to GQ queries on the SAME column (adjacent in the query list) form a group: the workgroup reads its 4096 coefficients once.
 template <int CW, int PW, int GQ>
 __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
     __shared__ uint64_t sh[NT * 3];
     const unsigned g = blockIdx.x % P.ngroups, b = blockIdx.x / P.ngroups, t = threadIdx.x;
     const unsigned q0 = P.group[2 * g], cnt = P.group[2 * g + 1];          // wave-uniform
-    const uint64_t* col = P.cols[P.qcol[q0]];
-    Q y[GQ], acc[GQ];                          // y = x^256 (wave-uniform), the lane's running sums
-    const uint64_t* pw[GQ];
+    const uint64_t* col = P.self_src ? P.self_src + (size_t)q0 * P.self_nblocks * 3 : P.cols[P.qcol[q0]];
+    unsigned qj[GQ];
     #pragma unroll
-    for (int j = 0; j < GQ; j++) {
-        pw[j] = P.qpow + (size_t)(q0 + (j < (int)cnt ? j : 0)) * 27;
-        y[j] = {{pw[j][24], pw[j][25], pw[j][26]}};
-        acc[j] = q_zero<PW>();
-    }
+    for (int j = 0; j < GQ; j++) qj[j] = q0 + (j < (int)cnt ? j : 0);
+    Q acc[GQ];
     const size_t start = (size_t)b * 4096 + t;
-    #pragma unroll 4
-    for (int k = 15; k >= 0; k--) {
-        const size_t i = start + (size_t)k * NT;
-        Q c = q_zero<PW>();
-        if (i < P.n) c = q_load<CW>(col, i);
+    if constexpr (CW == 1) {
+        uint64_t S[GQ][PW][6];
         #pragma unroll
-        for (int j = 0; j < GQ; j++) acc[j] = q_add<PW>(q_mul<PW>(acc[j], y[j]), c);
+        for (int j = 0; j < GQ; j++) {
+            #pragma unroll
+            for (int w = 0; w < PW; w++) {
+                #pragma unroll
+                for (int i = 0; i < 6; i++) S[j][w][i] = 0;
+            }
+        }
+        #pragma unroll 4
+        for (int k = 0; k < 16; k++) {
+            const size_t i = start + (size_t)k * NT;
+            const uint64_t c = i < P.n ? col[i] : 0;
+            #pragma unroll
+            for (int j = 0; j < GQ; j++) {
+                #pragma unroll
+                for (int w = 0; w < PW; w++) limb_mac(S[j][w], c, P.ylimb + (((size_t)qj[j] * 16 + k) * 3 + w) * 4);
+            }
+        }
+        #pragma unroll
+        for (int j = 0; j < GQ; j++) {
+            acc[j] = q_zero<PW>();
+            #pragma unroll
+            for (int w = 0; w < PW; w++) acc[j].w[w] = limb_sum_reduce(S[j][w]);
+        }
+    } else {
+        Q y[GQ];
+        #pragma unroll
+        for (int j = 0; j < GQ; j++) {
+            const uint64_t* yp = P.ypow + ((size_t)qj[j] * 16 + 1) * 3;
+            y[j] = {{yp[0], yp[1], yp[2]}};
+            acc[j] = q_zero<PW>();
+        }
+        #pragma unroll 4
+        for (int k = 15; k >= 0; k--) {
+            const size_t i = start + (size_t)k * NT;
+            Q c = q_zero<PW>();
+            if (i < P.n) c = q_load<CW>(col, i);
+            #pragma unroll
+            for (int j = 0; j < GQ; j++) acc[j] = q_add<PW>(q_mul<PW>(acc[j], y[j]), c);
+        }
     }
-    // combine per query: sum_t A_t x^t, pairwise: A_t += A_(t+step) * x^step
+    // per query: sum_t A_t x^t
     #pragma unroll
     for (int j = 0; j < GQ; j++) {
         if (j >= (int)cnt) break;
-        Q a = acc[j];
+        if (j > 0) __syncthreads();                 // the previous query's last levels may still be reading
+        const uint64_t* lo = P.xlo + ((size_t)qj[j] * 16 + (t & 15)) * 3;
+        const uint64_t* hi = P.xhi + ((size_t)qj[j] * 16 + (t >> 4)) * 3;
+        Q a = q_mul<PW>(acc[j], q_mul<PW>(Q{{lo[0], lo[1], lo[2]}}, Q{{hi[0], hi[1], hi[2]}}));
+        // level s: lanes t < 2 s hold values, lanes t < s add the value of lane t + s.  s = 128, 64 cross waves; from 32 on wave 0 alone
         #pragma unroll
-        for (unsigned l = 0; l < 8; l++) {
-            // levels 0..5 pair lanes of one wave (t and t + step < 64 apart): no workgroup barrier needed for those
-            sh[3 * t] = a.w[0]; sh[3 * t + 1] = a.w[1]; sh[3 * t + 2] = a.w[2];
-            if (l < 6) gld::wave_lockstep(); else __syncthreads();
-            const unsigned step = 1u << l;
-            if ((t & (2 * step - 1)) == 0) {
-                const Q other = {{sh[3 * (t + step)], sh[3 * (t + step) + 1], sh[3 * (t + step) + 2]}};
-                const Q xs = {{pw[j][3 * l], pw[j][3 * l + 1], pw[j][3 * l + 2]}};            // x^(2^l)
-                a = q_add<PW>(a, q_mul<PW>(other, xs));
-            }
-            if (l < 6) gld::wave_lockstep(); else __syncthreads();
+        for (unsigned s_ = NT / 2; s_ >= 1; s_ >>= 1) {
+            if (t < 2 * s_) { sh[3 * t] = a.w[0]; sh[3 * t + 1] = a.w[1]; sh[3 * t + 2] = a.w[2]; }
+            if (s_ >= 64) __syncthreads(); else gld::wave_lockstep();
+            if (t < s_) a = q_add<PW>(a, Q{{sh[3 * (t + s_)], sh[3 * (t + s_) + 1], sh[3 * (t + s_) + 2]}});
         }
         if (t == 0) {
-            uint64_t* o = P.partial + ((size_t)(q0 + j) * P.nblocks + b) * 3;
+            uint64_t* o = P.partial + ((size_t)qj[j] * P.nblocks + b) * 3;
             o[0] = a.w[0]; o[1] = a.w[1]; o[2] = a.w[2];
         }
     }

@@ -131,69 +131,100 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
     if (ncols > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per call", msdeep::MAXCOLS);
     if (nq == 0) return MS_OK;
     for (unsigned q = 0; q < nq; q++) if (h_qcol[q] >= ncols) return fail(MS_ERR_INVALID, "query %u names column %u of %u", q, h_qcol[q], ncols);
-    const unsigned log_block = 12;                                      // coefficients per workgroup (deep_kernels.h)
-    const unsigned nblocks = (unsigned)std::max<size_t>(1, (n + ((size_t)1 << log_block) - 1) >> log_block);
-    // device staging: qcol (u32), powers of the points, partials
-    std::vector<uint64_t> pts((size_t)nq * 3, 0);
-    for (unsigned q = 0; q < nq; q++) memcpy(&pts[3 * q], (const uint64_t*)h_qpoints + (size_t)q * PW, PW * 8);
     // queries on the same column that follow one another (the callers list them per column) share one pass over the coefficients
     constexpr unsigned GQ = 2;
-    std::vector<uint32_t> groups;
+    std::vector<uint32_t> groups, singles;
     for (unsigned q = 0; q < nq; q++) {
         if (!groups.empty() && groups[groups.size() - 1] < GQ && h_qcol[q] == h_qcol[q - 1]) groups[groups.size() - 1]++;
         else { groups.push_back(q); groups.push_back(1); }
+        singles.push_back(q); singles.push_back(1);
     }
-    const unsigned ngroups = (unsigned)(groups.size() / 2);
-    // x^(2^l), l = 0..8, per query: every lane of every workgroup needs the same nine values
-    std::vector<uint64_t> pows((size_t)nq * 27);
+    // Levels: blocks of 4096 coefficients -> one value each (deep_kernels.h); those values are the coefficients of a polynomial in
+    // x^4096, evaluated the same way by the next level (one row of block values per query) until one value per query is left --
+    // nothing is combined on the host (17 queries x 1024 blocks of dependent products there cost more than the kernel).
+    std::vector<size_t> level_n;
+    for (size_t m = n;; m = (m + 4095) >> 12) { level_n.push_back(m); if (m <= 4096) break; }
+    const unsigned nlevels = (unsigned)level_n.size();
+    // per level and query, for the level's point p = x^(4096^level): p^i and p^(16 i), i < 16 (a lane's weight p^t), and (p^256)^k,
+    // k < 16 (the factor of a lane's k-th coefficient), the latter also as 22 / 22 / 20-bit limbs for Fp coefficient columns.
+    // Fp points stay scalars here: these are dependent products on the host.
+    auto mulq = [PW](const gl::Fq3& a, const gl::Fq3& b) { return PW == 1 ? gl::Fq3{gl::mont_mul(a.c0, b.c0), 0, 0} : gl::mont_mul(a, b); };
+    const size_t per_level = (size_t)nq * 48;
+    std::vector<uint64_t> xlo(per_level * nlevels), xhi(per_level * nlevels), ypow(per_level * nlevels);
+    std::vector<uint32_t> ylimb((size_t)nq * 16 * 3 * 4, 0);                 // level 0 only
     for (unsigned q = 0; q < nq; q++) {
-        gl::Fq3 x = q3_load(&pts[3 * q], 3);
-        for (unsigned l = 0; l < 9; l++) {
-            uint64_t* o = &pows[(size_t)q * 27 + 3 * l];
-            o[0] = x.c0; o[1] = x.c1; o[2] = x.c2;
-            x = gl::mont_mul(x, x);
+        gl::Fq3 pnt = q3_load((const uint64_t*)h_qpoints + (size_t)q * PW, PW);
+        for (unsigned l = 0; l < nlevels; l++) {
+            uint64_t* lo = &xlo[per_level * l + (size_t)q * 48];
+            uint64_t* hi = &xhi[per_level * l + (size_t)q * 48];
+            uint64_t* yp = &ypow[per_level * l + (size_t)q * 48];
+            auto fill = [&](uint64_t* out, const gl::Fq3& base) {           // out[i] = base^i, i < 16; returns base^16
+                gl::Fq3 cur = {gl::ONE_MONT, 0, 0};
+                for (unsigned i = 0; i < 16; i++) { out[3 * i] = cur.c0; out[3 * i + 1] = cur.c1; out[3 * i + 2] = cur.c2; cur = mulq(cur, base); }
+                return cur;
+            };
+            const gl::Fq3 p16 = fill(lo, pnt), p256 = fill(hi, p16);
+            pnt = fill(yp, p256);                                           // (p^256)^16 = p^4096: the next level's point
+            if (l == 0 && CW == 1)
+                for (unsigned i = 0; i < 48; i++) {
+                    uint32_t* o = &ylimb[((size_t)q * 48 + i) * 4];
+                    o[0] = (uint32_t)(yp[i] & 0x3FFFFF); o[1] = (uint32_t)((yp[i] >> 22) & 0x3FFFFF); o[2] = (uint32_t)(yp[i] >> 44);
+                }
         }
     }
-    void *d_qcol = nullptr, *d_part = nullptr, *d_groups = nullptr, *d_pow = nullptr;
+    std::vector<unsigned> level_blocks(nlevels);
+    size_t part_words = 0;
+    for (unsigned l = 0; l < nlevels; l++) { level_blocks[l] = (unsigned)std::max<size_t>(1, (level_n[l] + 4095) >> 12); part_words += (size_t)nq * level_blocks[l] * 3; }
+    const unsigned ngroups = (unsigned)(groups.size() / 2);
+    if ((uint64_t)level_blocks[0] * ngroups > 0x7FFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "too many (block, query group) pairs for one launch");
+    void *d_qcol = nullptr, *d_part = nullptr, *d_groups = nullptr, *d_singles = nullptr, *d_xlo = nullptr, *d_xhi = nullptr, *d_ypow = nullptr, *d_ylimb = nullptr;
     PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
-    MSCHK(pooled.alloc(pows.size() * 8, &d_pow));
     MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
-    MSCHK(pooled.alloc((size_t)ngroups * 8, &d_groups));
-    MSCHK(pooled.alloc((size_t)nq * nblocks * 24, &d_part));
-    std::vector<uint64_t> part((size_t)nq * nblocks * 3);
+    MSCHK(pooled.alloc(groups.size() * 4, &d_groups));
+    MSCHK(pooled.alloc(singles.size() * 4, &d_singles));
+    MSCHK(pooled.alloc(xlo.size() * 8, &d_xlo));
+    MSCHK(pooled.alloc(xhi.size() * 8, &d_xhi));
+    MSCHK(pooled.alloc(ypow.size() * 8, &d_ypow));
+    MSCHK(pooled.alloc(ylimb.size() * 4, &d_ylimb));
+    MSCHK(pooled.alloc(part_words * 8, &d_part));
+    std::vector<uint64_t> res((size_t)nq * 3);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIPCHK(hipSetDevice(ctx->device));
         MSCHK(stage_upload(ctx, d_qcol, h_qcol, (size_t)nq * 4));
-        MSCHK(stage_upload(ctx, d_groups, groups.data(), (size_t)ngroups * 8));
-        MSCHK(stage_upload(ctx, d_pow, pows.data(), pows.size() * 8));
-        msdeep::HornerParams H;
-        memset(&H, 0, sizeof H);
-        for (unsigned c = 0; c < ncols; c++) H.cols[c] = (const uint64_t*)d_cols[c];
-        H.qcol = (const uint32_t*)d_qcol; H.partial = (uint64_t*)d_part; H.n = n; H.nblocks = nblocks; H.ngroups = ngroups;
-        H.group = (const uint32_t*)d_groups; H.qpow = (const uint64_t*)d_pow;
-        if ((uint64_t)nblocks * ngroups > 0x7FFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "too many (block, query group) pairs for one launch");
-        dim3 g(nblocks * ngroups);
-        {
-            ProfScope ps(ctx, "horner_blocks", 8.0 * CW * n * nq);
-            if (CW == 1 && PW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 1, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
-            else if (CW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 3, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
-            else hipLaunchKernelGGL((msdeep::horner_blocks<3, 3, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+        MSCHK(stage_upload(ctx, d_groups, groups.data(), groups.size() * 4));
+        MSCHK(stage_upload(ctx, d_singles, singles.data(), singles.size() * 4));
+        MSCHK(stage_upload(ctx, d_xlo, xlo.data(), xlo.size() * 8));
+        MSCHK(stage_upload(ctx, d_xhi, xhi.data(), xhi.size() * 8));
+        MSCHK(stage_upload(ctx, d_ypow, ypow.data(), ypow.size() * 8));
+        MSCHK(stage_upload(ctx, d_ylimb, ylimb.data(), ylimb.size() * 4));
+        uint64_t* part = (uint64_t*)d_part;
+        const uint64_t* below = nullptr;
+        for (unsigned l = 0; l < nlevels; l++) {
+            msdeep::HornerParams H;
+            memset(&H, 0, sizeof H);
+            if (l == 0) for (unsigned c = 0; c < ncols; c++) H.cols[c] = (const uint64_t*)d_cols[c];
+            H.qcol = (const uint32_t*)d_qcol; H.partial = part; H.n = level_n[l]; H.nblocks = level_blocks[l];
+            H.ngroups = l == 0 ? ngroups : nq; H.group = (const uint32_t*)(l == 0 ? d_groups : d_singles);
+            H.xlo = (const uint64_t*)d_xlo + per_level * l; H.xhi = (const uint64_t*)d_xhi + per_level * l; H.ypow = (const uint64_t*)d_ypow + per_level * l;
+            H.ylimb = (const uint32_t*)d_ylimb;
+            H.self_src = below; H.self_nblocks = l ? level_blocks[l - 1] : 0;
+            const dim3 g(H.nblocks * H.ngroups);
+            {
+                ProfScope ps(ctx, "horner_blocks", l == 0 ? 8.0 * CW * n * nq : 24.0 * level_n[l] * nq);
+                if (l > 0) hipLaunchKernelGGL((msdeep::horner_blocks<3, 3, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);       // block values: 3 words each
+                else if (CW == 1 && PW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 1, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+                else if (CW == 1) hipLaunchKernelGGL((msdeep::horner_blocks<1, 3, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+                else hipLaunchKernelGGL((msdeep::horner_blocks<3, 3, GQ>), g, dim3(msdeep::NT), 0, ctx->stream, H);
+            }
+            HIPCHK(hipGetLastError());
+            below = part;
+            part += (size_t)nq * level_blocks[l] * 3;
         }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(res.data(), below, res.size() * 8, hipMemcpyDeviceToHost, ctx->stream));   // the last level: one block per query
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    // combine the block values on the host: sum_b E_b * (x^block)^b
-    for (unsigned q = 0; q < nq; q++) {
-        gl::Fq3 x = q3_load(&pts[3 * q], 3), xb = x;
-        for (unsigned sq = 0; sq < log_block; sq++) xb = gl::mont_mul(xb, xb);
-        gl::Fq3 acc = {0, 0, 0};
-        for (unsigned b = nblocks; b-- > 0;) acc = gl::add(gl::mont_mul(acc, xb), q3_load(&part[((size_t)q * nblocks + b) * 3], 3));
-        uint64_t* o = (uint64_t*)h_out + (size_t)q * PW;
-        o[0] = acc.c0;
-        if (PW == 3) { o[1] = acc.c1; o[2] = acc.c2; }
-    }
+    for (unsigned q = 0; q < nq; q++) memcpy((uint64_t*)h_out + (size_t)q * PW, &res[3 * q], PW * 8);
     return MS_OK;
 }
 

@@ -141,3 +141,49 @@ def test_deep_252(kind):
         assert horner(qc, r) == want
     # degree bound: deg Q <= n - 2 before the adjustment, so the adjusted polynomial has n coefficients and no more
     assert len(qc) == n
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("ext", [False, True])
+def test_horner_sums_of_unreduced_products_at_the_edges(kind, ext):
+    # Fp coefficient columns: a lane adds sixteen unreduced 128-bit products c * y^k and reduces once (deep_kernels.h: Acc132).
+    # Columns whose Montgomery words are all p - 1 (the largest factor), all 0, and mixed edge values, at points whose powers are
+    # edge values themselves (z = 1, z = p - 1) and random ones; ragged length (n not a multiple of a block).
+    pl = backends.planner(kind)
+    rng = np.random.default_rng(77 + ext)
+    n = 1 << 13
+    words = [np.full(n, P - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64),
+             rng.choice(np.array([0, 1, P - 1, P - 2, 0xFFFFFFFF, 1 << 32, 0xFFFFFFFF00000000], dtype=np.uint64), size=n)]
+    m = Matrix.from_numpy(pl, words, FP)
+    canon = [[GL.from_mont(int(x)) for x in w] for w in words]
+    comp = [[_rq(rng, ext) for _ in range(8)]]
+    for z in ((1, 0, 0) if ext else 1, (P - 1, 0, 0) if ext else P - 1, _rq(rng, ext), (0, 1, 0) if ext else 0):
+        args = [(0, 0), (0, 1), (1, 0), (2, 0), (2, 1)]
+        composer = DeepPolyComposer(args, n, z, m, None, _mat(pl, comp, FQ3 if ext else FP))
+        got, _ = composer.get_ood_evals()
+        d = Radix2EvaluationDomain(n)
+        want = [pydeep.horner_evaluate(canon[c], pydeep.point_for(z, d.group_gen, d.group_gen_inv, off)) for c, off in args]
+        assert got == want, z
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_horner_three_levels_sparse(kind):
+    # 2^25 coefficients: blocks of 4096 -> 8192 block values -> 2 -> 1, every level on the device (ms_horner_eval).  The column is
+    # zero except at a few positions (first / last of a block, of a second-level block, the very last), so that the oracle is a
+    # handful of powers: sum_i c_i z^i.
+    pl = backends.planner(kind)
+    rng = np.random.default_rng(9)
+    n = 1 << 25
+    pos = sorted(set([0, 1, 4095, 4096, (1 << 24) - 1, 1 << 24, (1 << 24) + 4097, n - 4096, n - 1] + [int(x) for x in rng.integers(0, n, size=12)]))
+    vals = [int(x) for x in rng.integers(1, P, size=len(pos), dtype=np.uint64)]
+    col = np.zeros(n, dtype=np.uint64)
+    for i, v in zip(pos, vals):
+        col[i] = GL.to_mont(v)
+    m = Matrix.from_numpy(pl, [col], FP)
+    z = _rq(rng, False)
+    d = Radix2EvaluationDomain(n)
+    composer = DeepPolyComposer([(0, 0), (0, 1)], n, z, m, None, _mat(pl, [[_rq(rng, False) for _ in range(4)]], FP))
+    got, _ = composer.get_ood_evals()
+    for off, g in zip((0, 1), got):
+        x = pydeep.point_for(z, d.group_gen, d.group_gen_inv, off)
+        assert g == sum(v * pow(x, i, P) for i, v in zip(pos, vals)) % P
