@@ -124,14 +124,21 @@ __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
                 for (int i = 0; i < 6; i++) S[j][w][i] = 0;
             }
         }
-        #pragma unroll 4
+        // all sixteen loads first (a block lives for one memory latency, not four): clamped addresses, values past the end zeroed
+        uint64_t c[16];
+        #pragma unroll
         for (int k = 0; k < 16; k++) {
             const size_t i = start + (size_t)k * NT;
-            const uint64_t c = i < P.n ? col[i] : 0;
+            c[k] = col[i < P.n ? i : P.n - 1];
+        }
+        [[maybe_unused]] constexpr int UNR = PW == 1 ? 16 : 4;   // (an Fq3 point keeps 18 scalar factor words per step: fully unrolled they spill)
+        #pragma unroll UNR
+        for (int k = 0; k < 16; k++) {
+            if (start + (size_t)k * NT >= P.n) c[k] = 0;
             #pragma unroll
             for (int j = 0; j < GQ; j++) {
                 #pragma unroll
-                for (int w = 0; w < PW; w++) limb_mac(S[j][w], c, P.ylimb + (((size_t)qj[j] * 16 + k) * 3 + w) * 4);
+                for (int w = 0; w < PW; w++) limb_mac(S[j][w], c[k], P.ylimb + (((size_t)qj[j] * 16 + k) * 3 + w) * 4);
             }
         }
         #pragma unroll
@@ -148,8 +155,11 @@ __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
             y[j] = {{yp[0], yp[1], yp[2]}};
             acc[j] = q_zero<PW>();
         }
+        // only the steps the block has coefficients for (a second level of 1 024 block values: 4 of 16)
+        const size_t left = P.n - (size_t)b * 4096;
+        const int steps = left >= 4096 ? 16 : (int)((left + NT - 1) / NT);
         #pragma unroll 4
-        for (int k = 15; k >= 0; k--) {
+        for (int k = steps - 1; k >= 0; k--) {
             const size_t i = start + (size_t)k * NT;
             Q c = q_zero<PW>();
             if (i < P.n) c = q_load<CW>(col, i);

@@ -131,6 +131,7 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
     if (ncols > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns per call", msdeep::MAXCOLS);
     if (nq == 0) return MS_OK;
     for (unsigned q = 0; q < nq; q++) if (h_qcol[q] >= ncols) return fail(MS_ERR_INVALID, "query %u names column %u of %u", q, h_qcol[q], ncols);
+    if (n == 0) { memset(h_out, 0, (size_t)nq * PW * 8); return MS_OK; }           // the zero polynomial
     // queries on the same column that follow one another (the callers list them per column) share one pass over the coefficients
     constexpr unsigned GQ = 2;
     std::vector<uint32_t> groups, singles;
