@@ -3,8 +3,9 @@
 // (horner_evaluate src/utils.rs:124-133, divide_out_point(s)_into src/utils.rs:151-175).
 //
 //  * horner_blocks: out-of-domain evaluations P_c(x) for (column, point) queries.  One workgroup per
-//    4096 coefficients and query: lane t runs Horner in x^256 over coefficients t, t+256, ... (coalesced
-//    loads), the workgroup folds sum_t A_t x^t in LDS; the block values are combined on the host.
+//    4096 coefficients and query group: lane t sums c[t + 256 k] (x^256)^k over its sixteen coefficients
+//    (coalesced loads), weights the sum with x^t and the workgroup adds the 256 values up in LDS; the block
+//    values are the coefficients of a polynomial in x^4096 and go through the same kernel again (ms_deep.cpp).
 //  * deep_points: the reference builds  Q(X) = sum_t alpha_t (P_ct(X) - P_ct(z_t)) / (X - z_t)  by synthetic
 //    division in coefficient space.  Q has degree <= n-2, so it is determined by its values on any n
 //    points: this kernel evaluates the sum at the n points of the coset offset*<w_n> from coset
