@@ -179,12 +179,20 @@ int main(int argc, char** argv) {
         std::vector<size_t> pos(uniq.begin(), uniq.end());
         size_t opened = 0;
         std::vector<size_t> pos0; std::vector<uint64_t> rows0;
-        for (size_t l = 0; l < layers.size(); l++) {          // fri_prover.into_proof(&query_positions): fri.rs:148-165
-            pos = fold_positions(pos, fold);
-            auto rows = fri_layer_rows(layers[l], fold, pos);
-            auto view = trees[l].prove(pos);
-            opened += rows.size() / fold + view.nodes.size();
-            if (l == 0) { pos0 = pos; rows0 = std::move(rows); }
+        {                                                     // fri_prover.into_proof(&query_positions): fri.rs:148-165
+            std::vector<Pending> row_gathers; std::vector<MerkleTree::PendingView> view_gathers;     // every gather first, then the downloads
+            for (size_t l = 0; l < layers.size(); l++) {
+                pos = fold_positions(pos, fold);
+                if (l == 0) pos0 = pos;
+                row_gathers.push_back(fri_layer_rows_launch(layers[l], fold, pos));
+                view_gathers.push_back(trees[l].prove_launch(pos));
+            }
+            for (size_t l = 0; l < layers.size(); l++) {
+                auto rows = row_gathers[l].fetch<uint64_t>();
+                auto view = view_gathers[l].fetch();
+                opened += rows.size() / fold + view.nodes.size();
+                if (l == 0) rows0 = std::move(rows);
+            }
         }
         ph[5] = ms_since(t);
         ph[6] = ms_since(all);

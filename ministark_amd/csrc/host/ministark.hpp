@@ -59,6 +59,28 @@ private:
 };
 inline Planner& get_planner() { static Planner p(0); return p; }
 
+// The result of a gather that has been launched but not fetched: an opening launches every gather first and fetches afterwards,
+// so the host waits for the device once instead of once per call (the device runs them back to back on the context's stream).
+class Pending {
+public:
+    Pending() = default;
+    Pending(Planner& pl, size_t bytes) : pl_(&pl), bytes_(bytes) { if (bytes) check(ms_alloc(pl.ctx(), bytes, &d_)); }
+    ~Pending() { if (d_) ms_free(pl_->ctx(), d_); }
+    Pending(Pending&& o) noexcept : pl_(o.pl_), d_(o.d_), bytes_(o.bytes_) { o.d_ = nullptr; }
+    Pending& operator=(Pending&& o) noexcept { if (this != &o) { if (d_) ms_free(pl_->ctx(), d_); pl_ = o.pl_; d_ = o.d_; bytes_ = o.bytes_; o.d_ = nullptr; } return *this; }
+    Pending(const Pending&) = delete;
+    Pending& operator=(const Pending&) = delete;
+    void* ptr() const { return d_; }
+    size_t bytes() const { return bytes_; }
+    template <class T> std::vector<T> fetch() const {                   // waits for the stream, then copies
+        std::vector<T> out(bytes_ / sizeof(T));
+        if (bytes_) check(ms_download(pl_->ctx(), out.data(), d_, bytes_));
+        return out;
+    }
+private:
+    Planner* pl_ = nullptr; void* d_ = nullptr; size_t bytes_ = 0;
+};
+
 template <class F>
 class GpuVec {
 public:
@@ -196,17 +218,13 @@ public:
         return dst;
     }
     // Matrix::get_row for every queried position (src/trace.rs:139-152): row-major [positions][num_cols * words]
-    std::vector<uint64_t> get_rows(const std::vector<uint64_t>& positions) const {
+    std::vector<uint64_t> get_rows(const std::vector<uint64_t>& positions) const { return get_rows_launch(positions).template fetch<uint64_t>(); }
+    Pending get_rows_launch(const std::vector<uint64_t>& positions) const {
         const size_t words = num_cols() * F::words;
-        std::vector<uint64_t> out(positions.size() * words);
-        if (out.empty()) return out;
-        void* d = nullptr;
-        check(ms_alloc(planner().ctx(), out.size() * 8, &d));
+        Pending out(planner(), positions.size() * words * 8);
+        if (!out.bytes()) return out;
         std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
-        int rc = ms_gather_rows(planner().ctx(), F::id, num_rows(), in.data(), (unsigned)in.size(), positions.data(), positions.size(), d);
-        if (rc == MS_OK) rc = ms_download(planner().ctx(), out.data(), d, out.size() * 8);
-        ms_free(planner().ctx(), d);
-        check(rc);
+        check(ms_gather_rows(planner().ctx(), F::id, num_rows(), in.data(), (unsigned)in.size(), positions.data(), positions.size(), out.ptr()));
         return out;
     }
     std::vector<void*> ptrs() const { std::vector<void*> p; for (auto& c : columns) p.push_back(c.ptr()); return p; }
@@ -241,19 +259,33 @@ public:
     struct MerkleView { std::vector<Digest> nodes, initial_leaves, sibling_leaves; unsigned height = 0; };   // src/merkle.rs:72-84
     // MerkleTreeImpl::prove (src/merkle.rs:149-206): the walk over indices is bookkeeping, the digests it lists
     // are gathered on the device and come back in one copy per array
-    MerkleView prove(std::vector<size_t> indices) const {
+    // `prove` in two halves: the gathers are launched now, PendingView::fetch() downloads and assembles the view
+    struct PendingView {
+        Pending leaves, nodes; std::vector<size_t> initial, sibling; unsigned height = 0;
+        MerkleView fetch() const {
+            const auto lv = leaves.fetch<Digest>(), nd = nodes.fetch<Digest>();
+            MerkleView v;
+            v.nodes = nd;
+            for (size_t k : initial) v.initial_leaves.push_back(lv[k]);
+            for (size_t k : sibling) v.sibling_leaves.push_back(lv[k]);
+            v.height = height;
+            return v;
+        }
+    };
+    MerkleView prove(std::vector<size_t> indices) const { return prove_launch(std::move(indices)).fetch(); }
+    PendingView prove_launch(std::vector<size_t> indices) const {
         for (size_t i : indices) if (i >= n_) throw std::out_of_range("leaf index out of bounds");          // Error::LeafIndexOutOfBounds
         std::sort(indices.begin(), indices.end());
         indices.erase(std::unique(indices.begin(), indices.end()), indices.end());
         std::vector<uint64_t> leaf_ids, node_ids;
-        std::vector<size_t> initial, sibling;
+        PendingView pv;
         std::deque<size_t> node_queue, leaf_queue(indices.begin(), indices.end());
         while (!leaf_queue.empty()) {
             const size_t index = leaf_queue.front(); leaf_queue.pop_front();
-            initial.push_back(leaf_ids.size()); leaf_ids.push_back(index);
+            pv.initial.push_back(leaf_ids.size()); leaf_ids.push_back(index);
             node_queue.push_back((n_ + index) >> 1);
-            if (!leaf_queue.empty() && (index ^ 1) == leaf_queue.front()) { initial.push_back(leaf_ids.size()); leaf_ids.push_back(leaf_queue.front()); leaf_queue.pop_front(); continue; }
-            sibling.push_back(leaf_ids.size()); leaf_ids.push_back(index ^ 1);
+            if (!leaf_queue.empty() && (index ^ 1) == leaf_queue.front()) { pv.initial.push_back(leaf_ids.size()); leaf_ids.push_back(leaf_queue.front()); leaf_queue.pop_front(); continue; }
+            pv.sibling.push_back(leaf_ids.size()); leaf_ids.push_back(index ^ 1);
         }
         while (!node_queue.empty()) {
             const size_t index = node_queue.front(); node_queue.pop_front();
@@ -261,13 +293,10 @@ public:
             if (!node_queue.empty() && (index ^ 1) == node_queue.front()) { node_queue.pop_front(); continue; }
             node_ids.push_back(index ^ 1);
         }
-        const std::vector<Digest> leaves = gather(leaves_, leaf_ids), nodes = gather(nodes_, node_ids);
-        MerkleView v;
-        v.nodes = nodes;
-        for (size_t k : initial) v.initial_leaves.push_back(leaves[k]);
-        for (size_t k : sibling) v.sibling_leaves.push_back(leaves[k]);
-        while (((size_t)1 << v.height) < n_) v.height++;
-        return v;
+        pv.leaves = gather_launch(leaves_, leaf_ids);
+        pv.nodes = gather_launch(nodes_, node_ids);
+        while (((size_t)1 << pv.height) < n_) pv.height++;
+        return pv;
     }
     size_t num_leaves() const { return n_; }
     std::array<uint8_t, 32> root() const {                              // nodes[1], src/merkle.rs:145-147
@@ -283,15 +312,9 @@ private:
         if (h == Hash::Sha256) check(ms_sha256_merkle(pl_->ctx(), n_, leaves_, nodes_));
         else check(ms_rpo256_merkle(pl_->ctx(), n_, leaves_, nodes_));
     }
-    std::vector<Digest> gather(const void* digests, const std::vector<uint64_t>& ids) const {
-        std::vector<Digest> out(ids.size());
-        if (ids.empty()) return out;
-        void* d = nullptr;
-        check(ms_alloc(pl_->ctx(), ids.size() * 32, &d));
-        int rc = ms_gather_digests(pl_->ctx(), n_, digests, ids.data(), ids.size(), d);
-        if (rc == MS_OK) rc = ms_download(pl_->ctx(), out.data(), d, ids.size() * 32);
-        ms_free(pl_->ctx(), d);
-        check(rc);
+    Pending gather_launch(const void* digests, const std::vector<uint64_t>& ids) const {
+        Pending out(*pl_, ids.size() * 32);
+        if (!ids.empty()) check(ms_gather_digests(pl_->ctx(), n_, digests, ids.data(), ids.size(), out.ptr()));
         return out;
     }
     Planner* pl_; size_t n_; void* leaves_ = nullptr; void* nodes_ = nullptr;

@@ -64,26 +64,29 @@ inline std::vector<size_t> fold_positions(const std::vector<size_t>& positions, 
 // rows `positions` of Matrix::from_arrays(evaluations.as_chunks::<N>()) (src/fri.rs:213-215): N consecutive evaluations each,
 // gathered on the device as 32-byte records (FriProver::into_proof, src/fri.rs:148-165)
 template <class F>
+inline Pending fri_layer_rows_launch(const GpuVec<F>& layer, unsigned folding_factor, const std::vector<size_t>& positions) {
+    const size_t words = (size_t)folding_factor * F::words;
+    if (words % 4) throw std::invalid_argument("fri_layer_rows_launch: rows shorter than a 32-byte record");
+    Planner& pl = layer.planner();
+    Pending out(pl, positions.size() * words * 8);
+    if (!out.bytes()) return out;
+    const size_t per = words / 4;
+    std::vector<uint64_t> ids;
+    for (size_t p : positions) for (size_t k = 0; k < per; k++) ids.push_back(p * per + k);
+    check(ms_gather_digests(pl.ctx(), layer.len() * F::words / 4, layer.ptr(), ids.data(), ids.size(), out.ptr()));
+    return out;
+}
+template <class F>
 inline std::vector<uint64_t> fri_layer_rows(const GpuVec<F>& layer, unsigned folding_factor, const std::vector<size_t>& positions) {
     const size_t words = (size_t)folding_factor * F::words;
-    std::vector<uint64_t> out(positions.size() * words);
-    if (out.empty()) return out;
-    Planner& pl = layer.planner();
     if (words % 4) {                                       // rows shorter than a record: tiny layers only
+        std::vector<uint64_t> out(positions.size() * words);
+        if (out.empty()) return out;
         const auto all = layer.to_host();
         for (size_t i = 0; i < positions.size(); i++) memcpy(&out[i * words], &all[positions[i] * words], words * 8);
         return out;
     }
-    const size_t per = words / 4;
-    std::vector<uint64_t> ids;
-    for (size_t p : positions) for (size_t k = 0; k < per; k++) ids.push_back(p * per + k);
-    void* d = nullptr;
-    check(ms_alloc(pl.ctx(), out.size() * 8, &d));
-    int rc = ms_gather_digests(pl.ctx(), layer.len() * F::words / 4, layer.ptr(), ids.data(), ids.size(), d);
-    if (rc == MS_OK) rc = ms_download(pl.ctx(), out.data(), d, out.size() * 8);
-    ms_free(pl.ctx(), d);
-    check(rc);
-    return out;
+    return fri_layer_rows_launch(layer, folding_factor, positions).template fetch<uint64_t>();
 }
 
 // Queries::new: rows of the three LDE matrices at the query positions + batched openings of the three trees
@@ -94,12 +97,19 @@ struct Queries {
     Queries(const Matrix<Fp>& base_lde, const Matrix<FqT>* extension_lde, const Matrix<FqT>& composition_lde,
             const MerkleTree& base_tree, const MerkleTree* extension_tree, const MerkleTree& composition_tree, const std::vector<size_t>& positions) {
         std::vector<uint64_t> pos(positions.begin(), positions.end());
-        base_trace_proof = base_tree.prove(positions);
-        if (extension_tree) extension_trace_proof = extension_tree->prove(positions);
-        composition_trace_proof = composition_tree.prove(positions);
-        base_trace_values = base_lde.get_rows(pos);
-        if (extension_lde) extension_trace_values = extension_lde->get_rows(pos);
-        composition_trace_values = composition_lde.get_rows(pos);
+        // every gather first, then the downloads: one wait for the device instead of eight
+        auto bp = base_tree.prove_launch(positions);
+        MerkleTree::PendingView ep;
+        if (extension_tree) ep = extension_tree->prove_launch(positions);
+        auto cp = composition_tree.prove_launch(positions);
+        Pending bv = base_lde.get_rows_launch(pos), ev, cv = composition_lde.get_rows_launch(pos);
+        if (extension_lde) ev = extension_lde->get_rows_launch(pos);
+        base_trace_proof = bp.fetch();
+        if (extension_tree) extension_trace_proof = ep.fetch();
+        composition_trace_proof = cp.fetch();
+        base_trace_values = bv.template fetch<uint64_t>();
+        if (extension_lde) extension_trace_values = ev.template fetch<uint64_t>();
+        composition_trace_values = cv.template fetch<uint64_t>();
     }
 };
 

@@ -26,6 +26,21 @@ def test_cpp_mirror_compiles_and_links():
     assert os.path.exists(_build())
 
 
+def test_cpp_mirror_parity_under_the_simulator():
+    # the same parity program linked against the simulator build of the library (tests/emu): every mirror class against the C oracle
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from oracle import cref
+    so, osso = build_emu.build(), cref.build()
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_host_mirror_emu")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", SRC, "-o", exe, so, osso, "-Wl,-rpath," + os.path.dirname(so),
+                           "-Wl,-rpath," + os.path.dirname(osso), "-fopenmp"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "cpp host mirror ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_mirror_parity_on_gpu():
     exe = _build()
