@@ -104,7 +104,7 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
 // ---- pass A ----------------------------------------------------------------------------------------------------------
 // grid = (L / 64, beta, columns): coefficients src[col][i1 L + i0] -> dst[col][j n + k1 L + i0].  The cosets of a column are
 // adjacent in dispatch order, so its coefficients (read beta times) come from L2 / the Infinity Cache after the first read.
-template <bool UNI>
+template <bool STREAM, bool UNI>
 __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
     const uint64_t* __restrict__ src = P.src[blockIdx.z];
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
                 w4x4_at(P.tout4, slot0 + 4 * g, wc);
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
-                for (int e = 0; e < 4; e++, q += step) *q = glimb::mul_fold_co(v[4 * g + e], wc[e]);
+                for (int e = 0; e < 4; e++, q += step) NTT2_ST(q, glimb::mul_fold_co(v[4 * g + e], wc[e]), 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
             uint64_t tw = gld::mmul(twn_pow(P, (uint64_t)i0 * ap), P.aux[(size_t)j * L + i0]);
             #pragma unroll
             for (int d = 0; d < 16; d++, q += step) {
-                *q = gld::mmul(z[d], tw);
+                NTT2_ST(q, gld::mmul(z[d], tw), 1);
                 if (d < 15) tw = gld::mmul(tw, B);
                 if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
 // network, and a last trip through LDS so that the stores are runs of consecutive words.
 // grid = (256 T / 64, columns, beta)          [64 / T rows per workgroup, 256 rows per coset]
 static constexpr int X2P = 65;                               // pitch of the second exchange (words): conflict-free both ways
-template <int T, bool UNI>
+template <bool STREAM, int T, bool UNI>
 __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     constexpr int LOGT = T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
     constexpr int RSEL = 64 / T;                             // rows per workgroup
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     for (int h = 0; h < 2; h++) {
         const uint64_t* p = src + (size_t)(w + 8 * h) * T;
         #pragma unroll
-        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += 16 * T; }
+        for (int a = 0; a < 16; a++) { x[h][a] = NTT2_LD(p, 2); p += 16 * T; }
         glimb::Q3 qh{};
         if constexpr (UNI) qh = glimb::q3_from(gld::mmul(qm[h], 1), gld::mmul(qm[h], (uint64_t)1 << 24), gld::mmul(qm[h], (uint64_t)1 << 48));
         net1<UNI ? 2 : 0>(x[h], P, w + 8 * h, nullptr, qh);
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             const unsigned idx = i * NT + threadIdx.x;        // < 8192 = RSEL * 8 * 16 * T
             const unsigned tt = idx & (T - 1), c = (idx >> LOGT) & 15, xq = (idx >> (LOGT + 4)) & 7, rsel = idx >> (LOGT + 7);
             const unsigned k1 = row0 + rsel;
-            dst[(size_t)(__brev(k1) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + c * T + tt] = xch[idx + (idx >> 4)];
+            NTT2_ST(dst + ((size_t)(__brev(k1) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + c * T + tt), (uint64_t)xch[idx + (idx >> 4)], 2);
         }
     }
 }

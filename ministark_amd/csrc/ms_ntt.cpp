@@ -596,12 +596,16 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
                 Q.nfields = P.nfields;
                 for (unsigned f = 0; f < P.nfields; f++) Q.fields[f] = P.fields[f];
                 const dim3 g2((unsigned)(n * p->V / msntt2::TILE), nc), b2(msntt2::NT);
+                // non-temporal tile accesses once the columns of this launch and their scratch exceed the Infinity Cache (ntt2_kernels.h)
+                const bool stream_hint = 2 * (size_t)nc * col_bytes > ((size_t)256 << 20);
+#define MS_K2(NAME, ...) do { if (stream_hint) hipLaunchKernelGGL((msntt2::NAME<true, __VA_ARGS__>), g2, b2, 0, st, Q); \
+                              else hipLaunchKernelGGL((msntt2::NAME<false, __VA_ARGS__>), g2, b2, 0, st, Q); } while (0)
                 if (q == 0) {
                     const bool cos = (!p->inverse && p->coset);
                     const int na = valid_rows == 64 ? 4 : valid_rows == 32 ? 2 : valid_rows == 16 ? 1 : 16;
-#define MS_P1(INV, COS, NA) do { if (perm) hipLaunchKernelGGL((msntt2::ntt2_first_pass<INV, COS, NA, true, true>), g2, b2, 0, st, Q); \
-                                 else if (p->uni) hipLaunchKernelGGL((msntt2::ntt2_first_pass<INV, COS, NA, true>), g2, b2, 0, st, Q); \
-                                 else hipLaunchKernelGGL((msntt2::ntt2_first_pass<INV, COS, NA, false>), g2, b2, 0, st, Q); } while (0)
+#define MS_P1(INV, COS, NA) do { if (perm) MS_K2(ntt2_first_pass, INV, COS, NA, true, true); \
+                                 else if (p->uni) MS_K2(ntt2_first_pass, INV, COS, NA, true); \
+                                 else MS_K2(ntt2_first_pass, INV, COS, NA, false); } while (0)
                     if (p->inverse) MS_P1(true, false, 16);
                     else if (cos) {
                         if (na == 4) MS_P1(false, true, 4);
@@ -616,14 +620,14 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
                     }
 #undef MS_P1
                 } else if (small_mid) {     // (256, R, 256) plans: the whole radix-R network in registers
-#define MS_SM(LOGR) do { if (p->inverse) { if (perm) hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, LOGR, true>), g2, b2, 0, st, Q); \
-                                           else hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, LOGR, false>), g2, b2, 0, st, Q); } \
-                         else { if (perm) hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, LOGR, true>), g2, b2, 0, st, Q); \
-                                else hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, LOGR, false>), g2, b2, 0, st, Q); } } while (0)
-#define MS_MR(LOGT2) do { if (p->inverse) { if (perm) hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, LOGT2, true>), g2, b2, 0, st, Q); \
-                                            else hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, LOGT2, false>), g2, b2, 0, st, Q); } \
-                          else { if (perm) hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, LOGT2, true>), g2, b2, 0, st, Q); \
-                                 else hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, LOGT2, false>), g2, b2, 0, st, Q); } } while (0)
+#define MS_SM(LOGR) do { if (p->inverse) { if (perm) MS_K2(ntt2_small_mid_pass, true, LOGR, true); \
+                                           else MS_K2(ntt2_small_mid_pass, true, LOGR, false); } \
+                         else { if (perm) MS_K2(ntt2_small_mid_pass, false, LOGR, true); \
+                                else MS_K2(ntt2_small_mid_pass, false, LOGR, false); } } while (0)
+#define MS_MR(LOGT2) do { if (p->inverse) { if (perm) MS_K2(ntt2_mid_pass_r, true, LOGT2, true); \
+                                            else MS_K2(ntt2_mid_pass_r, true, LOGT2, false); } \
+                          else { if (perm) MS_K2(ntt2_mid_pass_r, false, LOGT2, true); \
+                                 else MS_K2(ntt2_mid_pass_r, false, LOGT2, false); } } while (0)
                     switch (p->lr[q]) {
                     case 1: MS_SM(1); break; case 2: MS_SM(2); break; case 3: MS_SM(3); break; case 4: MS_SM(4); break;
                     case 5: MS_MR(1); break; case 6: MS_MR(2); break; default: MS_MR(3); break;
@@ -632,22 +636,22 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
 #undef MS_SM
                 } else if (!last) {
                     if (perm) {             // ... and reads pass 1's permuted rows, writes the natural order (in place)
-                        if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0, true, true>), g2, b2, 0, st, Q);
-                        else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g2, b2, 0, st, Q);
+                        if (p->inverse) MS_K2(ntt2_mid_pass, true, false, 0, true, true);
+                        else MS_K2(ntt2_mid_pass, false, false, 0, true, true);
                     } else if (p->uni) {    // q == 1 of three: applies the per-lane remainder of pass 1's factor on its loads
-                        if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0, true>), g2, b2, 0, st, Q);
-                        else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true>), g2, b2, 0, st, Q);
-                    } else if (p->inverse) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, 0>), g2, b2, 0, st, Q);
-                    else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0>), g2, b2, 0, st, Q);
+                        if (p->inverse) MS_K2(ntt2_mid_pass, true, false, 0, true);
+                        else MS_K2(ntt2_mid_pass, false, false, 0, true);
+                    } else if (p->inverse) MS_K2(ntt2_mid_pass, true, false, 0);
+                    else MS_K2(ntt2_mid_pass, false, false, 0);
                 } else if (bitrev_out) {
-                    hipLaunchKernelGGL(msntt2::ntt2_last_pass_bitrev, g2, b2, 0, st, Q);
+                    { if (stream_hint) hipLaunchKernelGGL(msntt2::ntt2_last_pass_bitrev<true>, g2, b2, 0, st, Q); else hipLaunchKernelGGL(msntt2::ntt2_last_pass_bitrev<false>, g2, b2, 0, st, Q); }
                 } else {
                     const int scale = p->scale_mode;
                     if (p->inverse) {
-                        if (scale == 2) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 2>), g2, b2, 0, st, Q);
-                        else if (scale == 1) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 1>), g2, b2, 0, st, Q);
-                        else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, true, 0>), g2, b2, 0, st, Q);
-                    } else hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, st, Q);
+                        if (scale == 2) MS_K2(ntt2_mid_pass, true, true, 2);
+                        else if (scale == 1) MS_K2(ntt2_mid_pass, true, true, 1);
+                        else MS_K2(ntt2_mid_pass, true, true, 0);
+                    } else MS_K2(ntt2_mid_pass, false, true, 0);
                 }
                 continue;
             }
@@ -767,24 +771,30 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
         memset(&P, 0, sizeof P);
         P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2; P.tin4 = tb->tin4; P.tout4 = tb->tout4;
         const bool uni = tb->tin4 != nullptr;
+        const bool stream_hint = 2 * (size_t)nc * col_bytes > ((size_t)256 << 20);       // as for the transforms above
         P.tw_lo = fwd->d_tw_lo; P.tw_hi = fwd->d_tw_hi; P.lo_bits = fwd->lo_bits; P.log_n = log_n; P.log_b = log_b;
         for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)src[c0 + c]; P.dst[c] = (uint64_t*)((char*)scratch + (size_t)c * col_bytes); }
         {
             ProfScope ps(ctx, "lde2_pass_a", (double)(n * 8 + col_bytes) * nc);
             const dim3 ga((unsigned)(n >> 14), 1u << log_b, nc);
-            if (uni) hipLaunchKernelGGL(mslde2::lde2_strided_pass<true>, ga, dim3(msntt2::NT), 0, st, P);
-            else hipLaunchKernelGGL(mslde2::lde2_strided_pass<false>, ga, dim3(msntt2::NT), 0, st, P);
+            if (stream_hint) { if (uni) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, true>), ga, dim3(msntt2::NT), 0, st, P);
+                               else hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, false>), ga, dim3(msntt2::NT), 0, st, P); }
+            else { if (uni) hipLaunchKernelGGL((mslde2::lde2_strided_pass<false, true>), ga, dim3(msntt2::NT), 0, st, P);
+                   else hipLaunchKernelGGL((mslde2::lde2_strided_pass<false, false>), ga, dim3(msntt2::NT), 0, st, P); }
         }
         for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)((char*)scratch + (size_t)c * col_bytes); P.dst[c] = (uint64_t*)dst[c0 + c]; }
         {
             ProfScope ps(ctx, "lde2_pass_b", 2.0 * col_bytes * nc);
             const dim3 g(4 * T, nc, 1u << log_b), b(msntt2::NT);
+#define MS_RB(T_, UNI_) do { if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, T_, UNI_>), g, b, 0, st, P); \
+                             else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, T_, UNI_>), g, b, 0, st, P); } while (0)
             switch (T) {
-            case 16: if (uni) hipLaunchKernelGGL((mslde2::lde2_rows_pass<16, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<16, false>), g, b, 0, st, P); break;
-            case 8: if (uni) hipLaunchKernelGGL((mslde2::lde2_rows_pass<8, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<8, false>), g, b, 0, st, P); break;
-            case 4: if (uni) hipLaunchKernelGGL((mslde2::lde2_rows_pass<4, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<4, false>), g, b, 0, st, P); break;
-            default: hipLaunchKernelGGL((mslde2::lde2_rows_pass<2, false>), g, b, 0, st, P); break;
+            case 16: if (uni) MS_RB(16, true); else MS_RB(16, false); break;
+            case 8: if (uni) MS_RB(8, true); else MS_RB(8, false); break;
+            case 4: if (uni) MS_RB(4, true); else MS_RB(4, false); break;
+            default: MS_RB(2, false); break;
             }
+#undef MS_RB
         }
     }
     HIPCHK(hipGetLastError());

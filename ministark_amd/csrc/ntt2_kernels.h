@@ -26,6 +26,39 @@
 #include "gl_limb.h"
 #include "ntt_kernels.h"
 
+// Tile index of a workgroup.  scripts/ntt_pass_bench.hip re-defines it (e.g. blockIdx.x & 3) to time a pass on cache-resident tiles,
+// i.e. its arithmetic, exchange and issue alone.
+#ifndef NTT2_BX
+#define NTT2_BX blockIdx.x
+#endif
+// The tile loads / stores of the radix-256 passes.  Round 4: every word of a pass is read once and written once, so both carry the
+// non-temporal hint (global_load/store ... nt): 164 -> 154 us per 2^24 column for the three passes (profiles/r04_pass_bench2_nt.txt;
+// each hint alone, or on one pass alone, gives a third of it).  scripts/ntt_pass_bench2.hip re-defines the macros per pass (second /
+// third argument: 1, 2 or 3 = which pass of a three-pass plan the access belongs to).
+namespace msntt2 {
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T> __device__ __forceinline__ void nt_store(T* p, const T& v) {
+    if constexpr (sizeof(T) == 16) {
+        typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+        v2u64 t; __builtin_memcpy(&t, &v, 16); __builtin_nontemporal_store(t, (v2u64*)p);
+    } else __builtin_nontemporal_store(v, p);
+}
+#else
+template <class T> MS_HD T nt_load(const T* p) { return *p; }
+template <class T> MS_HD void nt_store(T* p, const T& v) { *p = v; }
+#endif
+}
+// STREAM is the kernels' first template parameter: the launcher sets it when data + scratch of a launch exceed the 256 MiB Infinity
+// Cache (ms_ntt.cpp).  Batches that fit stay on the default policy: the next pass finds them in the cache, and the hint costs
+// 2^17 x 64 columns 1.37 -> 1.54 us per column (profiles/r04_c2_sweep_nt_always.json).
+#ifndef NTT2_LD
+#define NTT2_LD(p, pass) (STREAM ? msntt2::nt_load(p) : *(p))
+#endif
+#ifndef NTT2_ST
+#define NTT2_ST(p, v, pass) do { if constexpr (STREAM) msntt2::nt_store(p, v); else *(p) = (v); } while (0)
+#endif
+
 namespace msntt2 {
 
 using msntt::MAXC;
@@ -216,7 +249,7 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
 //   a permutation INSIDE each run of 64 words.  The 64 words k1 = 64 q + lane of this tile are therefore this tile's own four
 //   128-byte lines, read once in a permuted lane order; the stores go to the natural positions, so the permutation ends here
 //   and the pass may run in place (every word of the tile is read before the first one is stored).
-template <bool INV, bool LAST, int SCALE, bool LOADQ = false, bool PERM = false>
+template <bool STREAM, bool INV, bool LAST, int SCALE, bool LOADQ = false, bool PERM = false>
 __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
@@ -225,11 +258,11 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t sw = ((size_t)1 << P.log_s) * P.V;
     const unsigned tiles_per_u = (unsigned)(sw / TW);
-    const unsigned U = blockIdx.x / tiles_per_u;
-    const size_t base = (size_t)U * 256 * sw + (size_t)(blockIdx.x % tiles_per_u) * TW + lane;
+    const unsigned U = NTT2_BX / tiles_per_u;
+    const size_t base = (size_t)U * 256 * sw + (size_t)(NTT2_BX % tiles_per_u) * TW + lane;
     size_t rbase = base;
     if constexpr (PERM) {       // natural k1 = 64 q + lane sits at 64 q + pi(lane): inside this tile's own 64 words, so dst may be src
-        const unsigned q = blockIdx.x % tiles_per_u;
+        const unsigned q = NTT2_BX % tiles_per_u;
         rbase = (size_t)U * 256 * sw + 64 * q + ((lane >> 5) & 1) * 32 + ((lane >> 3) & 1) * 16 + (lane & 7) * 2 + ((lane >> 4) & 1);
     }
 
@@ -242,19 +275,19 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
     auto load_half = [&](int h) {
         const uint64_t* p = src + rbase + (size_t)(w + 8 * h) * sw;
         #pragma unroll
-        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
+        for (int a = 0; a < 16; a++) { x[h][a] = NTT2_LD(p, LAST ? 3 : 2); p += step; }
     };
     // Both halves of the tile are requested up front (the registers allow it since the second half of the first networks'
     // results leaves for LDS before the second network runs).
     uint64_t qlo = 0, qhi = 0;
     if constexpr (SCALE == 2) {
         static_assert(SCALE != 2 || (LAST && !LOADQ), "the coset scale belongs to the last pass");
-        const uint64_t e = (blockIdx.x * (uint64_t)TW + lane) / P.V;      // the element this lane's words belong to (U = 0)
+        const uint64_t e = (NTT2_BX * (uint64_t)TW + lane) / P.V;      // the element this lane's words belong to (U = 0)
         qlo = P.aux_lo[e & ((1u << P.lo_bits) - 1)];
         qhi = P.aux_hi[e >> P.lo_bits];
     }
     if constexpr (LOADQ) {                                   // the two table words of w_n^(k1 j3) first: they come back before the
-        const unsigned k1 = ((blockIdx.x % tiles_per_u) * TW + lane) / P.V;              // tile's words and are combined meanwhile
+        const unsigned k1 = ((NTT2_BX % tiles_per_u) * TW + lane) / P.V;              // tile's words and are combined meanwhile
         const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
         qlo = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
         qhi = P.tw_hi[e >> P.lo_bits];
@@ -321,7 +354,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
                 else if constexpr (SCALE == 1) val = glimb::mul_fold_co<true>(v[d], w4_at(P.sc4, 0));
                 else if constexpr (SCALE == 2) val = glimb::mul_fold_co<true>(v[d], w4_at(P.scu4, ap + 16 * d));
                 else val = glimb::to_canon(v[d]);
-                dst[pos] = val;
+                NTT2_ST(dst + pos, val, LAST ? 3 : 2);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -334,7 +367,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass(Params P) {
 // (LOADQ's per-lane factor, see ntt2_mid_pass), the network, and the wave-uniform factor w_U^k2 (twu4[U][k2], with h^j3 of a
 // coset transform) on the stores.  A workgroup takes 256 / R runs (32 words per lane, 16384 per workgroup, as everywhere).
 // PERM: the rows are in the order ntt2_first_pass<.., PERM> leaves them; the natural order is restored here, in place.
-template <bool INV, int LOGR, bool PERM>
+template <bool STREAM, bool INV, int LOGR, bool PERM>
 __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
     constexpr int R = 1 << LOGR, NNET = 32 / R;               // networks per lane
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
@@ -343,7 +376,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t sw = ((size_t)1 << P.log_s) * P.V;
     const unsigned runs_per_u = (unsigned)(sw / TW);          // runs of 64 words per row
-    const unsigned g0 = blockIdx.x * (256 / R) + w * NNET;    // this wave's first run (runs count through the blocks U)
+    const unsigned g0 = NTT2_BX * (256 / R) + w * NNET;    // this wave's first run (runs count through the blocks U)
     const unsigned pl = PERM ? ((lane >> 5) & 1) * 32 + ((lane >> 3) & 1) * 16 + (lane & 7) * 2 + ((lane >> 4) & 1) : lane;
 
     // every word of the lane is requested up front; the factors' table words four networks at a time, one group ahead
@@ -366,7 +399,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
         unsigned U, q; run_of<PERM>(g0 + i, runs_per_u, U, q);
         const uint64_t* p = src + (size_t)U * R * sw + (size_t)q * TW + pl;
         #pragma unroll
-        for (int a = 0; a < R; a++) { x[i][a] = *p; p += sw; }
+        for (int a = 0; a < R; a++) { x[i][a] = NTT2_LD(p, 2); p += sw; }
     }
     if constexpr (PERM) wave_lockstep();      // in place: a lane's stores land on words that other lanes of its wave have read
     #pragma unroll
@@ -392,7 +425,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
                 for (int j = 0; j < 4 && k0 + j < R; j++) wc[j] = w4_at(P.twu4, U * R + k0 + j);
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
-                for (int j = 0; j < 4 && k0 + j < R; j++, o += sw) *o = glimb::mul_fold_co<false>(v[k0 + j], wc[j]);
+                for (int j = 0; j < 4 && k0 + j < R; j++, o += sw) NTT2_ST(o, glimb::mul_fold_co<false>(v[k0 + j], wc[j]), 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -405,7 +438,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_small_mid_pass(Params P) {
 // per-lane factor on the loads), times w_R^(a' b) (wave-uniform: wr4 holds the powers of w_R for this pass), exchange through LDS in which every word
 // stays in its lane and slot (s, c) collects the outputs a' = c mod T2 of all b, radix-T2 networks over b, times the
 // wave-uniform w_U^k2 (twu4[U][k2], k2 = a' + 16 b') on the stores.  PERM as in ntt2_mid_pass (in place).
-template <bool INV, int LOGT2, bool PERM>
+template <bool STREAM, bool INV, int LOGT2, bool PERM>
 __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
     constexpr int T2 = 1 << LOGT2, R = 16 * T2, NM = 8 / T2;  // NM networks of radix T2 per slot and round
     static_assert(LOGT2 >= 1 && LOGT2 <= 3, "R = 32, 64 or 128");
@@ -423,7 +456,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
     uint64_t qlo[2], qhi[2];
     #pragma unroll
     for (int h = 0; h < 2; h++) {                            // the factors' table words first (see ntt2_mid_pass)
-        const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2;
+        const unsigned g = NTT2_BX * (16 / T2) + (w + 8 * h) / T2;
         unsigned U, q; run_of<PERM>(g, runs_per_u, U, q);
         const unsigned k1 = (q * TW + lane) / P.V;
         const uint64_t e = (uint64_t)k1 * digit_rev(P, U);
@@ -432,11 +465,11 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
     }
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2, b = (w + 8 * h) % T2;
+        const unsigned g = NTT2_BX * (16 / T2) + (w + 8 * h) / T2, b = (w + 8 * h) % T2;
         unsigned U, q; run_of<PERM>(g, runs_per_u, U, q);
         const uint64_t* p = src + (size_t)U * R * sw + (size_t)b * sw + (size_t)q * TW + pl;
         #pragma unroll
-        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += T2 * sw; }
+        for (int a = 0; a < 16; a++) { x[h][a] = NTT2_LD(p, 2); p += T2 * sw; }
     }
     #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -473,7 +506,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
         }
         #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const unsigned g = blockIdx.x * (16 / T2) + (w + 8 * h) / T2, c = (w + 8 * h) % T2;
+            const unsigned g = NTT2_BX * (16 / T2) + (w + 8 * h) / T2, c = (w + 8 * h) % T2;
             unsigned U, q; run_of<PERM>(g, runs_per_u, U, q);
             uint64_t* const o = dst + (size_t)U * R * sw + (size_t)q * TW + lane;
             #pragma unroll
@@ -490,7 +523,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
                     for (int j = 0; j < 4 && b0 + j < T2; j++) wc[j] = w4_at(P.twu4, U * R + ap + 16 * (b0 + j));
                     __builtin_amdgcn_sched_barrier(0);
                     #pragma unroll
-                    for (int j = 0; j < 4 && b0 + j < T2; j++) o[(size_t)(ap + 16 * (b0 + j)) * sw] = glimb::mul_fold_co<false>(v[b0 + j], wc[j]);
+                    for (int j = 0; j < 4 && b0 + j < T2; j++) NTT2_ST(o + (size_t)(ap + 16 * (b0 + j)) * sw, glimb::mul_fold_co<false>(v[b0 + j], wc[j]), 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -506,14 +539,15 @@ __global__ void __launch_bounds__(NT, 4) ntt2_mid_pass_r(Params P) {
 // store one whole 128-byte line.  The buffer is shared with the exchange, so here the second half of the first networks'
 // results waits in registers until round 0 has stored (a few spilled registers, as before round 2b).
 static constexpr int BR_PITCH = 129;
-static __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) {
+template <bool STREAM>
+__global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) {
     __shared__ uint64_t xch[64 * BR_PITCH];                  // >= 16 * 8 * TW words of the exchange
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
     uint64_t* __restrict__ dst = P.dst[blockIdx.y];
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t sw = (size_t)1 << P.log_s;                  // V = 1; the last pass has a single block U = 0
-    const size_t lo0 = (size_t)blockIdx.x * TW;
+    const size_t lo0 = (size_t)NTT2_BX * TW;
     const size_t base = lo0 + lane;
     const size_t step = 16 * sw;
     uint64_t x[2][16];
@@ -521,7 +555,7 @@ static __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) 
     for (int h = 0; h < 2; h++) {
         const uint64_t* p = src + base + (size_t)(w + 8 * h) * sw;
         #pragma unroll
-        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
+        for (int a = 0; a < 16; a++) { x[h][a] = NTT2_LD(p, 3); p += step; }
         net1<false, 16, 0>(x[h], P, w + 8 * h);
         #pragma unroll
         for (int j = 0; j < 8; j++) xch[((w + 8 * h) * 8 + j) * TW + lane] = x[h][j];
@@ -555,7 +589,7 @@ static __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) 
             const unsigned idx = it * NT + threadIdx.x;       // (word t, chunk c, i): 16 lanes = one 128-byte line
             const unsigned i = idx & 15, c = (idx >> 4) & 7, t = idx >> 7;
             const size_t e_rev = P.log_s ? (size_t)(__brevll((unsigned long long)(lo0 + t)) >> (64 - P.log_s)) : 0;
-            dst[(e_rev << 8) + c * 32 + r * 16 + i] = xch[t * BR_PITCH + c * 16 + i];
+            NTT2_ST(dst + ((e_rev << 8) + c * 32 + r * 16 + i), (uint64_t)xch[t * BR_PITCH + c * 16 + i], 3);
         }
     }
 }
@@ -580,7 +614,7 @@ static __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) 
 // (ntt2_mid_pass<.., PERM>) and writes the natural one -- in place, since the permutation never leaves a pass-2 tile.
 // (Pass 1 itself cannot run in place without a rendezvous of the four tiles that share a 512 KiB slab of the column; that was
 // built and measured in round 3 -- 72 against 56 us per column, profiles/r03_ntt3_inplace.txt -- and dropped.)
-template <bool INV, bool COSET, int NA, bool UNI = false, bool PERM = false>
+template <bool STREAM, bool INV, bool COSET, int NA, bool UNI = false, bool PERM = false>
 __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * XPITCH];                // [b][a' - 8 round][word], pitch 68 words
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
@@ -589,7 +623,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row_words = ((size_t)1 << (P.log_n - 8)) * V;
-    const size_t w0 = (size_t)blockIdx.x * TW;
+    const size_t w0 = (size_t)NTT2_BX * TW;
     const unsigned j2 = UNI ? (unsigned)((w0 / V) >> P.r3) : 0;       // uniform: the block of R3 V words this tile lies in
 
     uint64_t x[2][16];
@@ -597,10 +631,10 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
         const uint64_t* p = src + (size_t)(w + 8 * h) * row_words + w0 + lane;
         #pragma unroll
         for (int a = 0; a < NA; a++) {
-            if constexpr (NA < 16) x[h][a] = *p;
+            if constexpr (NA < 16) x[h][a] = NTT2_LD(p, 1);
             else {                                            // rows >= valid_rows are implicit zeros (uniform select, no branch)
                 const bool in = 16u * a + w + 8 * h < P.valid_rows;
-                const uint64_t val = *(in ? p : src);
+                const uint64_t val = NTT2_LD(in ? p : src, 1);
                 x[h][a] = in ? val : 0;
             }
             p += 16 * row_words;
@@ -652,7 +686,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
                 for (int j = 0; j < 4; j += 2, q2 += 16)     // d = 4 g + j: position 64 g + 32 (j >> 1) + 16 r + 2 c3 + (d & 1)
-                    *q2 = Pair{glimb::mul_fold_co(v[4 * g + j], wc[j]), glimb::mul_fold_co(v[4 * g + j + 1], wc[j + 1])};
+                    NTT2_ST(q2, (Pair{glimb::mul_fold_co(v[4 * g + j], wc[j]), glimb::mul_fold_co(v[4 * g + j + 1], wc[j + 1])}), 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (UNI) {
@@ -673,7 +707,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
-                for (int j = 0; j < 4; j++, q += 16 * V) *q = glimb::mul_fold_co(v[4 * g + j], wc[j]);
+                for (int j = 0; j < 4; j++, q += 16 * V) NTT2_ST(q, glimb::mul_fold_co(v[4 * g + j], wc[j]), 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -693,7 +727,7 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
             if constexpr (COSET) tw = gld::mmul(tw, aux_pow(P, jp));
             #pragma unroll
             for (int d = 0; d < 16; d++, q += 16 * V) {
-                *q = gld::mmul(z[d], tw);
+                NTT2_ST(q, gld::mmul(z[d], tw), 1);
                 if (d < 15) tw = gld::mmul(tw, B);
                 if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }

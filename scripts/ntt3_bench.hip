@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     // settle the clocks
     {
         msntt2::Params A = Q; A.log_s = 16; for (unsigned c = 0; c < NC; c++) { A.src[c] = cols[c]; A.dst[c] = cols[c]; }
-        for (int i = 0; i < 300; i++) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), dim3(ntiles, NC), b2, 0, 0, A);
+        for (int i = 0; i < 300; i++) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, true, 0>), dim3(ntiles, NC), b2, 0, 0, A);
         CK(hipDeviceSynchronize());
     }
     // in place: pass 1 (team), pass 2 (permuted rows, in place), pass 3 (in place)
@@ -68,11 +68,11 @@ int main(int argc, char** argv) {
         for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = cols[c0 + c]; }
         A.ntiles = ntiles; A.ncols = nc; A.nslabs = nc * (ntiles / 4);
         A.log_s = 0; A.nfields = 2; A.fields[0] = f1[0]; A.fields[1] = f1[1];
-        if (which & 1) hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true, true, true>), g, b2, 0, st, A);
+        if (which & 1) hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, true, 16, true, true, true>), g, b2, 0, st, A);
         A.log_s = 8; A.nfields = 1; A.fields[0] = {0, 0, 255};
-        if (which & 2) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g, b2, 0, st, A);
+        if (which & 2) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, false, 0, true, true>), g, b2, 0, st, A);
         A.log_s = 16; A.nfields = 0;
-        if (which & 4) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g, b2, 0, st, A);
+        if (which & 4) hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, true, 0>), g, b2, 0, st, A);
     };
     // round 2: through a scratch column (col -> scr, scr -> col, col)
     auto scratch = [&](hipStream_t st, unsigned c0, unsigned nc, unsigned scr0) {
@@ -80,13 +80,13 @@ int main(int argc, char** argv) {
         const dim3 g(ntiles, nc);
         A.log_s = 0; A.nfields = 2; A.fields[0] = f1[0]; A.fields[1] = f1[1];
         for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = scr[scr0 + c]; }
-        hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true, true>), g, b2, 0, st, A);
+        hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, true, 16, true, true>), g, b2, 0, st, A);
         A.log_s = 8; A.nfields = 1; A.fields[0] = {0, 0, 255};
         for (unsigned c = 0; c < nc; c++) { A.src[c] = scr[scr0 + c]; A.dst[c] = cols[c0 + c]; }
-        hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g, b2, 0, st, A);
+        hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, false, 0, true, true>), g, b2, 0, st, A);
         A.log_s = 16; A.nfields = 0;
         for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = cols[c0 + c]; }
-        hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g, b2, 0, st, A);
+        hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, true, 0>), g, b2, 0, st, A);
     };
     hipStream_t sts[4]; hipEvent_t evs[5];
     for (int i = 0; i < 4; i++) CK(hipStreamCreateWithFlags(&sts[i], hipStreamNonBlocking));

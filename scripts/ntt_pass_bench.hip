@@ -67,33 +67,33 @@ int main(int argc, char** argv) {
   for (int round = 0; round < 2; round++) {
     set_pass(0);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_first_pass<false, true>), g1, b1, 0, 0, P); });   printf("round-1 pass 1 (coset)   %7.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset)   %7.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 16>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (subgroup) %6.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset, uniform factor)    %7.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, false, 16, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (subgroup, uniform factor) %7.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset, uniform, permuted rows)  %5.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, true, 16>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset)   %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, false, 16>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (subgroup) %6.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, true, 16, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset, uniform factor)    %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, false, 16, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (subgroup, uniform factor) %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, true, 16, true, true>), g2, b2, 0, 0, Q); }); printf("limb    pass 1 (coset, uniform, permuted rows)  %5.1f us/column\n", t / NC);
     set_pass(1);
     for (unsigned c = 0; c < NC; c++) Q.dst[c] = cols[c];
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g2, b2, 0, 0, Q); });   printf("limb    pass 2 (load factor, permuted rows in)  %5.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, false, 0, true, true>), g2, b2, 0, 0, Q); });   printf("limb    pass 2 (load factor, permuted rows in)  %5.1f us/column\n", t / NC);
     set_pass(1);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true>), g2, b2, 0, 0, Q); });   printf("limb    pass 2 (per-lane load factor)     %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, false, 0, true>), g2, b2, 0, 0, Q); });   printf("limb    pass 2 (per-lane load factor)     %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, false, 0>), g1, b1, 0, 0, P); }); printf("round-1 pass 2           %7.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0>), g2, b2, 0, 0, Q); });   printf("limb    pass 2           %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, false, 0>), g2, b2, 0, 0, Q); });   printf("limb    pass 2           %7.1f us/column\n", t / NC);
     // the middle passes of the (256, R, 256) plans (2^17 .. 2^23 points), run here over the same 2^24 words per "column" (blocks of
     // R rows of 256 words; in place on permuted rows, as in the plans): time per 2^24 words
     set_pass(1);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 1, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 2   (registers only)       %5.1f us per 2^24 words\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 2, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 4   (registers only)       %5.1f us per 2^24 words\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 3, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 8   (registers only)       %5.1f us per 2^24 words\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<false, 4, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 16  (registers only)       %5.1f us per 2^24 words\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, 1, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 32  (16 x 2, one exchange)  %5.1f us per 2^24 words\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, 2, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 64  (16 x 4, one exchange)  %5.1f us per 2^24 words\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<false, 3, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 128 (16 x 8, one exchange)  %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, false, 1, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 2   (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, false, 2, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 4   (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, false, 3, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 8   (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_small_mid_pass<true, false, 4, true>), g2, b2, 0, 0, Q); });   printf("limb    middle pass R = 16  (registers only)       %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, false, 1, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 32  (16 x 2, one exchange)  %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, false, 2, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 64  (16 x 4, one exchange)  %5.1f us per 2^24 words\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass_r<true, false, 3, true>), g2, b2, 0, 0, Q); });       printf("limb    middle pass R = 128 (16 x 8, one exchange)  %5.1f us per 2^24 words\n", t / NC);
     set_pass(2);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, true, 0>), g1, b1, 0, 0, P); });  printf("round-1 pass 3           %7.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g2, b2, 0, 0, Q); });    printf("limb    pass 3           %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, true, 0>), g2, b2, 0, 0, Q); });    printf("limb    pass 3           %7.1f us/column\n", t / NC);
     t = time_us([&] { hipLaunchKernelGGL((msntt::ntt_mid_pass<16, false, true, 0, true>), g1, b1, 0, 0, P); });  printf("round-1 pass 3, bit-reversed store  %7.1f us/column\n", t / NC);
-    t = time_us([&] { hipLaunchKernelGGL(msntt2::ntt2_last_pass_bitrev, g2, b2, 0, 0, Q); });    printf("limb    pass 3, bit-reversed store  %7.1f us/column\n", t / NC);
+    t = time_us([&] { hipLaunchKernelGGL(msntt2::ntt2_last_pass_bitrev<true>, g2, b2, 0, 0, Q); });    printf("limb    pass 3, bit-reversed store  %7.1f us/column\n", t / NC);
   }
     // whole transforms (uniform factor + permuted rows): launch orders
     {
@@ -105,13 +105,13 @@ int main(int argc, char** argv) {
             const dim3 g((unsigned)(n / msntt2::TILE), nc);
             A.log_s = 0; A.nfields = 2; A.fields[0] = f1[0]; A.fields[1] = f1[1];
             for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = scr[scr0 + c]; }
-            hipLaunchKernelGGL((msntt2::ntt2_first_pass<false, true, 16, true, true>), g, b2, 0, st, A);
+            hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, true, 16, true, true>), g, b2, 0, st, A);
             A.log_s = 8; A.nfields = 1; A.fields[0] = {0, 0, 255};
             for (unsigned c = 0; c < nc; c++) { A.src[c] = scr[scr0 + c]; A.dst[c] = cols[c0 + c]; }
-            hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, false, 0, true, true>), g, b2, 0, st, A);
+            hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, false, 0, true, true>), g, b2, 0, st, A);
             A.log_s = 16; A.nfields = 0;
             for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = cols[c0 + c]; }
-            hipLaunchKernelGGL((msntt2::ntt2_mid_pass<false, true, 0>), g, b2, 0, st, A);
+            hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, true, 0>), g, b2, 0, st, A);
         };
         for (int round = 0; round < 2; round++) {
             t = time_us([&] { passes(0, 0, NC, 0); });
