@@ -7,9 +7,15 @@ workload : configs[1] -- a batch of COLS columns of 2^24 canonical-uniform Goldi
            HBM before the timed region.  A "step" = one transform of every column.
 value    : whole-job algorithmic bytes (2 * n * 8 per column: one compulsory read + one
            write) / wall time of the K timed steps, max over ranks.
-N > 1    : one process per GPU (torchrun), columns are independent => each rank owns its
-           own COLS columns (weak scaling), no data-path collective; the only exchange is
-           the timing barrier / max-reduce.
+N > 1    : one process per GPU, columns are independent => each rank owns its own COLS
+           columns (weak scaling), no data-path collective; the only exchange is the timing
+           barrier / max-reduce.  Launch: either `python -m torch.distributed.run
+           --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE /
+           MASTER_* from the environment), or plain `python bench.py --gpus N`: without
+           WORLD_SIZE in the environment the process starts the N ranks itself (127.0.0.1,
+           a free port) and relays rank 0's JSON line.  `n_gpus` on the line is the number
+           of ranks that actually joined the process group; --gpus != that number is an
+           error (exit code 2), never a silently smaller run.
 
 Extra objects on the JSON line:
   roofline     : the transform against the HBM roofline.  achieved = algorithmic bytes of
@@ -64,9 +70,9 @@ def sharded_lde_commit(pl, comm, steps, warmup, log_rows=22, total_cols=32, log_
     n = 1 << log_rows
     N = n << log_blowup
     mine = owned_columns(total_cols, rank, world)
-    rng = np.random.default_rng(0xC5 + rank)
     P = (1 << 64) - (1 << 32) + 1
-    trace = Matrix([GpuVec.from_numpy(pl, rng.integers(0, P, size=n, dtype=np.uint64)) for _ in mine])
+    # column c holds the same values whichever rank owns it: the root on the line is the same for every N
+    trace = Matrix([GpuVec.from_numpy(pl, np.random.default_rng(0xC50000 + c).integers(0, P, size=n, dtype=np.uint64)) for c in mine])
     t_lde = t_x = t_c = 0.0
     root = None
     for it in range(warmup + steps):
@@ -347,6 +353,40 @@ def bench_constraint_eval(pl, with_cpu):
     return out
 
 
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) as children of this process with the
+    environment torch.distributed.run would give them, pass rank 0's stdout (the JSON line) through, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = []
+    for r, pr in enumerate(procs):
+        try:
+            rcs.append(pr.wait(timeout=1800))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            rcs.append(-9)
+    if any(rcs):
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        print(f"bench.py: ranks exited with {rcs}", file=sys.stderr)
+        sys.stdout.write(out0)
+        return max(1, max(abs(c) for c in rcs))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,31 +399,53 @@ def main():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
     ap.add_argument("--mode", choices=["ntt", "lde-commit"], default="ntt", help="lde-commit: only the column-sharded LDE + commitment (any N)")
     ap.add_argument("--no-extras", action="store_true", help="skip the lde_commit / prove / sharded objects")
+    ap.add_argument("--log-rows", type=int, default=22, help="--mode lde-commit: rows of the trace (configs[4]: 2^22)")
+    ap.add_argument("--total-cols", type=int, default=32, help="--mode lde-commit: columns of the trace, sharded over the ranks")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(_spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs", file=sys.stderr)
+        sys.exit(2)
+    # The launcher's own CPU test (tests/test_distributed.py) points these at the g++ simulator build of the library and at gloo;
+    # unset -- always, outside that test -- the product library on the rank's GPU and RCCL (torch's "nccl") are used.
+    lib_path, backend = os.environ.get("MS_BENCH_LIB"), os.environ.get("MS_BENCH_DIST_BACKEND", "nccl")
+    on_gpu = backend == "nccl"
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+        world = dist.get_world_size()
 
     from ministark_amd import GOLDILOCKS_FP, GpuFft, GpuVec, Planner, Radix2EvaluationDomain
     from ministark_amd.distributed import RcclComm
 
     log_n = args.log_n
     n = 1 << log_n
-    pl = Planner(local_rank)
+    if lib_path:
+        from ministark_amd import _lib
+        pl = Planner(local_rank if on_gpu else 0, _lib.Lib(lib_path))     # the simulator has one device
+    else:
+        pl = Planner(local_rank)
 
     def reduce_max(x):
         if dist is None:
             return x
         import torch
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -391,13 +453,14 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
     def run_sharded():
         with _stdout_to_stderr():
             comm = RcclComm.from_torch_distributed(pl) if dist is not None else RcclComm(pl, 0, 1, RcclComm.unique_id(pl.lib))
             try:
-                r = sharded_lde_commit(pl, comm, max(2, min(args.steps, 5)), 1, barrier=dist_barrier)
+                r = sharded_lde_commit(pl, comm, max(2, min(args.steps, 5)), 1, log_rows=args.log_rows, total_cols=args.total_cols, barrier=dist_barrier)
             finally:
                 comm.close()
         for key in ("lde_ms", "exchange_ms", "commit_ms"):
@@ -427,10 +490,7 @@ def main():
 
     def barrier():
         pl.sync()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist_barrier()
 
     # settle: plans built, scratch allocated, clocks up -- before the W untimed warm-up steps the contract asks for
     t_settle = time.perf_counter()
@@ -445,11 +505,7 @@ def main():
         fft.enqueue(cols)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max(elapsed)
 
     # per-kernel durations, measured live with hipEvents on the library's stream
     pl.profile(True)

@@ -90,7 +90,11 @@ int ms_download(ms_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* b
  * ms_ntt_encode        = fft.encode(&mut column): queue one column (n elements, in place)
  * ms_ntt_execute       = fft.execute(): run every queued column, BLOCKS, clears the queue
  *                        (the plan stays usable; the reference consumes it)
- * ms_ntt_enqueue       = encode + launch without blocking (for pipelines and timing) */
+ * ms_ntt_enqueue       = encode + launch without blocking (for pipelines and timing)
+ *
+ * Threads: calls on one context serialise on its lock.  Destroying a plan, or the context it was created on, must not run
+ * concurrently with a call that uses that plan (the liveness check and the use are not one atomic step); a plan that merely
+ * OUTLIVES its context is safe -- its entry points return MS_ERR_INVALID and ms_ntt_plan_destroy is a no-op. */
 int ms_ntt_plan_create(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset,
                        const void* h_group_gen, ms_ntt_plan** out);
 int ms_ntt_plan_destroy(ms_ntt_plan* plan);

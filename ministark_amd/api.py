@@ -522,16 +522,16 @@ class Matrix:
     def get_rows(self, positions):
         """`Matrix::get_row` for every queried position (src/trace.rs:139-152): numpy u64 array
         [len(positions), num_cols * words], Montgomery words, gathered on the device."""
-        pl, L = self.planner, self.planner.lib
-        pos = np.asarray(positions, dtype=np.uint64)
-        words = self.num_cols() * FIELD_WORDS[self.field]
         return self.get_rows_launch(positions)()
 
     def get_rows_launch(self, positions):
+        """Launches the gather and returns the function that fetches its result (callers start every gather of a phase first)."""
         pl, L = self.planner, self.planner.lib
         pos = np.asarray(positions, dtype=np.uint64)
         words = self.num_cols() * FIELD_WORDS[self.field]
-        out = DeviceBytes(pl, max(1, len(pos) * words * 8))
+        if len(pos) == 0:
+            return lambda: np.zeros((0, words), dtype=np.uint64)
+        out = DeviceBytes(pl, len(pos) * words * 8)
         L.check(L.ms_gather_rows(pl.handle, self.field, self.num_rows(), _ptr_array(self.columns), self.num_cols(), pos.ctypes.data, len(pos), out.ptr))
         return lambda: out.to_numpy().view(np.uint64)[: len(pos) * words].reshape(len(pos), words)
 

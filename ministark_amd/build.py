@@ -89,7 +89,10 @@ def build(force=False, verbose=True):
         return obj
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO, "-lhiprtc", "-ldl"]
+    # the link step sees the same architecture / code-generation options as the units (MS_HIPCC_FLAGS may override the arch);
+    # options that only make sense for a compile (-x hip, -c, warnings, -std) stay out
+    link_flags = [f for f in FLAGS + extra if f.startswith(("--offload-arch", "-O", "-f", "-m", "-g"))]
+    link = [HIPCC] + link_flags + ["-shared"] + objs + ["-o", SO, "-lhiprtc", "-ldl"]
     if verbose:
         print("[ministark_amd.build]", " ".join(link), flush=True)
     subprocess.check_call(link)

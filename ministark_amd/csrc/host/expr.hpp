@@ -208,12 +208,16 @@ struct Composition { E expr; unsigned ce_blowup_factor; unsigned num_coeffs; };
 inline Composition composition_constraint(size_t trace_len, const std::vector<E>& constraints) {
     size_t ce = 0;
     for (auto& c : constraints) ce = std::max(ce, constraint_blowup_factor(c, trace_len));
+    // every constraint of degree < trace_len / 2: trace_len * 0 - 1 underflows (the reference panics on the subtraction, the Python
+    // mirror asserts) -- an error here too, not a wrapped degree
+    if (ce == 0) throw std::invalid_argument("composition_constraint: ce_blowup_factor is 0 (every constraint has degree < trace_len / 2)");
     const size_t composition_degree = trace_len * ce - 1;
     E comp;
     for (size_t i = 0; i < constraints.size(); i++) {
         const auto d = degree(constraints[i], trace_len - 1);
         const size_t ev = d.first > d.second ? d.first - d.second : 0;
         if (ev > composition_degree) throw std::invalid_argument("constraint degree exceeds the composition degree");
+        if (composition_degree - ev > 0xFFFFFFFFull) throw std::invalid_argument("composition_constraint: degree adjustment does not fit an exponent");
         E term = constraints[i] * (pow(X(), (uint32_t)(composition_degree - ev)) * Challenge((uint32_t)(2 * i)) + Challenge((uint32_t)(2 * i + 1)));
         comp = comp ? comp + term : term;
     }

@@ -58,6 +58,8 @@ template <class F> inline GpuVec<F> running_product(const GpuVec<F>& factors, co
 // `fold_positions` (src/fri.rs:615-622): strictly increasing positions -> their cosets, deduplicated
 inline std::vector<size_t> fold_positions(const std::vector<size_t>& positions, unsigned folding_factor) {
     std::vector<size_t> out;
+    for (size_t i = 1; i < positions.size(); i++)          // the reference's precondition (src/fri.rs:613), asserted by the Python mirror too
+        if (positions[i] <= positions[i - 1]) throw std::invalid_argument("fold_positions: positions must be strictly increasing");
     for (size_t p : positions) if (out.empty() || out.back() != p / folding_factor) out.push_back(p / folding_factor);
     return out;
 }

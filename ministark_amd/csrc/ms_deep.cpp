@@ -256,6 +256,17 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
     if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
     if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
     const size_t n = (size_t)1 << log_n;
+    // Q is evaluated on the coset h<w_n> and a lane shares ONE inversion between the denominators x - z_k of its points: a point
+    // z_k ON that coset (possible only when it lies in the base field: probability about n / p per drawn point) has no quotient
+    // there and would zero its neighbours' factors as well.  The reference's synthetic division has no such restriction, so this
+    // is reported instead of computed wrongly; the caller re-draws z, as it must when z falls into the trace domain.
+    for (unsigned k = 0; k < npoints; k++) {
+        const uint64_t* zk = (const uint64_t*)h_points + (size_t)k * PW;
+        if (PW == 3 && (zk[1] != 0 || zk[2] != 0)) continue;
+        const uint64_t z = gl::from_mont(zk[0]);
+        if (z != 0 && gl::pow(gl::mul(z, gl::inv(h)), n) == 1)
+            return fail(MS_ERR_INVALID, "ms_deep_compose: out-of-domain point %u lies on the evaluation coset h<w_n> (x - z vanishes there)", k);
+    }
     // scratch: coset evaluations of every polynomial + the evaluation/coefficient column of Q
     std::vector<void*> ev(nbase + next, nullptr);
     void *d_terms = nullptr, *d_q = nullptr;

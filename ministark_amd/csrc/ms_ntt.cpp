@@ -24,7 +24,9 @@ static int plan_build252(ms_ctx* ctx, unsigned log_n, bool inverse, const void* 
 // Plan objects handed to the caller (ms_ntt_plan_create): a plan refers to its context (lock, stream, cached tables), so a
 // context that is destroyed first releases them itself and takes them out of this registry; every entry point that receives
 // a plan looks it up before touching it -- a plan destroyed after its context (a GpuFft collected after Planner.close()) is a
-// no-op, a transform on it an error, never a read of freed memory.
+// no-op, a transform on it an error, never a read of freed memory -- for calls that do not RACE with the teardown: the lookup
+// and the use that follows are two steps, so destroying a plan or its context on one thread while another thread is inside a
+// call on that plan is outside the contract (include/ministark_hip.h, "Threads"), as it is for the reference's plans.
 #include <set>
 static std::mutex g_user_plans_mu;
 static std::set<ms_ntt_plan*> g_user_plans;

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""gpurun_out/profiles_raw/ (scripts/collect_profiles.sh) -> profiles/rNN_* summaries.
-    python scripts/summarise_profiles.py [round_tag]
+"""gpurun_out/profiles_raw/ (scripts/collect_profiles.sh) -> rNN_* summaries.
+    python scripts/summarise_profiles.py round_tag [--raw DIR] [--out DIR]
+Run by collect_profiles.sh on the GPU box right after the measurements (--out gpurun_out/profiles_raw/summary; copy those files to
+profiles/).  Every input must be NEWER than the run's RUN_STAMP file: a raw file left over from an earlier collection (gpurun merges
+gpurun_out/, it does not replace it -- round 3's SQ counter summary was made from round 2's file that way) is refused, and a
+missing counter file is an error, not a skipped section.
 FETCH_SIZE is doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 tallies a coalesced stream at
 64 B); counter units are KB = 1024 B; values are averaged per launch (one launch = one 2^24 column)."""
 import collections
@@ -12,14 +16,36 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+args = sys.argv[1:]
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 PROF = os.path.join(ROOT, "profiles")
+if "--raw" in args:
+    i = args.index("--raw"); RAW = args[i + 1]; del args[i:i + 2]
+if "--out" in args:
+    i = args.index("--out"); PROF = args[i + 1]; del args[i:i + 2]
+tag = args[0] if args else "r04"
+os.makedirs(PROF, exist_ok=True)
+STAMP = os.path.join(RAW, "RUN_STAMP")
+if not os.path.exists(STAMP):
+    sys.exit(f"summarise_profiles: {STAMP} missing -- not the output of scripts/collect_profiles.sh")
+T0 = os.path.getmtime(STAMP)
+problems = []
+
+
+def fresh(path, what):
+    """path if it exists and was written after the run's stamp; otherwise None and a recorded problem"""
+    if path is None or not os.path.exists(path):
+        problems.append(f"{what}: missing")
+        return None
+    if os.path.getmtime(path) < T0 - 1.0:
+        problems.append(f"{what}: {os.path.relpath(path, RAW)} is older than RUN_STAMP (left over from an earlier collection) -- refused")
+        return None
+    return path
 
 
 def one(pattern):
     hits = glob.glob(os.path.join(RAW, pattern), recursive=True)
-    return hits[0] if hits else None
+    return fresh(hits[0] if hits else None, pattern)
 
 
 def counters(path, per_column=False):
@@ -50,8 +76,9 @@ if fetch and write:
     total = 0.0
     # the three launches of ONE forward coset transform (bench.py's other variants -- subgroup, inverse -- run in the
     # same process and must not be added in)
-    trio = ("ntt2_first_pass<false, true, 16", "ntt2_mid_pass<false, false, 0", "ntt2_mid_pass<false, true, 0",
-            "ntt_first_pass<false, true, 16>", "ntt_mid_pass<16, false, false, 0, false>", "ntt_mid_pass<16, false, true, 0, false>")
+    # (round 4: the limb-form kernels' first template argument is the cache-policy switch STREAM)
+    trio = tuple(f"{k}<{st}, {rest}" for st in ("true", "false")
+                 for k, rest in (("ntt2_first_pass", "false, true, 16"), ("ntt2_mid_pass", "false, false, 0"), ("ntt2_mid_pass", "false, true, 0")))
     for k in fc:
         if "msntt" not in k or not any(t in k for t in trio):
             continue
@@ -76,10 +103,13 @@ for name, dst in (("pmc_sq", "ntt_sq_counters"), ("pmc_sha", "sha256_sq_counters
             if "msntt" in k or "mssha" in k:
                 for cn, vals in sorted(c[k].items()):
                     w.writerow([k, len(vals), cn, sum(vals) / len(vals)])
-for src, dst in (("ubench3.txt", f"{tag}_ubench3_field_primitives.txt"), ("ntt_pass_bench.txt", f"{tag}_ntt_pass_bench.txt"),
+for src, dst in (("c2_sweep.json", f"{tag}_c2_sweep.json"), ("c2_sweep_small.json", f"{tag}_c2_sweep_small.json"), ("lde_sq_counters.txt", f"{tag}_lde_sq_counters.txt"),
                  ("bench_lde_commit_n1.json", f"{tag}_bench_lde_commit_n1.json"),
                  ("bench.json", f"{tag}_bench_ntt_2_24.json"), ("bench_configs.jsonl", f"{tag}_bench_configs.jsonl"), ("bench_commit.json", f"{tag}_bench_commit.json")):
     p = os.path.join(RAW, src)
-    if os.path.exists(p) and os.path.getsize(p):
+    if os.path.exists(p) and os.path.getsize(p) and fresh(p, src):
         shutil.copy(p, os.path.join(PROF, dst))
 print(json.dumps(traffic, indent=1)[:1200])
+if problems:
+    print("summarise_profiles: INCOMPLETE\n  " + "\n  ".join(problems), file=sys.stderr)
+    sys.exit(1)

@@ -61,6 +61,41 @@ def test_product_exchange_entry_points_with_more_than_one_rank(tmp_path, world):
         assert open(f).read().split("\n") == want
 
 
+def _bench_env():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    return dict(os.environ, MS_BENCH_LIB=build_emu.build(), MS_BENCH_DIST_BACKEND="gloo", MS_RCCL_LIB=build_emu.build_fake_rccl())
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_gpus_n_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it (the driver's command): the process starts N ranks itself, the ranks join
+    one process group, run the column-sharded LDE + commitment through the product's communicator entry points (here on the simulator
+    build over the shared-memory NCCL stand-in) and rank 0's line reports n_gpus = N and the root of the one-process run."""
+    import json
+    env = _bench_env()
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "lde-commit", "--log-rows", "8", "--total-cols", "4", "--steps", "2"]
+    lines = {}
+    for n in (1, world):
+        r = subprocess.run(cmd + ["--gpus", str(n)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        out = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        assert len(out) == 1, r.stdout.decode()[-2000:]
+        lines[n] = json.loads(out[0])
+    assert lines[world]["n_gpus"] == world and lines[world]["sharded_lde_commit"]["n_gpus"] == world
+    assert lines[1]["n_gpus"] == 1
+    assert lines[world]["sharded_lde_commit"]["root"] == lines[1]["sharded_lde_commit"]["root"] is not None
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus 4 inside a 1-rank environment must not print an n_gpus = 1 line (`--gpus` was parsed and never read)."""
+    env = dict(_bench_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mode", "lde-commit", "--log-rows", "8", "--total-cols", "4"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and not r.stdout.strip() and b"--gpus 4" in r.stderr
+
+
 @pytest.mark.gpu
 def test_rccl_entry_points_world1_hip():
     """The RCCL leg on the single-GPU lease, through the C ABI without torch: ncclGetUniqueId / ncclCommInitRank,

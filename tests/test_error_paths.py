@@ -82,3 +82,29 @@ def test_constraint_programs_are_validated_before_they_run(pl):
 def test_proof_of_work_bits(pl):
     with pytest.raises(MsError, match="<= 64"):
         grind_proof_of_work(pl, bytes(32), 70)
+
+
+def test_deep_point_on_the_evaluation_coset_is_refused(pl):
+    """ms_deep_compose evaluates the quotients on the coset 7<w_n> with one shared inversion per lane: an out-of-domain point ON that
+    coset (Fq = Fp, probability ~ n / p) has no quotient there.  It is an error with a message, not a column of silently zeroed
+    factors; the reference's synthetic division has no such point, the caller re-draws z."""
+    from ministark_amd.composer import DeepCompositionCoeffs, DeepPolyComposer
+    P = (1 << 64) - (1 << 32) + 1
+    n = 64
+    rng = np.random.default_rng(5)
+    mk = lambda k: Matrix([GpuVec.from_numpy(pl, np.array([pow(2, 64, P) * int(x) % P for x in rng.integers(0, P, size=n, dtype=np.uint64)], dtype=np.uint64), FP) for _ in range(k)])
+    g = Radix2EvaluationDomain(n).group_gen
+    z = 7 * pow(g, 5, P) % P
+    composer = DeepPolyComposer([(0, 0), (0, 1)], n, z, mk(1), None, mk(1))
+    composer.get_ood_evals()
+    with pytest.raises(MsError, match="lies on the evaluation coset"):
+        composer.into_deep_poly(DeepCompositionCoeffs([3, 4], [5], (1, 2)))
+    ok = DeepPolyComposer([(0, 0), (0, 1)], n, z + 1, mk(1), None, mk(1))          # next to it: fine
+    ok.get_ood_evals()
+    assert len(ok.into_deep_poly(DeepCompositionCoeffs([3, 4], [5], (1, 2)))) == n
+
+
+def test_get_rows_of_no_positions(pl):
+    m = Matrix([_vec(pl), _vec(pl)])
+    assert m.get_rows([]).shape == (0, 2)
+    assert m.get_rows([3, 1]).shape == (2, 2)
