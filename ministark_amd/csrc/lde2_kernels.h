@@ -1,5 +1,5 @@
-// Two-pass coset transforms for the LDE of columns of n = 256 L points, L = 256 T, T in {2, 4, 8, 16}
-// (2^17 <= n <= 2^20), Goldilocks Fp -- src/matrix.rs:142-251 / src/prover.rs:50-51 for blow-up beta:
+// Two-pass coset transforms for the LDE of columns of n = 256 L points, L = 256 T, T in {2, 4, 8, 16, 32, 64}
+// (2^17 <= n <= 2^22), Goldilocks Fp -- src/matrix.rs:142-251 / src/prover.rs:50-51 for blow-up beta:
 //
 //   the evaluations on the coset h<w_N>, N = beta n, are beta transforms of size n: E_j[k] = sum_i c_i (h w_N^j)^i w_n^(i k),
 //   j < beta, and in the committed bit-reversed order E_j is the CONTIGUOUS block rev(j) n .. rev(j) n + n, itself in
@@ -10,7 +10,9 @@
 //                               (G^L)^i1 (wave-uniform), output k1 at row k1 (in place layout) times (G w_n^k1)^i0, G = h w_N^j;
 //   pass B (lde2_rows_pass)     radix L over i0 on whole contiguous rows: 256 x T with a 16 x 16 x T register / LDS
 //                               decomposition, output k = k1 + 256 k0 written to row rev8(k1) at rev(k0): whole rows of
-//                               L consecutive words again, no scattered store anywhere.
+//                               L consecutive words again, no scattered store anywhere.  T = 32, 64 (round 4: rows of 8192 /
+//                               16384 words, the 2^23 / 2^24-point domains of a 2^21 / 2^22-row trace at blow-up 4): the radix-T
+//                               part is 16 x T1 (T1 = T / 16) with one more exchange, its factor w_T^(t1 s0) wave-uniform.
 //
 // Arithmetic is ntt2_kernels.h's (limb form, wave-uniform twiddles through scalar loads); the two per-lane twiddles are
 // pass A's inter-pass factor (running product, as in ntt2_first_pass) and pass B's w_L^(k t) between its radix-256 and
@@ -42,6 +44,7 @@ struct Params {
     const uint64_t* tin4;      // pass A: [i0h][b][a'] w_256^(a' b) w_n^(a' 64 i0h), 4 plain copies     (between the networks)
     const uint64_t* tout4;     // pass A: [j][i0h][b'] G_j^(64 i0h) w_n^(16 b' 64 i0h), 4 plain copies   (after the second network)
                                // pass B applies (G_j w_n^k1)^t, one value per lane and (wave, half), on its loads
+    const uint64_t* c3;        // pass B, T >= 32: [t1][s0] w_T^(t1 s0), t1 < T / 16, s0 < 16, 4 plain copies (between radix 16 and radix T / 16)
     unsigned log_n, log_b, lo_bits;   // n = 2^log_n points per coset, beta = 2^log_b cosets
 };
 
@@ -190,8 +193,10 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
 static constexpr int X2P = 65;                               // pitch of the second exchange (words): conflict-free both ways
 template <bool STREAM, int T, bool UNI>
 __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
-    constexpr int LOGT = T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
+    constexpr int LOGT = T == 64 ? 6 : T == 32 ? 5 : T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
     constexpr int RSEL = 64 / T;                             // rows per workgroup
+    constexpr int T1 = T > 16 ? T / 16 : 1, LOGT1 = T1 == 4 ? 2 : T1 == 2 ? 1 : 0;     // T >= 32: radix T = 16 x T1
+    constexpr int ITEMP = 16 * T1 + 1;                       // T >= 32: pitch (words) of a (k, row) item in the third exchange
     constexpr int X3WORDS = 8192 + 8192 / 16;               // third exchange: the 8192 words of a round, one pad word per 16
     constexpr int XWORDS = X3WORDS > 128 * X2P ? X3WORDS : 128 * X2P;
     __shared__ uint64_t xch[XWORDS];
@@ -264,6 +269,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             }
         }
         __syncthreads();
+        if constexpr (T <= 16) {
         // the T words of (row, k) pairs: this lane owns pairs pr = threadIdx.x + 512 u, u < T / ... (128 k x RSEL rows = 8192 / T pairs)
         constexpr int NPAIR = (128 * RSEL) / NT;             // pairs per lane and round: 16 / T
         uint64_t out[NPAIR][T];
@@ -304,6 +310,52 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             const unsigned tt = idx & (T - 1), c = (idx >> LOGT) & 15, xq = (idx >> (LOGT + 4)) & 7, rsel = idx >> (LOGT + 7);
             const unsigned k1 = row0 + rsel;
             NTT2_ST(dst + ((size_t)(__brev(k1) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + c * T + tt), (uint64_t)xch[idx + (idx >> 4)], 2);
+        }
+        } else {
+        // ---- T = 16 T1 (T1 = 2, 4): t = t1 + T1 t0, output s = s0 + 16 s1.  Radix 16 over t0 with t1 WAVE-UNIFORM (one (k, row, t1)
+        // item per lane: 128 k x RSEL rows x T1 = 512), times w_T^(t1 s0) from scalar registers, third exchange, radix T1 over t1.
+        {
+            const unsigned t1 = w & (T1 - 1);
+            const unsigned q = (w >> LOGT1) * 64 + lane, kk = q & 127, rsel = q >> 7;
+            glimb::L4 v[16];
+            #pragma unroll
+            for (int t0 = 0; t0 < 16; t0++) v[t0] = glimb::from_u64(xch[kk * X2P + rsel * T + t1 + T1 * t0]);
+            glimb::dft<16, false>(v);
+            __syncthreads();                                  // the second exchange has been read
+            uint64_t* const e3 = xch + (size_t)(rsel * 128 + kk) * ITEMP + t1;
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                glimb::W4 wc[4];
+                w4x4_at(P.c3, t1 * 16 + 4 * g, wc);
+                __builtin_amdgcn_sched_barrier(0);
+                #pragma unroll
+                for (int e = 0; e < 4; e++) e3[(4 * g + e) * T1] = pin(glimb::mul_fold_co(v[4 * g + e], wc[e]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        // radix T1 and the stores: wave = a' (as after the first exchange), lane = (position s0r = rev4(s0) of the run, bq); a lane takes the
+        // chunks rev4(b') = bq + 4 i of its wave's 16 T-word chunks: T1 consecutive words each (bit-reversed order of s1), 16-byte stores
+        {
+            const unsigned s0r = lane & 15, bq = lane >> 4, s0 = __brev(s0r) >> 28;
+            #pragma unroll
+            for (int i = 0; i < 4 * RSEL; i++) {
+                const unsigned brev = bq + 4 * (i & 3), rsel = i >> 2, bp = __brev(brev) >> 28, kk = w * 16 + bp;
+                const uint64_t* const e3 = xch + (size_t)(rsel * 128 + kk) * ITEMP + s0 * T1;
+                glimb::L4 u[T1];
+                #pragma unroll
+                for (int tt = 0; tt < T1; tt++) u[tt] = glimb::from_u64(e3[tt]);
+                glimb::dft<T1, false>(u);
+                const unsigned k1 = row0 + rsel;
+                uint64_t* const o = dst + (size_t)(__brev(k1) >> 24) * L + (size_t)((r + 2 * (__brev(w) >> 29)) * 16 + brev) * T + s0r * T1;
+                if constexpr (T1 == 4) {
+                    NTT2_ST((msntt2::Pair*)o, (msntt2::Pair{glimb::to_canon(u[0]), glimb::to_canon(u[2])}), 2);
+                    NTT2_ST((msntt2::Pair*)(o + 2), (msntt2::Pair{glimb::to_canon(u[1]), glimb::to_canon(u[3])}), 2);
+                } else {
+                    NTT2_ST((msntt2::Pair*)o, (msntt2::Pair{glimb::to_canon(u[0]), glimb::to_canon(u[1])}), 2);
+                }
+            }
+        }
         }
     }
 }

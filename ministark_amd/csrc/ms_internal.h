@@ -148,7 +148,7 @@ struct ms_ntt_plan {
     uint64_t *d_tin4 = nullptr, *d_tout4 = nullptr;
     // two-pass coset LDE (lde2_kernels.h), built on first use on the forward plan of the LDE domain: per blow-up
     // [gpl | aux | t2] in one allocation
-    struct Lde2 { unsigned log_b = 0; uint64_t *d = nullptr, *gpl = nullptr, *aux = nullptr, *t2 = nullptr, *tin4 = nullptr, *tout4 = nullptr; };
+    struct Lde2 { unsigned log_b = 0; uint64_t *d = nullptr, *gpl = nullptr, *aux = nullptr, *t2 = nullptr, *tin4 = nullptr, *tout4 = nullptr, *c3 = nullptr; };
     std::vector<Lde2> lde2;
     uint64_t offset_canon = 1;          // the coset offset h (canonical)
     std::vector<void*> queue;

@@ -694,9 +694,13 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
 }
 
 // ---- two-pass coset LDE (lde2_kernels.h) ------------------------------------------------------------------------------
-// fwd = the forward plan of the LDE domain (N = n << log_b points, offset h).  Applies to Fp columns of 2^17..2^20 rows.
+// fwd = the forward plan of the LDE domain (N = n << log_b points, offset h).  Applies to Fp columns of 2^17..2^22 rows
+// (rows of pass B: n / 256 <= 16384 words = one workgroup's tile).
+#ifndef MS_LDE2_MAX_LOG_N            // (a build with -DMS_LDE2_MAX_LOG_N=20 is the round-3 dispatch, for before / after timings)
+#define MS_LDE2_MAX_LOG_N 22
+#endif
 static bool lde2_applicable(const ms_ntt_plan* fwd, unsigned V, unsigned log_n, unsigned log_b) {
-    return V == 1 && log_n >= 17 && log_n <= 20 && log_b >= 1 && log_b <= 6 && !fwd->small && fwd->d_wr4[0] != nullptr;
+    return V == 1 && log_n >= 17 && log_n <= MS_LDE2_MAX_LOG_N && log_b >= 1 && log_b <= 6 && !fwd->small && fwd->d_wr4[0] != nullptr;
 }
 static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_plan::Lde2** out) {
     for (auto& l : fwd->lde2) if (l.log_b == log_b) { *out = &l; return MS_OK; }
@@ -704,12 +708,14 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
     const uint64_t wN = gl::root_of_unity(log_n + log_b), wL = gl::root_of_unity(log_n - 8), h = fwd->offset_canon;
     const bool uni = T >= 4;                                      // lde2_kernels.h: uniform split of pass A's factor
     const size_t nt = L >> 6, n_tin = uni ? nt * 256 * 4 : 0, n_tout = uni ? beta * nt * 16 * 4 : 0;
-    std::vector<uint64_t> host(beta * 256 * 4 + beta * L + 256 * T * 4 + n_tin + n_tout);
+    const size_t T1 = T > 16 ? T / 16 : 0, n_c3 = T1 * 16 * 4;      // pass B, rows of 8192 / 16384 words: w_T^(t1 s0)
+    std::vector<uint64_t> host(beta * 256 * 4 + beta * L + 256 * T * 4 + n_tin + n_tout + n_c3);
     uint64_t* gpl = host.data();
     uint64_t* aux = gpl + beta * 256 * 4;
     uint64_t* t2 = aux + beta * L;
     uint64_t* tin4 = t2 + 256 * T * 4;
     uint64_t* tout4 = tin4 + n_tin;
+    uint64_t* c3 = tout4 + n_tout;
     const uint64_t sh[4] = {1, (uint64_t)1 << 24, (uint64_t)1 << 48, gl::pow(2, 72)};
     if (uni) {
         const uint64_t wn = gl::root_of_unity(log_n);
@@ -744,12 +750,23 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
         uint64_t x = 1;
         for (size_t t = 0; t < T; t++) { for (int c = 0; c < 4; c++) t2[(k * T + t) * 4 + c] = gl::mul(x, sh[c]); x = gl::mul(x, wk); }          // plain, 4 copies
     }
+    if (T1) {
+        unsigned log_t = 0;
+        while (((size_t)1 << log_t) < T) log_t++;
+        const uint64_t wT = gl::root_of_unity(log_t);
+        for (size_t t1 = 0; t1 < T1; t1++)
+            for (size_t s0 = 0; s0 < 16; s0++) {
+                const uint64_t x = gl::pow(wT, (uint64_t)(t1 * s0));
+                for (int c = 0; c < 4; c++) c3[(t1 * 16 + s0) * 4 + c] = gl::mul(x, sh[c]);
+            }
+    }
     ms_ntt_plan::Lde2 l;
     l.log_b = log_b;
     if (hipMalloc(&l.d, host.size() * 8) != hipSuccess) return fail(MS_ERR_NOMEM, "LDE tables (%zu bytes)", host.size() * 8);
     if (hipMemcpy(l.d, host.data(), host.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(l.d); return fail(MS_ERR_HIP, "LDE table upload"); }
     l.gpl = l.d; l.aux = l.d + beta * 256 * 4; l.t2 = l.aux + beta * L;
     if (uni) { l.tin4 = l.t2 + 256 * T * 4; l.tout4 = l.tin4 + n_tin; }
+    if (T1) l.c3 = l.t2 + 256 * T * 4 + n_tin + n_tout;
     fwd->lde2.push_back(l);
     *out = &fwd->lde2.back();
     return MS_OK;
@@ -771,7 +788,7 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
         const unsigned nc = std::min(group, ncols - c0);
         mslde2::Params P;
         memset(&P, 0, sizeof P);
-        P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2; P.tin4 = tb->tin4; P.tout4 = tb->tout4;
+        P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2; P.tin4 = tb->tin4; P.tout4 = tb->tout4; P.c3 = tb->c3;
         const bool uni = tb->tin4 != nullptr;
         const bool stream_hint = 2 * (size_t)nc * col_bytes > ((size_t)256 << 20);       // as for the transforms above
         P.tw_lo = fwd->d_tw_lo; P.tw_hi = fwd->d_tw_hi; P.lo_bits = fwd->lo_bits; P.log_n = log_n; P.log_b = log_b;
@@ -791,6 +808,8 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
 #define MS_RB(T_, UNI_) do { if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, T_, UNI_>), g, b, 0, st, P); \
                              else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, T_, UNI_>), g, b, 0, st, P); } while (0)
             switch (T) {
+            case 64: MS_RB(64, true); break;
+            case 32: MS_RB(32, true); break;
             case 16: if (uni) MS_RB(16, true); else MS_RB(16, false); break;
             case 8: if (uni) MS_RB(8, true); else MS_RB(8, false); break;
             case 4: if (uni) MS_RB(4, true); else MS_RB(4, false); break;

@@ -4,7 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ministark_amd import GOLDILOCKS_FP, Matrix, Planner
 
-pl = Planner(0)
+if os.environ.get("MS_LIB"):                      # a second build of the library (before / after timings)
+    from ministark_amd import _lib
+    pl = Planner(0, _lib.Lib(os.environ["MS_LIB"]))
+else:
+    pl = Planner(0)
 log_n, log_b, ncols = int(os.environ.get("LOGN", 20)), int(os.environ.get("LOGB", 3)), int(os.environ.get("NCOLS", 32))
 rng = np.random.default_rng(3)
 P = (1 << 64) - (1 << 32) + 1

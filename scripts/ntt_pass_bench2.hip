@@ -69,20 +69,21 @@ int main(int argc, char** argv) {
     Q.log_n = log_n; Q.V = 1; Q.valid_rows = 256; Q.lo_bits = 12; Q.tin4 = tin4; Q.tout4 = tout4; Q.r3 = 8;
     const msntt::DigitField f1[2] = {{0, 8, 255}, {8, 0, 255}};
     const dim3 b2(msntt2::NT);
+    unsigned scr_of = 0xFFFFFFFFu;      // chain modes: every column through scratch column scr_of
     auto pass = [&](int q, hipStream_t st, unsigned c0, unsigned nc) {
         msntt2::Params A = Q;
         const dim3 g((unsigned)(n / msntt2::TILE), nc);
         if (q == 0) {
             A.log_s = 0; A.nfields = 2; A.fields[0] = f1[0]; A.fields[1] = f1[1];
-            for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = scr[c0 + c]; }
+            for (unsigned c = 0; c < nc; c++) { A.src[c] = cols[c0 + c]; A.dst[c] = scr[scr_of == 0xFFFFFFFFu ? c0 + c : scr_of + c]; }
             hipLaunchKernelGGL((msntt2::ntt2_first_pass<true, false, true, 16, true, true>), g, b2, 0, st, A);
         } else if (q == 1) {
             A.log_s = 8; A.nfields = 1; A.fields[0] = {0, 0, 255};
-            for (unsigned c = 0; c < nc; c++) { A.src[c] = scr[c0 + c]; A.dst[c] = scr[c0 + c]; }
+            for (unsigned c = 0; c < nc; c++) { A.src[c] = A.dst[c] = scr[scr_of == 0xFFFFFFFFu ? c0 + c : scr_of + c]; }
             hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, false, 0, true, true>), g, b2, 0, st, A);
         } else {
             A.log_s = 16; A.nfields = 0;
-            for (unsigned c = 0; c < nc; c++) { A.src[c] = scr[c0 + c]; A.dst[c] = cols[c0 + c]; }
+            for (unsigned c = 0; c < nc; c++) { A.src[c] = scr[scr_of == 0xFFFFFFFFu ? c0 + c : scr_of + c]; A.dst[c] = cols[c0 + c]; }
             hipLaunchKernelGGL((msntt2::ntt2_mid_pass<true, false, true, 0>), g, b2, 0, st, A);
         }
     };
@@ -93,6 +94,21 @@ int main(int argc, char** argv) {
         const double tt = time_us([&] { pass(0, 0, 0, NC); pass(1, 0, 0, NC); pass(2, 0, 0, NC); }) / NC;
         printf("%-10s pass 1 %6.1f  pass 2 %6.1f  pass 3 %6.1f  sum %6.1f   transform (batch order) %6.1f us/column = %.3f of 8 TB/s\n",
                tag, t1, t2, t3, t1 + t2 + t3, tt, 268435456.0 / (tt * 1e-6) / 8e12);
+        // chain per column through ONE scratch column (128 MiB: stays in the Infinity Cache), one stream; and two chains on two streams
+        scr_of = 0;
+        const double tc = time_us([&] { for (unsigned c = 0; c < NC; c++) { pass(0, 0, c, 1); pass(1, 0, c, 1); pass(2, 0, c, 1); } }) / NC;
+        static hipStream_t s2[2] = {nullptr, nullptr};
+        static hipEvent_t ev[3];
+        if (!s2[0]) { for (int i = 0; i < 2; i++) CK(hipStreamCreateWithFlags(&s2[i], hipStreamNonBlocking)); for (int i = 0; i < 3; i++) CK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); }
+        const double tc2 = time_us([&] {
+            CK(hipEventRecord(ev[2], 0));
+            for (int i = 0; i < 2; i++) CK(hipStreamWaitEvent(s2[i], ev[2], 0));
+            for (unsigned c = 0; c < NC; c++) { scr_of = c & 1; pass(0, s2[c & 1], c, 1); pass(1, s2[c & 1], c, 1); pass(2, s2[c & 1], c, 1); }
+            for (int i = 0; i < 2; i++) { CK(hipEventRecord(ev[i], s2[i])); CK(hipStreamWaitEvent(0, ev[i], 0)); }
+        }) / NC;
+        scr_of = 0xFFFFFFFFu;
+        printf("%-10s chain per column, one scratch column: %6.1f us/column = %.3f;  two chains on two streams (two scratch columns): %6.1f = %.3f\n",
+               tag, tc, 268435456.0 / (tc * 1e-6) / 8e12, tc2, 268435456.0 / (tc2 * 1e-6) / 8e12);
         fflush(stdout);
     }
     return 0;

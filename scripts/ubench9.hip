@@ -100,6 +100,42 @@ __global__ void __launch_bounds__(512, 4) k_tile(Cols C) {
     }
 }
 
+// L8 / S8 with non-temporal loads and stores; MODE 1 = pass 1 (rows at stride 2^16 words in, 64 runs of 256 words out with the product's
+// permuted 16-byte stores -- ntt2_first_pass<.., PERM>), MODE 2 / 3 as above
+template <int MODE, int SPIN, bool NT>
+__global__ void __launch_bounds__(512, 4) k_tile_nt(Cols C) {
+    const uint64_t* __restrict__ src = C.src[blockIdx.y];
+    uint64_t* __restrict__ dst = C.dst[blockIdx.y];
+    const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ uint64_t occ[8192];
+    occ[tid] = tid;
+    size_t rbase, rstride;
+    if (MODE == 1) { const unsigned j2 = blockIdx.x >> 2, g = blockIdx.x & 3; rbase = (size_t)j2 * 256 + 64 * g; rstride = 65536; }
+    else geom<MODE>(blockIdx.x, rbase, rstride);
+    uint64_t v[32];
+    #pragma unroll
+    for (int i = 0; i < 32; i++) { const uint64_t* p = src + rbase + (size_t)(w + 8 * i) * rstride + lane; v[i] = NT ? __builtin_nontemporal_load(p) : *p; }
+    #pragma unroll
+    for (int i = 0; i < 32; i++) v[i] = work<SPIN>(v[i]);
+    __syncthreads();
+    v[0] += occ[tid ^ 64] >> 20;
+    if (MODE == 1) {
+        typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+        const unsigned j2 = blockIdx.x >> 2, g = blockIdx.x & 3, c3 = lane & 7, tl = lane >> 3;
+        #pragma unroll
+        for (int i = 0; i < 32; i += 2) {
+            const unsigned r = i >> 4, d = i & 15, t = 8 * w + tl;
+            const unsigned pos = r * 128 + (d >> 1) * 16 + c3 * 2;
+            v2* p = (v2*)(dst + ((size_t)(64 * g + t) * 256 + j2) * 256 + pos);
+            v2 val; val.x = v[i]; val.y = v[i + 1];
+            if (NT) __builtin_nontemporal_store(val, p); else *p = val;
+        }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < 32; i++) { uint64_t* p = dst + rbase + (size_t)(w + 8 * i) * rstride + lane; if (NT) __builtin_nontemporal_store(v[i], p); else *p = v[i]; }
+    }
+}
+
 // 256 rows x 128 words, 1024 threads, one 1 KiB row run per wave instruction; 16 words per lane
 template <int MODE, int SPIN>
 __global__ void __launch_bounds__(1024) k_tile_w128(Cols C) {
@@ -252,5 +288,17 @@ int main() {
     }
     run_mode<3, 8>();
     run_mode<3, 26>();
+    for (int round = 0; round < 2; round++) {
+        Cols C1; for (int c = 0; c < NCOL; c++) { C1.src[c] = IN[c]; C1.dst[c] = SCR[c]; }
+        const Cols C2 = cols<2>(), C3 = cols<3>();
+        timeit("pass 1 pattern (permuted 16-byte stores), default policy, 17 units", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, false>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 1 pattern (permuted 16-byte stores), non-temporal,   17 units", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 2 pattern, default policy, 17 units", [&] { hipLaunchKernelGGL((k_tile_nt<2, 17, false>), dim3(1024, NCOL), dim3(512), 0, 0, C2); });
+        timeit("pass 2 pattern, non-temporal,   17 units", [&] { hipLaunchKernelGGL((k_tile_nt<2, 17, true>), dim3(1024, NCOL), dim3(512), 0, 0, C2); });
+        timeit("pass 3 pattern, default policy, 17 units", [&] { hipLaunchKernelGGL((k_tile_nt<3, 17, false>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
+        timeit("pass 3 pattern, non-temporal,   17 units", [&] { hipLaunchKernelGGL((k_tile_nt<3, 17, true>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
+        timeit("pass 3 pattern, non-temporal,    0 units", [&] { hipLaunchKernelGGL((k_tile_nt<3, 0, true>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
+        timeit("pass 2 pattern, non-temporal,    0 units", [&] { hipLaunchKernelGGL((k_tile_nt<2, 0, true>), dim3(1024, NCOL), dim3(512), 0, 0, C2); });
+    }
     return 0;
 }

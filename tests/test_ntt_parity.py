@@ -391,9 +391,11 @@ def test_lde_fq3_emu():
 
 @pytest.mark.parametrize("log_n,log_b,bit_reversed", [(17, 1, True), (17, 2, False),
                                                       # T = 4, 8, 16: the uniform split of pass A's factor (per-lane remainder in pass B)
-                                                      (18, 2, True), (19, 1, True), (20, 1, False)])
+                                                      (18, 2, True), (19, 1, True), (20, 1, False),
+                                                      # T = 32, 64 (round 4): rows of 8192 / 16384 words, radix T = 16 x T1 with a third exchange
+                                                      (21, 1, True), (22, 1, True)])
 def test_lde_two_pass_cosets_emu(log_n, log_b, bit_reversed):
-    """lde2_kernels.h (columns of 2^17..2^20 rows: beta coset transforms in two passes each), smallest size, T = 2."""
+    """lde2_kernels.h (columns of 2^17..2^22 rows: beta coset transforms in two passes each), smallest blow-ups."""
     _lde("emu", GOLDILOCKS_FP, log_n, log_b, ncols=2, bit_reversed=bit_reversed)
 
 
@@ -403,6 +405,17 @@ def test_lde_two_pass_cosets_hip(log_n, log_b):
     """every row-length instantiation of lde2_rows_pass (T = 2, 4, 8, 16) and blow-ups 2..32"""
     _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=3)
     _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=1, bit_reversed=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,log_b", [(21, 1), (21, 3), (22, 2), (22, 1)])
+def test_large_lde_random_hip(log_n, log_b):
+    """the two-pass coset LDE on rows of 8192 / 16384 words (lde2_rows_pass<32 / 64>): BASELINE configs[4]'s 2^22-row trace at blow-up 4
+    (a 2^24-point domain), its neighbours, natural and bit-reversed order, and ms_evaluate's entry on the same kernels"""
+    _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=3)
+    _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=1, bit_reversed=False)
+    if log_b == 2:
+        _evaluate("hip", GOLDILOCKS_FP, log_n, log_b, ncols=2)
 
 
 @pytest.mark.gpu
