@@ -241,6 +241,11 @@ int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_digests, const
  * (MS_ERR_INVALID otherwise). */
 int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
                 const void* h_offset, const void* d_evals, void* d_out);
+/* ms_fri_fold_rows: the same fold on a ROW SHARD of the layer -- chunks [first_chunk, first_chunk + nchunks) of the 2^log_n /
+ * folding_factor chunks; d_evals holds those nchunks * folding_factor evaluations, d_out receives nchunks.  (A chunk folds from its own
+ * values and its position alone: the multi-GPU FRI prover keeps every layer sharded by rows and folds without communication.) */
+int ms_fri_fold_rows(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
+                     const void* h_offset, size_t first_chunk, size_t nchunks, const void* d_evals, void* d_out);
 
 /* ---- DEEP composition (host-side and sequential in the reference):
  * DeepPolyComposer::get_ood_evals / into_deep_poly (src/composer.rs:43-188).  `point_field` is Fq
@@ -255,9 +260,21 @@ int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor,
  *                  (point_field; the caller appends the composition-trace polynomials there), ood_t must be
  *                  P_ct(z_pt) (from ms_horner_eval).  Equals divide_out_point(s)_into + sum_columns + the
  *                  degree adjustment of src/composer.rs:89-188, computed through n coset evaluations.
- *                  h_offset: coset used internally (Fp, NULL = the generator 7).  Asynchronous. */
+ *                  h_offset: coset used internally (Fp, NULL = the generator 7).  Asynchronous.
+ * ms_deep_rows     the same polynomial EVALUATED at rows [first, first + count) of the bit-reversed LDE domain (2^log_domain
+ *                  points, offset h_offset, NULL = 7) from those rows of the committed LDE columns (d_base_rows: Fp,
+ *                  d_ext_rows: point_field; `count` elements each): deep_composition_poly.into_bit_reversed_evaluations
+ *                  (src/prover.rs:149-152) without forming the coefficients -- the quotient is a polynomial, so its values
+ *                  at the LDE points are these, bit for bit.  With first = 0, count = 2^log_domain one GPU's whole first FRI
+ *                  layer; with a row shard (rank r of G: first = r 2^log_domain / G) the multi-GPU form, no communication.
+ *                  Goldilocks fields.  Asynchronous. */
 int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, size_t n, const void* const* d_cols, unsigned ncols,
                    const unsigned* h_qcol, const void* h_qpoints, unsigned nq, void* h_out);
+int ms_deep_rows(ms_ctx* ctx, int point_field, unsigned log_domain, const void* h_offset, size_t first, size_t count,
+                 const void* const* d_base_rows, unsigned nbase, const void* const* d_ext_rows, unsigned next,
+                 const void* h_points, unsigned npoints, const unsigned* h_term_col, const unsigned* h_term_point,
+                 const void* h_term_alpha, const void* h_term_ood, unsigned nterms,
+                 const void* h_degree_alpha, const void* h_degree_beta, void* d_out);
 int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, const void* h_offset,
                     const void* const* d_base_polys, unsigned nbase, const void* const* d_ext_polys, unsigned next,
                     const void* h_points, unsigned npoints, const unsigned* h_term_col, const unsigned* h_term_point,

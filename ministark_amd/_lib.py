@@ -70,10 +70,12 @@ class Lib:
             "ms_gather_rows": (i, [vp, i, sz, c_void_pp, u, vp, sz, vp]),
             "ms_gather_digests": (i, [vp, sz, vp, vp, sz, vp]),
             "ms_fri_fold": (i, [vp, i, u, u, vp, vp, vp, vp]),
+            "ms_fri_fold_rows": (i, [vp, i, u, u, vp, vp, sz, sz, vp, vp]),
             "ms_sha256_rows": (i, [vp, i, sz, c_void_pp, u, vp]),
             "ms_sha256_merkle": (i, [vp, sz, vp, vp]),
             "ms_horner_eval": (i, [vp, i, i, sz, c_void_pp, u, vp, vp, u, vp]),
             "ms_deep_compose": (i, [vp, i, u, vp, c_void_pp, u, c_void_pp, u, vp, u, vp, vp, vp, vp, u, vp, vp, vp]),
+            "ms_deep_rows": (i, [vp, i, u, vp, sz, sz, c_void_pp, u, c_void_pp, u, vp, u, vp, vp, vp, vp, u, vp, vp, vp]),
             "ms_sha256_pow_grind": (i, [vp, vp, u, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
             "ms_rpo256_rows": (i, [vp, sz, c_void_pp, u, vp]),
             "ms_rpo256_rows_row_major": (i, [vp, sz, u, vp, vp]),

@@ -208,6 +208,36 @@ def _gather_digests(planner, digests, ndigests, ids):
 HASHES = ("sha256", "rpo256")
 
 
+def merkle_view_ids(n, indices):
+    """The index walk of `MerkleTreeImpl::prove` (src/merkle.rs:149-206) over a tree of n leaves: -> (leaf_ids, initial, sibling,
+    node_ids): the leaves to fetch (initial / sibling: which of them are the queried ones / their siblings) and the internal nodes of
+    the batched opening, in the reference's order.  Indices only -- a single-device tree and a row-sharded one walk the same lists."""
+    for i in indices:
+        if i >= n:
+            raise IndexError(f"leaf index {i} out of bounds ({n})")         # Error::LeafIndexOutOfBounds
+    leaf_ids, initial, sibling = [], [], []
+    node_queue = deque()
+    leaf_queue = deque(sorted(set(int(i) for i in indices)))
+    while leaf_queue:
+        index = leaf_queue.popleft()
+        initial.append(len(leaf_ids)); leaf_ids.append(index)
+        node_queue.append((n + index) >> 1)
+        if leaf_queue and (index ^ 1) == leaf_queue[0]:
+            initial.append(len(leaf_ids)); leaf_ids.append(leaf_queue.popleft())
+            continue
+        sibling.append(len(leaf_ids)); leaf_ids.append(index ^ 1)
+    node_ids = []
+    while node_queue:
+        index = node_queue.popleft()
+        if index > 2:
+            node_queue.append(index >> 1)
+        if node_queue and (index ^ 1) == node_queue[0]:
+            node_queue.popleft()
+            continue
+        node_ids.append(index ^ 1)
+    return leaf_ids, initial, sibling, node_ids
+
+
 class MerkleTree:
     """`MatrixMerkleTreeImpl<H>` (src/merkle.rs:296-361): `from_matrix` hashes the rows and builds the node
     array on device; `root` is nodes[1] (src/merkle.rs:145-147).  H is selected by `hash`:
@@ -262,29 +292,7 @@ class MerkleTree:
     def prove_launch(self, indices):
         """`prove` in two halves: the device gathers are launched now, the returned function fetches and assembles the view."""
         n = self.nleaves
-        for i in indices:
-            if i >= n:
-                raise IndexError(f"leaf index {i} out of bounds ({n})")         # Error::LeafIndexOutOfBounds
-        leaf_ids, initial, sibling = [], [], []
-        node_queue = deque()
-        leaf_queue = deque(sorted(set(int(i) for i in indices)))
-        while leaf_queue:
-            index = leaf_queue.popleft()
-            initial.append(len(leaf_ids)); leaf_ids.append(index)
-            node_queue.append((n + index) >> 1)
-            if leaf_queue and (index ^ 1) == leaf_queue[0]:
-                initial.append(len(leaf_ids)); leaf_ids.append(leaf_queue.popleft())
-                continue
-            sibling.append(len(leaf_ids)); leaf_ids.append(index ^ 1)
-        node_ids = []
-        while node_queue:
-            index = node_queue.popleft()
-            if index > 2:
-                node_queue.append(index >> 1)
-            if node_queue and (index ^ 1) == node_queue[0]:
-                node_queue.popleft()
-                continue
-            node_ids.append(index ^ 1)
+        leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices)
         fetch_leaves = _gather_digests_launch(self.planner, self.leaves, n, leaf_ids)
         fetch_nodes = _gather_digests_launch(self.planner, self.nodes, n, node_ids)
 

@@ -43,6 +43,15 @@ def _from_words(w):
     return tuple(gl_from_mont(int(x)) for x in w) if len(w) == 3 else gl_from_mont(int(w[0]))
 
 
+class _Cols:
+    """stands in for a polynomial matrix where only its column count matters"""
+    def __init__(self, k):
+        self.k = k
+
+    def num_cols(self):
+        return self.k
+
+
 class DeepCompositionCoeffs:                      # src/composer.rs:191-198
     def __init__(self, execution_trace, composition_trace, degree):
         self.execution_trace, self.composition_trace, self.degree = execution_trace, composition_trace, degree
@@ -69,6 +78,22 @@ class DeepPolyComposer:
         self.nbase = base_trace_polys.num_cols()
         self.next = extension_trace_polys.num_cols() if extension_trace_polys is not None else 0
         self._ood = None
+
+    @classmethod
+    def for_row_shards(cls, trace_arguments, trace_len, z, planner, nbase, next_, ncomp, ood, base_field=GOLDILOCKS_FP):
+        """The composer of a rank of the multi-GPU prover (ministark_amd.distributed.prove_sharded): no rank holds every polynomial --
+        the out-of-domain evaluations `ood` = (execution, composition) were computed by the columns' owners and gathered -- and
+        into_deep_evaluations works on the rank's rows of the committed LDEs.  Columns are numbered as on one device."""
+        self = cls.__new__(cls)
+        self.args, self.z, self.n, self.planner, self.base_field = list(trace_arguments), z, trace_len, planner, base_field
+        self.base = self.ext = None
+        self.comp = _Cols(ncomp)
+        self.p = F252_P if base_field == STARK252_FP else GL_P
+        self.fq = GOLDILOCKS_FQ3 if isinstance(z, tuple) else base_field
+        d = Radix2EvaluationDomain(trace_len, 1, base_field)
+        self.g, self.g_inv = d.group_gen, d.group_gen_inv
+        self.nbase, self.next, self._ood = nbase, next_, ood
+        return self
 
     def _point(self, offset):
         gen = self.g if offset >= 0 else self.g_inv
@@ -100,12 +125,12 @@ class DeepPolyComposer:
         self._ood = (execution, composition)
         return execution, composition
 
-    def into_deep_poly(self, coeffs):             # src/composer.rs:89-188
+    def _terms(self, coeffs):
+        """the DEEP composition's terms (column, point, alpha, P(point)) in the order of src/composer.rs:89-165; columns are numbered
+        base | extension | composition-trace"""
         if self._ood is None:
             self.get_ood_evals()
         execution, composition = self._ood
-        pl, L = self.planner, self.planner.lib
-        pw = FIELD_WORDS[self.fq]
         points, pindex = [], {}
 
         def pid(p):
@@ -114,25 +139,54 @@ class DeepPolyComposer:
                 points.append(p)
             return pindex[p]
         z_n = _q_pow(self.z, self.comp.num_cols(), self.p)
-        ext_cols = (list(self.ext.columns) if self.ext is not None else []) + list(self.comp.columns)
         tcol, tpoint, talpha, tood = [], [], [], []
         for c in range(self.comp.num_cols()):
             tcol.append(self.nbase + self.next + c); tpoint.append(pid(z_n)); talpha.append(coeffs.composition_trace[c]); tood.append(composition[c])
         for (c, o), alpha, val in zip(self.args, coeffs.execution_trace, execution):
             tcol.append(c); tpoint.append(pid(self._point(o))); talpha.append(alpha); tood.append(val)
+        return points, tcol, tpoint, talpha, tood
+
+    def _compose(self, entry, head_args, coeffs, base_cols, ext_cols, comp_cols, out):
+        points, tcol, tpoint, talpha, tood = self._terms(coeffs)
+        pl, L = self.planner, self.planner.lib
+        ext_all = list(ext_cols) + list(comp_cols)
         if self.fq != GOLDILOCKS_FQ3:
-            base_cols, ext_list = list(self.base.columns) + ext_cols, []      # Fq = Fp: everything is a base column
+            base_list, ext_list = list(base_cols) + ext_all, []              # Fq = Fp: everything is a base column
         else:
-            base_cols, ext_list = list(self.base.columns), ext_cols
+            base_list, ext_list = list(base_cols), ext_all
         VP = ctypes.c_void_p
-        out = GpuVec(pl, self.n, self.fq)
         flat = lambda qs: np.array([w for q in qs for w in _words(q, self.fq)], dtype=np.uint64)
         pts, al, od = flat(points), flat(talpha), flat(tood)
         da, db = flat([coeffs.degree[0]]), flat([coeffs.degree[1]])
-        L.check(L.ms_deep_compose(pl.handle, self.fq, self.n.bit_length() - 1, None,
-                                  (VP * max(1, len(base_cols)))(*[c.ptr for c in base_cols]), len(base_cols),
-                                  (VP * max(1, len(ext_list)))(*[c.ptr for c in ext_list]), len(ext_list),
-                                  pts.ctypes.data, len(points), (ctypes.c_uint * len(tcol))(*tcol), (ctypes.c_uint * len(tpoint))(*tpoint),
-                                  al.ctypes.data, od.ctypes.data, len(tcol), da.ctypes.data, db.ctypes.data, out.ptr))
+        L.check(entry(pl.handle, self.fq, *[a.ctypes.data if isinstance(a, np.ndarray) else a for a in head_args],
+                      (VP * max(1, len(base_list)))(*[c.ptr for c in base_list]), len(base_list),
+                      (VP * max(1, len(ext_list)))(*[c.ptr for c in ext_list]), len(ext_list),
+                      pts.ctypes.data, len(points), (ctypes.c_uint * len(tcol))(*tcol), (ctypes.c_uint * len(tpoint))(*tpoint),
+                      al.ctypes.data, od.ctypes.data, len(tcol), da.ctypes.data, db.ctypes.data, out.ptr))
         pl.sync()
         return out
+
+    def into_deep_poly(self, coeffs):             # src/composer.rs:89-188
+        ext_cols = list(self.ext.columns) if self.ext is not None else []
+        return self._compose(self.planner.lib.ms_deep_compose, (self.n.bit_length() - 1, None), coeffs, self.base.columns, ext_cols,
+                             self.comp.columns, GpuVec(self.planner, self.n, self.fq))
+
+    def into_deep_evaluations(self, coeffs, base_lde, ext_lde, comp_lde, domain_size, first=0, offset=None):
+        """`into_deep_poly(coeffs)` followed by `into_bit_reversed_evaluations(lde_domain)` (src/prover.rs:149-152) in one step and
+        without the transforms: the composition polynomial's values at rows [first, first + count) of the bit-reversed LDE domain
+        (domain_size points, coset offset `offset`, default 7), computed from those rows of the committed LDE matrices -- the same
+        field elements (the quotient is a polynomial).  The matrices hold `count` rows: the whole domain on one GPU, or a rank's
+        row shard (ministark_amd.distributed.prove_sharded)."""
+        if self.base_field == STARK252_FP:
+            raise ValueError("into_deep_evaluations: Goldilocks fields")
+        count = base_lde.num_rows()
+        ext_cols = list(ext_lde.columns) if ext_lde is not None else []
+        for m in ([base_lde, comp_lde] + ([ext_lde] if ext_lde is not None else [])):
+            if m.num_rows() != count:
+                raise ValueError("LDE matrices of different heights")
+        off = None
+        if offset is not None:
+            from .api import _offset_words
+            off = _offset_words(GOLDILOCKS_FP, offset)          # (kept alive by head_args until the call has returned)
+        return self._compose(self.planner.lib.ms_deep_rows, (domain_size.bit_length() - 1, off, first, count), coeffs, base_lde.columns,
+                             ext_cols, comp_lde.columns, GpuVec(self.planner, count, self.fq))

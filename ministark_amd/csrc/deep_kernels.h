@@ -203,6 +203,12 @@ struct DeepParams {
     size_t n;
     unsigned nbase, nterms, npoints, lo_bits, xshift;
     unsigned term_start[MAXPOINTS + 1];   // terms are sorted by point: those of point k are [term_start[k], term_start[k + 1])
+    // ms_deep_rows: the n inputs are ROWS [first, first + n) of LDE columns over a domain of 2^log_dom points in bit-reversed
+    // order (log_dom = 0: natural order from 0, the coset of ms_deep_compose); adjust: the result is multiplied by
+    // (adj_alpha + adj_beta x), the degree adjustment of src/composer.rs:170-186 applied pointwise
+    size_t first;
+    unsigned log_dom, adjust;
+    uint64_t adj_alpha[3], adj_beta[3];
 };
 // PTS points per lane (points i, i + NT, ... of the workgroup's NT * PTS: coalesced): their PTS * npoints denominators x - z_k
 // share ONE inversion (Montgomery's trick: 72 products for Fp, more for Fq3, against 3 per denominator), and the terms arrive
@@ -213,14 +219,18 @@ template <int PW, int PTS, int MP>       // MP: the most distinct points this in
 __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
     const size_t i0 = (size_t)blockIdx.x * (NT * PTS) + threadIdx.x;
     Q d[PTS][MP], pre[PTS][MP];
+    uint64_t xv[PTS];
     Q run = {{gl::ONE_MONT, 0, 0}};
     #pragma unroll
     for (int j = 0; j < PTS; j++) {
         const size_t i = i0 + (size_t)j * NT;
-        const size_t e = (i < P.n ? i : 0) << P.xshift;
+        size_t nat = i < P.n ? i : 0;
+        if (P.log_dom) nat = (size_t)(__brevll((unsigned long long)(P.first + nat)) >> (64 - P.log_dom));      // position -> point index
+        const size_t e = nat << P.xshift;
         uint64_t xs = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
         if (e >> P.lo_bits) xs = gld::mmul(xs, P.tw_hi[e >> P.lo_bits]);
         xs = gld::mmul(xs, P.h_mont);
+        xv[j] = xs;
         const Q x = {{xs, 0, 0}};
         #pragma unroll
         for (int k = 0; k < MP; k++) if (k < (int)P.npoints) {
@@ -268,6 +278,13 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
     for (int j = 0; j < PTS; j++) {
         const size_t i = i0 + (size_t)j * NT;
         if (i >= P.n) continue;
+        if (P.adjust) {
+            const Q a = {{P.adj_alpha[0], P.adj_alpha[1], P.adj_alpha[2]}}, b = {{P.adj_beta[0], P.adj_beta[1], P.adj_beta[2]}};
+            Q bx = q_zero<PW>();
+            #pragma unroll
+            for (int w = 0; w < PW; w++) bx.w[w] = gld::mmul(b.w[w], xv[j]);
+            acc[j] = q_mul<PW>(acc[j], q_add<PW>(a, bx));
+        }
         #pragma unroll
         for (int w = 0; w < PW; w++) P.out[PW * i + w] = acc[j].w[w];
     }

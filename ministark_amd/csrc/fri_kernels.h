@@ -30,16 +30,16 @@ struct FoldParams {
     unsigned log_m;            // bits 0-7: log2(n / ff) = number of chunks; bits 8+: log2(table size / n)
     uint64_t hinv;             // h^-1, Montgomery form
     uint64_t alpha[3];         // Montgomery form; Fp: alpha[0]
+    size_t c0, count;          // this call folds chunks [c0, c0 + count) of the layer; src / dst point at chunk c0 (ms_fri_fold: 0, all)
 };
 
 template <int FF, int V>
 __global__ void __launch_bounds__(NT) fri_fold(FoldParams P) {
     const size_t c = (size_t)blockIdx.x * NT + threadIdx.x;
     const unsigned log_m = P.log_m & 255, tshift = P.log_m >> 8;
-    const size_t m = (size_t)1 << log_m;
-    if (c >= m) return;
-    // x_i^-1 = h^-1 w_n^-i,  i = bitrev(c);  the table holds powers of w_N^-1 with N = n << tshift
-    const size_t i = log_m ? (size_t)(__brevll((unsigned long long)c) >> (64 - log_m)) : 0;
+    if (c >= P.count) return;
+    // x_i^-1 = h^-1 w_n^-i,  i = bitrev(c0 + c);  the table holds powers of w_N^-1 with N = n << tshift
+    const size_t i = log_m ? (size_t)(__brevll((unsigned long long)(P.c0 + c)) >> (64 - log_m)) : 0;
     const size_t e = i << tshift;
     uint64_t xinv = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
     if (e >> P.lo_bits) xinv = gld::mmul(xinv, P.tw_hi[e >> P.lo_bits]);

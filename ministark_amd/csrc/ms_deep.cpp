@@ -341,3 +341,89 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
     }
     return MS_OK;
 }
+
+// The DEEP composition polynomial evaluated where the committed LDEs already are: rows [first, first + count) of the bit-reversed LDE
+// domain (2^log_domain points, offset h).  Same terms and points as ms_deep_compose; the columns are the LDE columns' rows (a row
+// shard of a multi-GPU run, or the whole domain with first = 0).  The value at x is
+//      (alpha + beta x) sum_k 1/(x - z_k) sum_{t: pt = k} alpha_t (P_ct(x) - ood_t),
+// the polynomial ms_deep_compose returns in coefficient form, at that point: its LDE (src/prover.rs:149-152) without the transforms.
+extern "C" int ms_deep_rows(ms_ctx* ctx, int point_field, unsigned log_domain, const void* h_offset, size_t first, size_t count,
+                            const void* const* d_base_rows, unsigned nbase, const void* const* d_ext_rows, unsigned next,
+                            const void* h_points, unsigned npoints, const unsigned* h_term_col, const unsigned* h_term_point,
+                            const void* h_term_alpha, const void* h_term_ood, unsigned nterms,
+                            const void* h_degree_alpha, const void* h_degree_beta, void* d_out) {
+    if (!ctx || !h_points || !h_term_col || !h_term_point || !h_term_alpha || !h_term_ood || !h_degree_alpha || !h_degree_beta || !d_out)
+        return fail(MS_ERR_INVALID, "ms_deep_rows: null argument");
+    if (point_field == MS_STARK252_FP) return fail(MS_ERR_UNSUPPORTED, "ms_deep_rows: Goldilocks fields only (the 252-bit composer goes through ms_deep_compose)");
+    unsigned PW = 0;
+    MSCHK(point_words(point_field, &PW));
+    if (PW == 1 && next) return fail(MS_ERR_INVALID, "extension columns need point_field = Fq3");
+    if (nbase > (unsigned)msdeep::MAXCOLS || next > (unsigned)msdeep::MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d columns of each kind", msdeep::MAXCOLS);
+    if (npoints == 0 || npoints > (unsigned)msdeep::MAXPOINTS) return fail(MS_ERR_UNSUPPORTED, "1..%d distinct out-of-domain points", msdeep::MAXPOINTS);
+    if ((nbase && !d_base_rows) || (next && !d_ext_rows)) return fail(MS_ERR_INVALID, "ms_deep_rows: null column table");
+    if (log_domain == 0 || log_domain > 32) return fail(MS_ERR_INVALID, "ms_deep_rows: domain of 2^%u points", log_domain);
+    const size_t N = (size_t)1 << log_domain;
+    if (first > N || count > N - first) return fail(MS_ERR_INVALID, "ms_deep_rows: rows [%zu, %zu) outside the domain", first, first + count);
+    for (unsigned t = 0; t < nterms; t++)
+        if (h_term_col[t] >= nbase + next || h_term_point[t] >= npoints) return fail(MS_ERR_INVALID, "term %u out of range", t);
+    uint64_t h = gl::GENERATOR;
+    if (h_offset) { uint64_t h_m; memcpy(&h_m, h_offset, 8); h = gl::from_mont(h_m); }
+    if (h == 0) return fail(MS_ERR_INVALID, "coset offset must be non-zero");
+    for (unsigned k = 0; k < npoints; k++) {           // a point ON the LDE coset has no quotient there (cf. ms_deep_compose)
+        const uint64_t* zk = (const uint64_t*)h_points + (size_t)k * PW;
+        if (PW == 3 && (zk[1] != 0 || zk[2] != 0)) continue;
+        const uint64_t z = gl::from_mont(zk[0]);
+        if (z != 0 && gl::pow(gl::mul(z, gl::inv(h)), N) == 1)
+            return fail(MS_ERR_INVALID, "ms_deep_rows: out-of-domain point %u lies on the LDE coset h<w_N> (x - z vanishes there)", k);
+    }
+    if (count == 0) return MS_OK;
+    std::vector<msdeep::Term> terms;
+    terms.reserve(nterms);
+    unsigned term_start[msdeep::MAXPOINTS + 1];
+    for (unsigned k = 0; k < npoints; k++) {
+        term_start[k] = (unsigned)terms.size();
+        for (unsigned t = 0; t < nterms; t++) {
+            if (h_term_point[t] != k) continue;
+            msdeep::Term T;
+            memset(&T, 0, sizeof T);
+            T.col = h_term_col[t]; T.point = k;
+            memcpy(T.alpha, (const uint64_t*)h_term_alpha + (size_t)t * PW, PW * 8);
+            memcpy(T.ood, (const uint64_t*)h_term_ood + (size_t)t * PW, PW * 8);
+            terms.push_back(T);
+        }
+    }
+    for (unsigned k = npoints; k <= (unsigned)msdeep::MAXPOINTS; k++) term_start[k] = (unsigned)terms.size();
+    void* d_terms = nullptr;
+    PoolGuard pooled(ctx);
+    MSCHK(pooled.alloc(std::max<size_t>(1, nterms) * sizeof(msdeep::Term), &d_terms));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (nterms) MSCHK(stage_upload(ctx, d_terms, terms.data(), nterms * sizeof(msdeep::Term)));
+    ms_ntt_plan* tw = nullptr;
+    const unsigned tl = std::max(log_domain, 12u);
+    MSCHK(ctx_plan(ctx, 1, tl, false, 1, &tw));
+    msdeep::DeepParams D;
+    memset(&D, 0, sizeof D);
+    for (unsigned c = 0; c < nbase; c++) D.base[c] = (const uint64_t*)d_base_rows[c];
+    for (unsigned c = 0; c < next; c++) D.ext[c] = (const uint64_t*)d_ext_rows[c];
+    D.terms = (const msdeep::Term*)d_terms; D.tw_lo = tw->d_tw_lo; D.tw_hi = tw->d_tw_hi; D.lo_bits = tw->lo_bits; D.xshift = tl - log_domain;
+    for (unsigned k = 0; k < npoints; k++) memcpy(D.points[k], (const uint64_t*)h_points + (size_t)k * PW, PW * 8);
+    D.out = (uint64_t*)d_out; D.h_mont = gl::to_mont(h); D.n = count; D.nbase = nbase; D.nterms = nterms; D.npoints = npoints;
+    memcpy(D.term_start, term_start, sizeof term_start);
+    D.first = first; D.log_dom = log_domain; D.adjust = 1;
+    memcpy(D.adj_alpha, h_degree_alpha, PW * 8);
+    memcpy(D.adj_beta, h_degree_beta, PW * 8);
+    {
+        ProfScope ps(ctx, "deep_rows", 8.0 * count * (nbase + 3.0 * next + PW));
+        auto blocks = [&](unsigned pts) { return dim3((unsigned)((count + (size_t)msdeep::NT * pts - 1) / ((size_t)msdeep::NT * pts))); };
+        if (PW == 1) {
+            if (npoints <= 3 && count >= 4096) hipLaunchKernelGGL((msdeep::deep_points<1, 4, 3>), blocks(4), dim3(msdeep::NT), 0, ctx->stream, D);
+            else hipLaunchKernelGGL((msdeep::deep_points<1, 1, msdeep::MAXPOINTS>), blocks(1), dim3(msdeep::NT), 0, ctx->stream, D);
+        } else {
+            if (npoints <= 4 && count >= 4096) hipLaunchKernelGGL((msdeep::deep_points<3, 2, 4>), blocks(2), dim3(msdeep::NT), 0, ctx->stream, D);
+            else hipLaunchKernelGGL((msdeep::deep_points<3, 1, msdeep::MAXPOINTS>), blocks(1), dim3(msdeep::NT), 0, ctx->stream, D);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}

@@ -190,8 +190,21 @@ static void launch_fold(unsigned ff, dim3 g, hipStream_t st, const msfri::FoldPa
     default: hipLaunchKernelGGL((msfri::fri_fold<16, V>), g, dim3(msfri::NT), 0, st, P); break;
     }
 }
+static int fri_fold_impl(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
+                         const void* h_offset, size_t first_chunk, size_t nchunks, bool whole, const void* d_evals, void* d_out);
 extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
                            const void* h_offset, const void* d_evals, void* d_out) {
+    return fri_fold_impl(ctx, field, log_n, folding_factor, h_alpha, h_offset, 0, 0, true, d_evals, d_out);
+}
+// A row shard of a layer: chunks [first_chunk, first_chunk + nchunks) of the bit-reversed layer of 2^log_n evaluations (d_evals holds
+// those nchunks * folding_factor evaluations, d_out receives nchunks).  The fold of a chunk needs nothing but the chunk and its
+// position, so a rank that holds rows [r n / G, (r + 1) n / G) of a layer produces its rows of the next one without communication.
+extern "C" int ms_fri_fold_rows(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
+                                const void* h_offset, size_t first_chunk, size_t nchunks, const void* d_evals, void* d_out) {
+    return fri_fold_impl(ctx, field, log_n, folding_factor, h_alpha, h_offset, first_chunk, nchunks, false, d_evals, d_out);
+}
+static int fri_fold_impl(ms_ctx* ctx, int field, unsigned log_n, unsigned folding_factor, const void* h_alpha,
+                         const void* h_offset, size_t first_chunk, size_t nchunks, bool whole, const void* d_evals, void* d_out) {
     if (!ctx || !h_alpha || !d_evals || !d_out) return fail(MS_ERR_INVALID, "ms_fri_fold: null argument");
     unsigned V = 0;
     MSCHK(field_words(field, &V));
@@ -200,8 +213,13 @@ extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned fold
     unsigned log_ff = 0;
     while ((1u << log_ff) < folding_factor) log_ff++;
     if (log_n < log_ff || log_n > 32) return fail(MS_ERR_INVALID, "bad layer size 2^%u for folding factor %u", log_n, folding_factor);
+    const size_t all_chunks = (size_t)1 << (log_n - log_ff);
+    if (whole) { first_chunk = 0; nchunks = all_chunks; }
+    else if (V == 4) return fail(MS_ERR_UNSUPPORTED, "ms_fri_fold_rows: Goldilocks fields");
+    if (first_chunk > all_chunks || nchunks > all_chunks - first_chunk) return fail(MS_ERR_INVALID, "ms_fri_fold_rows: chunks [%zu, %zu) outside the layer", first_chunk, first_chunk + nchunks);
+    if (nchunks == 0) return MS_OK;
     {   // lane c reads d_evals[c*ff .. c*ff + ff) and writes d_out[c]: overlapping buffers would corrupt the next layer
-        const size_t in_bytes = ((size_t)1 << log_n) * V * 8, out_bytes = in_bytes / folding_factor;
+        const size_t in_bytes = nchunks * folding_factor * V * 8, out_bytes = in_bytes / folding_factor;
         const char *a = (const char*)d_evals, *b = (const char*)d_out;
         if (a < b + out_bytes && b < a + in_bytes) return fail(MS_ERR_INVALID, "ms_fri_fold: d_out overlaps d_evals (the fold is not an in-place operation)");
     }
@@ -254,9 +272,10 @@ extern "C" int ms_fri_fold(ms_ctx* ctx, int field, unsigned log_n, unsigned fold
     memcpy(P.alpha, h_alpha, V * 8);
     // table exponent scale: w_n = w_(2^tl)^(2^(tl-log_n)); fold it into the index below
     P.log_m |= (tl - log_n) << 8;
-    const size_t m = (size_t)1 << (log_n - log_ff);
+    P.c0 = first_chunk; P.count = nchunks;
+    const size_t m = nchunks;
     dim3 g((unsigned)((m + msfri::NT - 1) / msfri::NT));
-    ProfScope ps(ctx, "fri_fold", 8.0 * V * (((size_t)1 << log_n) + m));
+    ProfScope ps(ctx, "fri_fold", 8.0 * V * (m * folding_factor + m));
     if (V == 1) launch_fold<1>(folding_factor, g, ctx->stream, P); else launch_fold<3>(folding_factor, g, ctx->stream, P);
     HIPCHK(hipGetLastError());
     return MS_OK;

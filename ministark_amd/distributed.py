@@ -28,7 +28,7 @@ import ctypes
 
 import numpy as np
 
-from .api import FIELD_WORDS, GOLDILOCKS_FP, GL_GENERATOR, DeviceBytes, GpuVec, Matrix, MerkleTree, _ptr_array
+from .api import FIELD_WORDS, GOLDILOCKS_FP, GL_GENERATOR, DeviceBytes, GpuVec, Matrix, MerkleTree, _ptr_array, merkle_view_ids
 
 COMM_ID_BYTES = 128
 
@@ -220,3 +220,337 @@ def eval_constraints_sharded(prog, planner, comm, challenges, hints, lde_step, d
     wq = FIELD_WORDS[res.field] * 8
     L.check(L.ms_copy(planner.handle, mine.ptr, res.ptr + r * rows * wq, rows * wq))
     return mine, r * rows, rows
+
+
+# =====================================================================================================================
+# The whole prover on row shards (BASELINE configs[4]: "full prover.rs ... columns sharded across 8 x MI355X")
+# =====================================================================================================================
+# After the base-trace commitment every later phase of default_prove (src/prover.rs:57-174) works on ROWS of the committed
+# LDEs, so the column -> row exchange of the commitment is the only bulk movement of the trace:
+#
+#   phase (prover.rs)                    placement                                               moved per rank (C5, G = 8)
+#   1 interpolate + LDE  (:50-51)        column shards (rank c mod G), no communication          --
+#     commit             (:52-55)        cols_to_rows, hash own rows, subtree, 32-byte all-gather 7/8 of its LDE columns (112 MiB)
+#   2 constraint evaluation (:97-107)    row shards (eval_constraints_sharded)                   0, or the CE coset's shards
+#   3 composition trace (:111-124)       evaluations -> rank 0: iNTT + split; column c -> rank c mod G: LDE;   <= 32 MiB + 112 MiB
+#                                        cols_to_rows, subtree, all-gather
+#   4 out-of-domain evaluations (:137-146)  each polynomial by its owner (Horner), values gathered   a few hundred bytes
+#   5 DEEP composition + its LDE (:149-152) ms_deep_rows on the rank's rows of both committed LDEs  0
+#   6 FRI layers (fri.rs:179-231)        every layer stays sharded by rows: subtree + all-gather per commitment, fold in place   32 B per layer
+#                                        (ms_fri_fold_rows); a layer with fewer than two leaves per rank is collected on rank 0
+#   7 remainder, grinding, openings      rank 0; rows and digests of the openings come from their owners   kilobytes
+#
+# Every value is the one the single-device prover computes (tests/test_distributed.py compares roots, remainder, nonce and every
+# opening at 2, 4 and 8 ranks): sharding changes where a row is hashed, folded or composed, not what is computed.
+
+def _sharded_root(planner, comm, tree, hash):
+    """(root of the whole tree, the top-levels tree over the G subtree roots or None at G = 1)"""
+    if comm.world == 1:
+        return tree.root(), None
+    top = MerkleTree(planner, comm.allgather_digests(tree.nodes.ptr + 32), comm.world, hash)
+    return top.root(), top
+
+
+def _collect(planner, comm, buf, nbytes_of, root=0):
+    """Device buffers of nbytes_of[rank] bytes on every rank -> on `root` one DeviceBytes holding them in rank order (None elsewhere)."""
+    r, G = comm.rank, comm.world
+    offs = np.concatenate([[0], np.cumsum(nbytes_of)]).astype(np.int64)
+    out, ops = None, []
+    if r == root:
+        out = DeviceBytes(planner, max(8, int(offs[-1])))
+        if nbytes_of[r]:
+            planner.lib.check(planner.lib.ms_copy(planner.handle, out.ptr + int(offs[r]), buf.ptr, int(nbytes_of[r])))
+        ops = [(XCHG_RECV, peer, out.ptr + int(offs[peer]), int(nbytes_of[peer])) for peer in range(G) if peer != root and nbytes_of[peer]]
+    elif nbytes_of[r]:
+        ops = [(XCHG_SEND, root, buf.ptr, int(nbytes_of[r]))]
+    comm.p2p(ops)
+    return out
+
+
+def _allgather_words(planner, comm, words):
+    """numpy u64 array (same length on every rank) -> [G, len] array on every rank (small host data through the device exchange)."""
+    r, G = comm.rank, comm.world
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    if G == 1:
+        return words.reshape(1, -1).copy()
+    nb = words.size * 8
+    buf = DeviceBytes(planner, max(8, nb * G))
+    L = planner.lib
+    if nb:
+        L.check(L.ms_upload(planner.handle, buf.ptr + r * nb, words.ctypes.data, nb))
+        ops = []
+        for peer in range(G):
+            if peer != r:
+                ops += [(XCHG_SEND, peer, buf.ptr + r * nb, nb), (XCHG_RECV, peer, buf.ptr + peer * nb, nb)]
+        comm.p2p(ops)
+    return buf.to_numpy()[: nb * G].view(np.uint64).reshape(G, -1).copy()
+
+
+class ShardedTree:
+    """A Merkle tree whose leaves are spread over the ranks in row blocks: rank r holds the subtree over leaves [r n / G, (r + 1) n / G)
+    (node G + r of the whole tree) and every rank the top levels (nodes 1 .. G - 1)."""
+
+    def __init__(self, planner, comm, local_tree, hash="sha256"):
+        self.planner, self.comm, self.local, self.hash = planner, comm, local_tree, hash
+        self.nleaves = local_tree.nleaves * comm.world
+        self._root, self.top = _sharded_root(planner, comm, local_tree, hash)
+
+    def root(self):
+        return self._root
+
+    def prove(self, indices, root=0):
+        """`MerkleTreeImpl::prove` (src/merkle.rs:149-206) -> the MerkleView of the whole tree on `root` (None elsewhere): every digest
+        is fetched by the rank that holds it and collected."""
+        pl, comm, G, r = self.planner, self.comm, self.comm.world, self.comm.rank
+        n, per = self.nleaves, self.local.nleaves
+        leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices)
+        # where each digest lives: (owner, "leaf" | "node" | "top", local id)
+        where = [(i // per, "leaf", i % per) for i in leaf_ids]
+        for k in node_ids:
+            lvl = 1 << (k.bit_length() - 1)
+            if lvl < G:
+                where.append((root, "top", k))
+            else:
+                j, per_lvl = k - lvl, lvl // G
+                where.append((j // per_lvl, "node", per_lvl + j % per_lvl))
+        mine = [(kind, i) for owner, kind, i in where if owner == r]
+        parts = []
+        for kind, src, count in (("leaf", self.local.leaves, per), ("node", self.local.nodes, per), ("top", self.top.nodes if self.top else None, G)):
+            ids = [i for k, i in mine if k == kind]
+            if ids:
+                idx = np.asarray(ids, dtype=np.uint64)
+                out = DeviceBytes(pl, 32 * len(ids))
+                pl.lib.check(pl.lib.ms_gather_digests(pl.handle, count, src.ptr, idx.ctypes.data, len(ids), out.ptr))
+                parts.append((kind, out, len(ids)))
+        buf = DeviceBytes(pl, max(8, 32 * len(mine)))
+        off = 0
+        for kind, out, cnt in parts:                          # rank-local layout: leaves, then nodes, then top digests
+            pl.lib.check(pl.lib.ms_copy(pl.handle, buf.ptr + off, out.ptr, 32 * cnt))
+            off += 32 * cnt
+        nbytes = [32 * sum(1 for owner, _, _ in where if owner == q) for q in range(G)]
+        got = _collect(pl, comm, buf, nbytes, root)
+        if r != root:
+            return None
+        raw = got.to_numpy().tobytes()
+        offs = np.concatenate([[0], np.cumsum(nbytes)]).astype(np.int64)
+        # per owner the digests arrive grouped by kind (leaf, node, top), each group in id order
+        cursor = {}
+        for q in range(G):
+            base = int(offs[q])
+            for kind in ("leaf", "node", "top"):
+                cursor[(q, kind)] = base
+                base += 32 * sum(1 for owner, k, _ in where if owner == q and k == kind)
+        digests = []
+        for owner, kind, _ in where:
+            o = cursor[(owner, kind)]
+            digests.append(raw[o:o + 32])
+            cursor[(owner, kind)] = o + 32
+        leaves, nodes = digests[: len(leaf_ids)], digests[len(leaf_ids):]
+        return {"nodes": nodes, "initial_leaves": [leaves[k] for k in initial], "sibling_leaves": [leaves[k] for k in sibling],
+                "height": n.bit_length() - 1}
+
+
+def _sharded_rows(planner, comm, columns, field, positions, per, root=0):
+    """Rows `positions` (global row numbers, any order) of a matrix whose rows are spread over the ranks in blocks of `per`:
+    -> numpy [len(positions), words] on `root` in the order given (None elsewhere)."""
+    r, G = comm.rank, comm.world
+    positions = [int(p) for p in positions]
+    words = len(columns) * FIELD_WORDS[field]
+    mine = [p - r * per for p in positions if p // per == r]
+    buf = DeviceBytes(planner, max(8, len(mine) * words * 8))
+    if mine:
+        pos = np.asarray(mine, dtype=np.uint64)
+        planner.lib.check(planner.lib.ms_gather_rows(planner.handle, field, per, _ptr_array(columns), len(columns), pos.ctypes.data, len(pos), buf.ptr))
+    nbytes = [sum(1 for p in positions if p // per == q) * words * 8 for q in range(G)]
+    got = _collect(planner, comm, buf, nbytes, root)
+    if r != root:
+        return None
+    flat = got.to_numpy()[: len(positions) * words * 8].view(np.uint64).reshape(-1, words) if positions else np.zeros((0, words), dtype=np.uint64)
+    nxt = {q: int(sum(nbytes[:q]) // (words * 8)) for q in range(G)}
+    out = np.zeros((len(positions), words), dtype=np.uint64)
+    for k, p in enumerate(positions):
+        q = p // per
+        out[k] = flat[nxt[q]]
+        nxt[q] += 1
+    return out
+
+
+def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, draws, blowup=4, folding=8, max_remainder_coeffs=64,
+                  grinding_bits=8, hash="sha256", ce_blowup=None):
+    """`pipeline.prove_phases` with the trace's columns spread over the ranks (local_cols: this rank's columns, owned_columns order;
+    Fq = Fp AIRs over Goldilocks).  Returns on every rank dict(base_root, composition_root, fri_roots) and on rank 0 also ood,
+    remainder_coeffs, nonce, queries (the six members of api.Queries as a dict) and fri_openings -- the values of the single-device
+    prover.  See the placement table above."""
+    from . import expr as E
+    from .api import Radix2EvaluationDomain, apply_drp, gl_to_mont, grind_proof_of_work, _offset_words
+    from .composer import DeepPolyComposer
+    from .pipeline import _lowered, fold_positions
+    pl, L, G, r = planner, planner.lib, comm.world, comm.rank
+    n_t = 1 << log_rows
+    N = n_t * blowup
+    ce_blowup = blowup if ce_blowup is None else ce_blowup
+    n_ce = n_t * ce_blowup
+    if N % G or N // G < 2 * folding:
+        raise ValueError("LDE domain too small for this many ranks")
+    rows = N // G
+    mine = owned_columns(total_cols, r, G)
+    if len(local_cols) != len(mine):
+        raise ValueError(f"rank {r} of {G} owns {len(mine)} of {total_cols} columns, {len(local_cols)} given")
+    trace_dom, lde_dom, ce_dom = Radix2EvaluationDomain(n_t), Radix2EvaluationDomain(N, 7), Radix2EvaluationDomain(n_ce, 7)
+    prog = _lowered(comp_expr, total_cols)
+    ch = np.array([gl_to_mont(c) for c in draws.challenges], dtype=np.uint64).reshape(-1, 1)
+    hints = np.array([gl_to_mont(c) for c in draws.hints], dtype=np.uint64).reshape(-1, 1)
+    out = {}
+
+    # 1. base trace: column shards -> LDE -> row shards -> commitment
+    vecs = [c if isinstance(c, GpuVec) else GpuVec.from_numpy(pl, np.asarray(c, dtype=np.uint64)) for c in local_cols]
+    base_polys = Matrix(vecs).interpolate(trace_dom) if vecs else None
+    lde_local = base_polys.bit_reversed_evaluate(lde_dom).columns if vecs else []
+    base_shard = comm.cols_to_rows(lde_local, total_cols, N)
+    del lde_local
+    tree_b = ShardedTree(pl, comm, MerkleTree.from_matrix(Matrix(base_shard), hash), hash)
+    out["base_root"] = tree_b.root()
+
+    # 2. constraint evaluation on the row shards
+    got = eval_constraints_sharded(prog, pl, comm, ch, hints, ce_blowup, 7, n_ce, base_shard, n_lde=N)
+
+    # 3. composition trace: evaluations -> rank 0 (iNTT, split) -> column owners (LDE) -> row shards -> commitment
+    holders = 1 if n_ce <= rows else n_ce // rows
+    nb = [(min(rows, n_ce) * 8 if q < holders else 0) for q in range(G)]
+    evals_all = _collect(pl, comm, got[0] if got is not None else None, nb, 0)
+    comp_cols_local = []
+    comp_owned = owned_columns(ce_blowup, r, G)
+    if r == 0:
+        ev = GpuVec(pl, n_ce)
+        L.check(L.ms_copy(pl.handle, ev.ptr, evals_all.ptr, n_ce * 8))
+        comp_poly = Matrix([ev]).bit_reverse_rows().into_polynomials(ce_dom).columns[0]
+        comp_all = Matrix.from_chunks(comp_poly, ce_blowup).columns
+        ops = [(XCHG_SEND, c % G, comp_all[c].ptr, n_t * 8) for c in range(ce_blowup) if c % G != 0]
+        comm.p2p(ops)
+        comp_cols_local = [comp_all[c] for c in comp_owned]
+    else:
+        comp_cols_local = [GpuVec(pl, n_t) for _ in comp_owned]
+        comm.p2p([(XCHG_RECV, 0, v.ptr, n_t * 8) for v in comp_cols_local])
+    comp_polys = Matrix(comp_cols_local) if comp_cols_local else None
+    comp_lde_local = comp_polys.bit_reversed_evaluate(lde_dom).columns if comp_polys is not None else []
+    comp_shard = comm.cols_to_rows(comp_lde_local, ce_blowup, N)
+    del comp_lde_local
+    tree_c = ShardedTree(pl, comm, MerkleTree.from_matrix(Matrix(comp_shard), hash), hash)
+    out["composition_root"] = tree_c.root()
+
+    # 4. out-of-domain evaluations: every polynomial by its owner, the values to everybody
+    args = list(draws.trace_args)
+    helper = DeepPolyComposer.for_row_shards(args, n_t, draws.z, pl, total_cols, 0, ce_blowup, None)
+    vals = np.zeros(len(args) + ce_blowup, dtype=np.uint64)
+    if base_polys is not None:
+        q = [(k, mine.index(c), helper._point(o)) for k, (c, o) in enumerate(args) if c in mine]
+        for (k, _, _), v in zip(q, helper._horner(base_polys, GOLDILOCKS_FP, [(lc, p) for _, lc, p in q])):
+            vals[k] = v
+    if comp_polys is not None:
+        z_n = pow(draws.z, ce_blowup, (1 << 64) - (1 << 32) + 1)
+        for lc, v in enumerate(helper._horner(comp_polys, GOLDILOCKS_FP, [(lc, z_n) for lc in range(len(comp_owned))])):
+            vals[len(args) + comp_owned[lc]] = v
+    allv = _allgather_words(pl, comm, vals)
+    execution = [int(allv[c % G][k]) for k, (c, _) in enumerate(args)]
+    composition = [int(allv[c % G][len(args) + c]) for c in range(ce_blowup)]
+    out["ood"] = (execution, composition)
+
+    # 5. the DEEP composition polynomial's LDE = the first FRI layer, on this rank's rows of both committed LDEs
+    composer = DeepPolyComposer.for_row_shards(args, n_t, draws.z, pl, total_cols, 0, ce_blowup, (execution, composition))
+    cur = composer.into_deep_evaluations(draws.deep, Matrix(base_shard), None, Matrix(comp_shard), N, first=r * rows)
+
+    # 6. FRI: every layer sharded by rows while a rank holds at least two leaves of it
+    n, sharded = N, True
+    roots, layers = [], []                                       # layers: (evaluations, tree, sharded?, size)
+    for alpha in draws.fri_alphas:
+        if sharded and (n // G) // folding < 2:
+            whole = _collect(pl, comm, cur, [n // G * 8] * G, 0)
+            sharded = False
+            cur = None
+            if r == 0:
+                cur = GpuVec(pl, n)
+                L.check(L.ms_copy(pl.handle, cur.ptr, whole.ptr, n * 8))
+        al = np.array([gl_to_mont(alpha)], dtype=np.uint64)
+        if sharded:
+            tree = ShardedTree(pl, comm, MerkleTree.from_fri_layer(cur, folding, hash), hash)
+            roots.append(tree.root())
+            layers.append((cur, tree, True, n))
+            nch = n // G // folding
+            nxt = GpuVec(pl, nch)
+            L.check(L.ms_fri_fold_rows(pl.handle, GOLDILOCKS_FP, n.bit_length() - 1, folding, al.ctypes.data, _offset_words(GOLDILOCKS_FP, 1).ctypes.data,
+                                       r * nch, nch, cur.ptr, nxt.ptr))
+            cur = nxt
+        elif r == 0:
+            tree = MerkleTree.from_fri_layer(cur, folding, hash)
+            roots.append(tree.root())
+            layers.append((cur, tree, False, n))
+            cur = apply_drp(cur, al, folding, 1)
+        n //= folding
+    if sharded:
+        whole = _collect(pl, comm, cur, [n // G * 8] * G, 0)
+        cur = None
+        if r == 0:
+            cur = GpuVec(pl, n)
+            L.check(L.ms_copy(pl.handle, cur.ptr, whole.ptr, n * 8))
+    # the roots of layers committed after the switch to rank 0 reach the other ranks as 32-byte words
+    have = np.zeros(4 * len(draws.fri_alphas), dtype=np.uint64)
+    if r == 0:
+        for k, rt in enumerate(roots):
+            have[4 * k:4 * k + 4] = np.frombuffer(rt, dtype=np.uint64)
+    allr = _allgather_words(pl, comm, have)[0]
+    out["fri_roots"] = [allr[4 * k:4 * k + 4].tobytes() for k in range(len(draws.fri_alphas))]
+    # 7. remainder, grinding (rank 0), openings (collective)
+    if r == 0:
+        rem = Matrix([cur.clone()]).bit_reverse_rows().into_polynomials(Radix2EvaluationDomain(n)).columns[0]
+        out["remainder_coeffs"] = rem.to_numpy()[: max(n // blowup, 1)]
+        out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)
+    positions = [int(p) for p in draws.positions]
+    q = {"base_trace_proof": tree_b.prove(positions), "extension_trace_proof": None, "composition_trace_proof": tree_c.prove(positions),
+         "base_trace_values": _sharded_rows(pl, comm, base_shard, GOLDILOCKS_FP, positions, rows), "extension_trace_values": None,
+         "composition_trace_values": _sharded_rows(pl, comm, comp_shard, GOLDILOCKS_FP, positions, rows)}
+    pos, openings = sorted(set(positions)), []
+    for k in range(len(draws.fri_alphas)):
+        pos = fold_positions(pos, folding)
+        entry = None
+        if k < len(layers) and layers[k][2]:                     # a sharded layer: rows of `folding` evaluations, owners by row block
+            lay, tree, _, size = layers[k]
+            per = size // G // folding
+            rows_k = _fri_rows_sharded(pl, comm, lay, folding, pos, per)
+            proof = tree.prove(pos)
+            entry = {"positions": pos, "rows": rows_k, "proof": proof}
+        elif r == 0:
+            from .pipeline import fri_layer_rows
+            lay, tree, _, size = layers[k]
+            entry = {"positions": pos, "rows": fri_layer_rows(lay, folding, pos), "proof": tree.prove(pos)}
+        openings.append(entry)
+    if r == 0:
+        out["queries"], out["fri_openings"] = q, openings
+    return out
+
+
+def _fri_rows_sharded(planner, comm, layer_shard, folding, positions, per, root=0):
+    """rows `positions` of Matrix::from_arrays(evaluations.as_chunks::<N>()) (src/fri.rs:213-215) of a row-sharded layer: `per` rows of
+    `folding` evaluations on each rank -> numpy [len(positions), folding] on root.  A row is `folding` consecutive words = folding / 4
+    32-byte records of the shard, fetched with the digest gather (as pipeline.fri_layer_rows_launch does on one device)."""
+    r, G = comm.rank, comm.world
+    rec = folding // 4
+    mine = [p - r * per for p in positions if p // per == r]
+    buf = DeviceBytes(planner, max(8, len(mine) * folding * 8))
+    if mine and folding % 4:                                  # rows shorter than a 32-byte record (folding factor 2): picked on the host
+        picked = np.ascontiguousarray(layer_shard.to_numpy().reshape(-1, folding)[mine])
+        planner.lib.check(planner.lib.ms_upload(planner.handle, buf.ptr, picked.ctypes.data, picked.nbytes))
+    elif mine:
+        ids = np.asarray([p * rec + k for p in mine for k in range(rec)], dtype=np.uint64)
+        planner.lib.check(planner.lib.ms_gather_digests(planner.handle, per * rec, layer_shard.ptr, ids.ctypes.data, len(ids), buf.ptr))
+    nbytes = [sum(1 for p in positions if p // per == q) * folding * 8 for q in range(G)]
+    got = _collect(planner, comm, buf, nbytes, root)
+    if r != root:
+        return None
+    flat = got.to_numpy()[: len(positions) * folding * 8].view(np.uint64).reshape(-1, folding)
+    nxt = {q: int(sum(nbytes[:q]) // (folding * 8)) for q in range(G)}
+    out = np.zeros((len(positions), folding), dtype=np.uint64)
+    for k, p in enumerate(positions):
+        q = p // per
+        out[k] = flat[nxt[q]]
+        nxt[q] += 1
+    return out

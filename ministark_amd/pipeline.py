@@ -258,8 +258,12 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
     lap("composition trace: iNTT + split + LDE + commit")
     composer = DeepPolyComposer(draws.trace_args, n_t, draws.z, base_polys, None, comp_polys)          # prover.rs:137-144
     out["ood"] = composer.get_ood_evals()                                      # prover.rs:145-146
-    deep_poly = composer.into_deep_poly(draws.deep)                            # prover.rs:149
-    deep = Matrix([deep_poly.clone() if keep else deep_poly]).into_bit_reversed_evaluations(lde_dom)   # prover.rs:150-152
+    # prover.rs:149-152: deep_composition_poly = composer.into_deep_poly(coeffs); its bit-reversed evaluations over the LDE domain are
+    # the first FRI layer.  Both committed LDEs are still resident (the queries need them), so those evaluations are computed where the
+    # LDEs lie -- the quotient is a polynomial: same values -- instead of 9 coset transforms, the composition, an inverse transform and
+    # an LDE (ms_deep_rows; tests/test_deep_parity.py checks it against the two-step form).  keep=True also forms the coefficients.
+    deep_poly = composer.into_deep_poly(draws.deep) if keep else None
+    deep = Matrix([composer.into_deep_evaluations(draws.deep, lde_t, None, comp_lde, n_lde)])
     lap("DEEP: OOD evaluations + composition + LDE")
     cur, n, roots, layers, fri_layers, fri_trees = deep.columns[0], n_lde, [], [], [], []     # fri.rs:179-231
     for alpha in draws.fri_alphas:

@@ -187,3 +187,34 @@ def test_horner_three_levels_sparse(kind):
     for off, g in zip((0, 1), got):
         x = pydeep.point_for(z, d.group_gen, d.group_gen_inv, off)
         assert g == sum(v * pow(x, i, P) for i, v in zip(pos, vals)) % P
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("ext", [False, True])
+def test_deep_evaluations_on_the_committed_ldes(kind, ext):
+    """ms_deep_rows: the DEEP composition polynomial's bit-reversed LDE computed pointwise from the rows of the committed LDEs equals
+    into_deep_poly + into_bit_reversed_evaluations (src/prover.rs:149-152) -- on the whole domain and on a row shard of it."""
+    from ministark_amd import Matrix
+    pl = backends.planner(kind)
+    for n, blow in ((64, 4), (4096, 2)) if kind == "emu" else ((1 << 12, 8), (1 << 16, 4)):
+        rng = np.random.default_rng(7 + ext)
+        nbase, next_, ncomp = 2, (1 if ext else 0), 2
+        base = [[int(x) for x in rng.integers(0, P, size=n, dtype=np.uint64)] for _ in range(nbase)]
+        extp = [[_rq(rng, True) for _ in range(n)] for _ in range(next_)]
+        comp = [[_rq(rng, ext) for _ in range(n)] for _ in range(ncomp)]
+        args = [(0, 0), (0, 1), (1, 0), (1, -1)] + ([(2, 0), (2, 1)] if ext else [])
+        z = _rq(rng, ext)
+        bm, em, cm = _mat(pl, base, FP), (_mat(pl, extp, FQ3) if ext else None), _mat(pl, comp, FQ3 if ext else FP)
+        composer = DeepPolyComposer(args, n, z, bm, em, cm)
+        composer.get_ood_evals()
+        co = DeepCompositionCoeffs([_rq(rng, ext) for _ in args], [_rq(rng, ext) for _ in range(ncomp)], (_rq(rng, ext), _rq(rng, ext)))
+        N = n * blow
+        dom = Radix2EvaluationDomain(N, 7)
+        want = Matrix([composer.into_deep_poly(co)]).into_bit_reversed_evaluations(dom).columns[0].to_numpy()
+        bl, cl = bm.bit_reversed_evaluate(dom), cm.bit_reversed_evaluate(dom)
+        el = em.bit_reversed_evaluate(dom) if ext else None
+        assert np.array_equal(composer.into_deep_evaluations(co, bl, el, cl, N).to_numpy(), want)
+        f, c, V = 3 * N // 8, N // 8, (3 if ext else 1)                                   # rank 3 of 8
+        sl = lambda m, words: Matrix.from_numpy(pl, [col[f * words:(f + c) * words] for col in m.to_numpy()], m.field)
+        got = composer.into_deep_evaluations(co, sl(bl, 1), sl(el, 3) if ext else None, sl(cl, V), N, first=f).to_numpy()
+        assert np.array_equal(got, want[f * V:(f + c) * V])

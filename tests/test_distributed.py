@@ -61,6 +61,43 @@ def test_product_exchange_entry_points_with_more_than_one_rank(tmp_path, world):
         assert open(f).read().split("\n") == want
 
 
+def _run_prove_workers(tmp_path, world, kind, env):
+    port = str(30700 + (os.getpid() % 400) + world + (50 if kind == "emu" else 0))
+    procs, files = [], []
+    for r in range(world):
+        f = str(tmp_path / f"p{r}.txt")
+        files.append(f)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_prove_worker.py"), str(r), str(world), port, kind, f],
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-3000:]
+    lines = [open(f).read().split("\n") for f in files]
+    assert all(len(l) == 3 for l in lines)
+    for l in lines:
+        assert l == lines[0]                                    # every rank ends with the same roots
+        assert all(":ok:" in entry for entry in l), l
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_whole_prover_on_row_shards_gloo(tmp_path, world):
+    """distributed.prove_sharded -- every phase of default_prove after the base commitment on row shards (composition-trace commitment,
+    out-of-domain evaluations by the owners, DEEP composition on the rows of both committed LDEs, every FRI layer folded and committed
+    where its rows are, openings served by the owners) -- against pipeline.prove_phases on one device: roots, OOD values, FRI roots,
+    remainder, nonce, every Merkle view and every opened row, for the fib AIR (ce_blowup 1 < blow-up 4: BASELINE configs[4]'s shape) and
+    an AIR with ce_blowup = blow-up, folding factors 8, 4 and 2."""
+    _run_prove_workers(tmp_path, world, "emu", dict(os.environ))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_whole_prover_on_row_shards_product_exchange(tmp_path, world):
+    """the same through the product's communicator entry points (ms_cols_to_rows_alltoall, ms_p2p_batch, ms_allgather_digests) over
+    tests/emu/fake_rccl.cpp"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    _run_prove_workers(tmp_path, world, "emu-rccl", dict(os.environ, MS_RCCL_LIB=build_emu.build_fake_rccl()))
+
+
 def _bench_env():
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
