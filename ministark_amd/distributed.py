@@ -376,11 +376,12 @@ def _sharded_rows(planner, comm, columns, field, positions, per, root=0):
 
 
 def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, draws, blowup=4, folding=8, max_remainder_coeffs=64,
-                  grinding_bits=8, hash="sha256", ce_blowup=None):
+                  grinding_bits=8, hash="sha256", ce_blowup=None, phases_ms=None):
     """`pipeline.prove_phases` with the trace's columns spread over the ranks (local_cols: this rank's columns, owned_columns order;
     Fq = Fp AIRs over Goldilocks).  Returns on every rank dict(base_root, composition_root, fri_roots) and on rank 0 also ood,
     remainder_coeffs, nonce, queries (the six members of api.Queries as a dict) and fri_openings -- the values of the single-device
-    prover.  See the placement table above."""
+    prover.  See the placement table above.  phases_ms: a dict that receives this rank's wall time per phase (a device sync each)."""
+    import time
     from . import expr as E
     from .api import Radix2EvaluationDomain, apply_drp, gl_to_mont, grind_proof_of_work, _offset_words
     from .composer import DeepPolyComposer
@@ -401,6 +402,14 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
     ch = np.array([gl_to_mont(c) for c in draws.challenges], dtype=np.uint64).reshape(-1, 1)
     hints = np.array([gl_to_mont(c) for c in draws.hints], dtype=np.uint64).reshape(-1, 1)
     out = {}
+    t_lap = [time.perf_counter()]
+
+    def lap(name):
+        if phases_ms is not None:
+            pl.sync()
+            now = time.perf_counter()
+            phases_ms[name] = phases_ms.get(name, 0.0) + (now - t_lap[0]) * 1e3
+            t_lap[0] = now
 
     # 1. base trace: column shards -> LDE -> row shards -> commitment
     vecs = [c if isinstance(c, GpuVec) else GpuVec.from_numpy(pl, np.asarray(c, dtype=np.uint64)) for c in local_cols]
@@ -410,9 +419,11 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
     del lde_local
     tree_b = ShardedTree(pl, comm, MerkleTree.from_matrix(Matrix(base_shard), hash), hash)
     out["base_root"] = tree_b.root()
+    lap("base trace: interpolate + LDE + exchange + commit")
 
     # 2. constraint evaluation on the row shards
     got = eval_constraints_sharded(prog, pl, comm, ch, hints, ce_blowup, 7, n_ce, base_shard, n_lde=N)
+    lap("constraint evaluation")
 
     # 3. composition trace: evaluations -> rank 0 (iNTT, split) -> column owners (LDE) -> row shards -> commitment
     holders = 1 if n_ce <= rows else n_ce // rows
@@ -437,6 +448,7 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
     del comp_lde_local
     tree_c = ShardedTree(pl, comm, MerkleTree.from_matrix(Matrix(comp_shard), hash), hash)
     out["composition_root"] = tree_c.root()
+    lap("composition trace: gather + iNTT + split + LDE + exchange + commit")
 
     # 4. out-of-domain evaluations: every polynomial by its owner, the values to everybody
     args = list(draws.trace_args)
@@ -458,6 +470,7 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
     # 5. the DEEP composition polynomial's LDE = the first FRI layer, on this rank's rows of both committed LDEs
     composer = DeepPolyComposer.for_row_shards(args, n_t, draws.z, pl, total_cols, 0, ce_blowup, (execution, composition))
     cur = composer.into_deep_evaluations(draws.deep, Matrix(base_shard), None, Matrix(comp_shard), N, first=r * rows)
+    lap("DEEP: OOD evaluations + composition on the LDE rows")
 
     # 6. FRI: every layer sharded by rows while a rank holds at least two leaves of it
     n, sharded = N, True
@@ -499,6 +512,7 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
             have[4 * k:4 * k + 4] = np.frombuffer(rt, dtype=np.uint64)
     allr = _allgather_words(pl, comm, have)[0]
     out["fri_roots"] = [allr[4 * k:4 * k + 4].tobytes() for k in range(len(draws.fri_alphas))]
+    lap("FRI layers (commit + fold)")
     # 7. remainder, grinding (rank 0), openings (collective)
     if r == 0:
         rem = Matrix([cur.clone()]).bit_reverse_rows().into_polynomials(Radix2EvaluationDomain(n)).columns[0]
@@ -525,6 +539,7 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
         openings.append(entry)
     if r == 0:
         out["queries"], out["fri_openings"] = q, openings
+    lap("remainder + proof of work + openings")
     return out
 
 

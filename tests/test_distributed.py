@@ -112,7 +112,7 @@ def test_bench_gpus_n_starts_its_own_ranks(world):
     import json
     env = _bench_env()
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "lde-commit", "--log-rows", "8", "--total-cols", "4", "--steps", "2"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "lde-commit", "--log-rows", "8", "--total-cols", "8", "--steps", "2"]
     lines = {}
     for n in (1, world):
         r = subprocess.run(cmd + ["--gpus", str(n)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -123,6 +123,8 @@ def test_bench_gpus_n_starts_its_own_ranks(world):
     assert lines[world]["n_gpus"] == world and lines[world]["sharded_lde_commit"]["n_gpus"] == world
     assert lines[1]["n_gpus"] == 1
     assert lines[world]["sharded_lde_commit"]["root"] == lines[1]["sharded_lde_commit"]["root"] is not None
+    pn, p1 = lines[world]["sharded_lde_commit"]["prove"], lines[1]["sharded_lde_commit"]["prove"]       # the whole prover on the same ranks
+    assert "error" not in pn and pn["n_gpus"] == world and pn["base_root"] == p1["base_root"] and pn["fri_root_last"] == p1["fri_root_last"]
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
