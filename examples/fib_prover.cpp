@@ -143,9 +143,10 @@ int main(int argc, char** argv) {
         for (size_t k = 0; k < args.size(); k++) dc.execution_trace.push_back({{splitmix(seed), 0, 0}});
         for (unsigned k = 0; k < ce; k++) dc.composition_trace.push_back({{splitmix(seed), 0, 0}});
         dc.degree[0] = {{splitmix(seed), 0, 0}}; dc.degree[1] = {{splitmix(seed), 0, 0}};
-        Matrix<Fp> deep;
-        deep.columns.push_back(composer.into_deep_poly(dc));
-        Matrix<Fp> deep_lde = deep.bit_reversed_evaluate(lde_dom);
+        // prover.rs:149-152: into_deep_poly + into_bit_reversed_evaluations, computed on the committed LDEs where they lie (ms_deep_rows:
+        // the same evaluations; tests/cpp/test_host_mirror.cpp checks the two routes against each other)
+        Matrix<Fp> deep_lde;
+        deep_lde.columns.push_back(composer.into_deep_evaluations(dc, base_lde, nullptr, comp_lde));
         ph[3] = ms_since(t); t = Clock::now();
         // 5. FRI layers + remainder                                                  fri.rs:179-249
         std::vector<GpuVec<Fp>> layers;                       // FriLayer { merkle_tree, evaluations } (fri.rs:218-221)

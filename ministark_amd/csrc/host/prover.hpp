@@ -152,30 +152,54 @@ public:
         return {ood_exec_, ood_comp_};
     }
     GpuVec<FqT> into_deep_poly(const DeepCompositionCoeffs& coeffs) {           // src/composer.rs:89-188
+        std::vector<const void*> bp, ep;
+        for (auto& c : base_.columns) bp.push_back(c.ptr());
+        auto& second = FqT::words == 1 ? bp : ep;                    // Fq = Fp: everything is a base column
+        if (ext_) for (auto& c : ext_->columns) second.push_back(c.ptr());
+        for (auto& c : comp_.columns) second.push_back(c.ptr());
+        unsigned log_n = 0; while (((size_t)1 << log_n) < n_) log_n++;
+        return compose(coeffs, bp, ep, n_, [&](Planner& pl, const Terms& t, void* out) {
+            return ms_deep_compose(pl.ctx(), FqT::id, log_n, nullptr, bp.empty() ? nullptr : bp.data(), (unsigned)bp.size(), ep.empty() ? nullptr : ep.data(), (unsigned)ep.size(),
+                                   t.pts.data(), t.npoints, t.tcol.data(), t.tpoint.data(), t.al.data(), t.od.data(), (unsigned)t.tcol.size(), t.da.data(), t.db.data(), out); });
+    }
+    // into_deep_poly(coeffs) followed by into_bit_reversed_evaluations(lde_domain) (src/prover.rs:149-152) in one step: the polynomial's
+    // values on the LDE domain (domain_size points, offset 7) computed from the committed LDE matrices themselves (ms_deep_rows) -- the
+    // same field elements, without the coset transforms, the inverse transform and the LDE.  Goldilocks fields.
+    GpuVec<FqT> into_deep_evaluations(const DeepCompositionCoeffs& coeffs, const Matrix<Fp>& base_lde, const Matrix<FqT>* ext_lde, const Matrix<FqT>& comp_lde) {
+        const size_t N = base_lde.num_rows();
+        if (comp_lde.num_rows() != N || (ext_lde && ext_lde->num_rows() != N)) throw std::invalid_argument("into_deep_evaluations: LDE matrices of different heights");
+        std::vector<const void*> bp, ep;
+        for (auto& c : base_lde.columns) bp.push_back(c.ptr());
+        auto& second = FqT::words == 1 ? bp : ep;
+        if (ext_lde) for (auto& c : ext_lde->columns) second.push_back(c.ptr());
+        for (auto& c : comp_lde.columns) second.push_back(c.ptr());
+        unsigned log_N = 0; while (((size_t)1 << log_N) < N) log_N++;
+        return compose(coeffs, bp, ep, N, [&](Planner& pl, const Terms& t, void* out) {
+            return ms_deep_rows(pl.ctx(), FqT::id, log_N, nullptr, 0, N, bp.empty() ? nullptr : bp.data(), (unsigned)bp.size(), ep.empty() ? nullptr : ep.data(), (unsigned)ep.size(),
+                                t.pts.data(), t.npoints, t.tcol.data(), t.tpoint.data(), t.al.data(), t.od.data(), (unsigned)t.tcol.size(), t.da.data(), t.db.data(), out); });
+    }
+private:
+    struct Terms { std::vector<unsigned> tcol, tpoint; std::vector<uint64_t> pts, al, od, da, db; unsigned npoints = 0; };
+    template <class Call>
+    GpuVec<FqT> compose(const DeepCompositionCoeffs& coeffs, const std::vector<const void*>&, const std::vector<const void*>&, size_t out_len, Call call) {
         if (!have_ood_) get_ood_evals();
         Planner& pl = base_.planner();
         std::vector<FqVal> points;
         auto pid = [&](const FqVal& p) { for (size_t k = 0; k < points.size(); k++) if (points[k] == p) return (unsigned)k; points.push_back(p); return (unsigned)points.size() - 1; };
         const FqVal z_n = fq::pow(z_, comp_.num_cols());
         const unsigned next = ext_ ? (unsigned)ext_->num_cols() : 0;
-        std::vector<unsigned> tcol, tpoint; std::vector<FqVal> talpha, tood;
-        for (unsigned c = 0; c < comp_.num_cols(); c++) { tcol.push_back(nbase_ + next + c); tpoint.push_back(pid(z_n)); talpha.push_back(coeffs.composition_trace.at(c)); tood.push_back(ood_comp_[c]); }
-        for (size_t k = 0; k < args_.size(); k++) { tcol.push_back(args_[k].first); tpoint.push_back(pid(point(args_[k].second))); talpha.push_back(coeffs.execution_trace.at(k)); tood.push_back(ood_exec_[k]); }
-        std::vector<const void*> bp, ep;
-        for (auto& c : base_.columns) bp.push_back(c.ptr());
-        auto& second = FqT::words == 1 ? bp : ep;                    // Fq = Fp: everything is a base column
-        if (ext_) for (auto& c : ext_->columns) second.push_back(c.ptr());
-        for (auto& c : comp_.columns) second.push_back(c.ptr());
+        Terms t;
+        std::vector<FqVal> talpha, tood;
+        for (unsigned c = 0; c < comp_.num_cols(); c++) { t.tcol.push_back(nbase_ + next + c); t.tpoint.push_back(pid(z_n)); talpha.push_back(coeffs.composition_trace.at(c)); tood.push_back(ood_comp_[c]); }
+        for (size_t k = 0; k < args_.size(); k++) { t.tcol.push_back(args_[k].first); t.tpoint.push_back(pid(point(args_[k].second))); talpha.push_back(coeffs.execution_trace.at(k)); tood.push_back(ood_exec_[k]); }
         auto flat = [](const std::vector<FqVal>& v) { std::vector<uint64_t> o; for (auto& q : v) fq::push_words<FqT>(o, q); return o; };
-        const auto pts = flat(points), al = flat(talpha), od = flat(tood), da = flat({coeffs.degree[0]}), db = flat({coeffs.degree[1]});
-        GpuVec<FqT> out(pl, n_);
-        unsigned log_n = 0; while (((size_t)1 << log_n) < n_) log_n++;
-        check(ms_deep_compose(pl.ctx(), FqT::id, log_n, nullptr, bp.empty() ? nullptr : bp.data(), (unsigned)bp.size(), ep.empty() ? nullptr : ep.data(), (unsigned)ep.size(),
-                              pts.data(), (unsigned)points.size(), tcol.data(), tpoint.data(), al.data(), od.data(), (unsigned)tcol.size(), da.data(), db.data(), out.ptr()));
+        t.pts = flat(points); t.al = flat(talpha); t.od = flat(tood); t.da = flat({coeffs.degree[0]}); t.db = flat({coeffs.degree[1]});
+        t.npoints = (unsigned)points.size();
+        GpuVec<FqT> out(pl, out_len);
+        check(call(pl, t, out.ptr()));
         pl.sync();
         return out;
     }
-private:
     FqVal point(int offset) const { return fq::mul_base(z_, gl::pow(offset >= 0 ? g_ : g_inv_, (uint64_t)(offset >= 0 ? offset : -offset))); }
     template <class CF>
     std::vector<FqVal> horner(const Matrix<CF>& m, const std::vector<unsigned>& qcol, const std::vector<FqVal>& qpt) {

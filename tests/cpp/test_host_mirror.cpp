@@ -257,6 +257,12 @@ int main() {
         }
         rhs = mulp(rhs, addp(5, mulp(11, r)));
         REQUIRE(mulp(at(qm, 0, r), D) == rhs);
+        // into_deep_evaluations (ms_deep_rows: the polynomial's values taken from the committed LDEs) == into_deep_poly + its LDE, src/prover.rs:149-152
+        ms::Radix2EvaluationDomain lde_dom(4 * n, 7);
+        ms::Matrix<ms::Fp> bl = base.bit_reversed_evaluate(lde_dom), cl = comp.bit_reversed_evaluate(lde_dom);
+        const auto want = qm.bit_reversed_evaluate(lde_dom).columns[0].to_host();
+        const auto got = composer.into_deep_evaluations(co, bl, nullptr, cl).to_host();
+        REQUIRE(got == want);
     }
     {   // proof of work (src/random.rs:48-55): the nonce found has the leading zero bits, no smaller one does
         std::array<uint8_t, 32> seed{};

@@ -409,7 +409,7 @@ def test_lde_two_pass_cosets_hip(log_n, log_b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_n,log_b", [(21, 1), (21, 3), (22, 2), (22, 1)])
-def test_large_lde_random_hip(log_n, log_b):
+def test_two_pass_lde_of_long_rows_hip(log_n, log_b):
     """the two-pass coset LDE on rows of 8192 / 16384 words (lde2_rows_pass<32 / 64>): BASELINE configs[4]'s 2^22-row trace at blow-up 4
     (a 2^24-point domain), its neighbours, natural and bit-reversed order, and ms_evaluate's entry on the same kernels"""
     _lde("hip", GOLDILOCKS_FP, log_n, log_b, ncols=3)
