@@ -211,7 +211,8 @@ HASHES = ("sha256", "rpo256")
 def merkle_view_ids(n, indices):
     """The index walk of `MerkleTreeImpl::prove` (src/merkle.rs:149-206) over a tree of n leaves: -> (leaf_ids, initial, sibling,
     node_ids): the leaves to fetch (initial / sibling: which of them are the queried ones / their siblings) and the internal nodes of
-    the batched opening, in the reference's order.  Indices only -- a single-device tree and a row-sharded one walk the same lists."""
+    the batched opening, in the reference's order.  Indices only -- a single-device tree and a row-sharded one walk the same lists.
+    (An array form of the two queues was tried in round 4: 0.25 ms against 0.10 ms for 32 queries of a 2^24-leaf tree -- kept as queues.)"""
     for i in indices:
         if i >= n:
             raise IndexError(f"leaf index {i} out of bounds ({n})")         # Error::LeafIndexOutOfBounds

@@ -190,7 +190,8 @@ __global__ void __launch_bounds__(NT) horner_blocks(HornerParams P) {
     }
 }
 
-struct Term { uint32_t col, point; uint64_t alpha[3]; uint64_t ood[3]; };   // col: < nbase base, else ext
+// col: < nbase base, else ext.  alimb: the 22 / 22 / 20-bit limbs of alpha's words (limb_mac's second operand; filled by the host)
+struct Term { uint32_t col, point; uint64_t alpha[3]; uint64_t ood[3]; uint32_t alimb[3][4]; };
 struct DeepParams {
     const uint64_t* base[MAXCOLS];     // coset evaluations, natural order, n x Fp
     const uint64_t* ext[MAXCOLS];      //                                  n x Fq3
@@ -203,6 +204,7 @@ struct DeepParams {
     size_t n;
     unsigned nbase, nterms, npoints, lo_bits, xshift;
     unsigned term_start[MAXPOINTS + 1];   // terms are sorted by point: those of point k are [term_start[k], term_start[k + 1])
+    uint64_t csum[MAXPOINTS][3];          // sum_{t: pt = k} alpha_t ood_t (host): the constant part of a point's numerator
     // ms_deep_rows: the n inputs are ROWS [first, first + n) of LDE columns over a domain of 2^log_dom points in bit-reversed
     // order (log_dom = 0: natural order from 0, the coset of ms_deep_compose); adjust: the result is multiplied by
     // (adj_alpha + adj_beta x), the degree adjustment of src/composer.rs:170-186 applied pointwise
@@ -249,30 +251,70 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
             inv = q_mul<PW>(inv, dk);
         }
     }
-    // terms outermost, the lane's PTS points innermost: PTS independent loads per term
+    // terms outermost, the lane's PTS points innermost: PTS independent loads per term.  A point's numerator is
+    //     sum_t alpha_t (P_ct(x) - ood_t)  =  sum_t alpha_t P_ct(x)  -  csum_k:
+    // for Fp columns the first sum is accumulated as UNREDUCED 54-bit limb products (limb_mac: six multiply-adds per term and component,
+    // no carry, no reduction) and reduced once per sixteen terms -- the dependent modular product per term was two thirds of this kernel
+    // (round 4; the Horner kernel's trick).  Extension columns keep the Fq3 product.  Exact arithmetic either way: the same value.
     Q acc[PTS];
     #pragma unroll
     for (int j = 0; j < PTS; j++) acc[j] = q_zero<PW>();
     #pragma unroll
     for (int k = 0; k < MP; k++) if (k < (int)P.npoints) {
         Q sum[PTS];
+        uint64_t S[PTS][PW][6];
         #pragma unroll
-        for (int j = 0; j < PTS; j++) sum[j] = q_zero<PW>();
-        for (unsigned t = P.term_start[k]; t < P.term_start[k + 1]; t++) {          // wave-uniform bounds and terms
-            const Term T = P.terms[t];
-            const Q ood = {{T.ood[0], T.ood[1], T.ood[2]}}, alpha = {{T.alpha[0], T.alpha[1], T.alpha[2]}};
-            Q v[PTS];
+        for (int j = 0; j < PTS; j++) {
+            sum[j] = q_zero<PW>();
+            #pragma unroll
+            for (int w = 0; w < PW; w++) {
+                #pragma unroll
+                for (int i = 0; i < 6; i++) S[j][w][i] = 0;
+            }
+        }
+        unsigned pending = 0;                                                        // unreduced terms in S (wave-uniform)
+        auto flush = [&]() {
             #pragma unroll
             for (int j = 0; j < PTS; j++) {
-                const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
-                if (T.col < P.nbase) v[j] = q_load<1>(P.base[T.col], i);
-                else { if constexpr (PW == 3) v[j] = q_load<3>(P.ext[T.col - P.nbase], i); else v[j] = q_zero<PW>(); }
+                Q r = q_zero<PW>();
+                #pragma unroll
+                for (int w = 0; w < PW; w++) {
+                    r.w[w] = limb_sum_reduce(S[j][w]);
+                    #pragma unroll
+                    for (int i = 0; i < 6; i++) S[j][w][i] = 0;
+                }
+                sum[j] = q_add<PW>(sum[j], r);
             }
-            #pragma unroll
-            for (int j = 0; j < PTS; j++) sum[j] = q_add<PW>(sum[j], q_mul<PW>(q_sub<PW>(v[j], ood), alpha));
+            pending = 0;
+        };
+        for (unsigned t = P.term_start[k]; t < P.term_start[k + 1]; t++) {          // wave-uniform bounds and terms
+            const Term& T = P.terms[t];
+            if (T.col < P.nbase) {
+                uint64_t v[PTS];
+                #pragma unroll
+                for (int j = 0; j < PTS; j++) {
+                    const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
+                    v[j] = P.base[T.col][i];
+                }
+                #pragma unroll
+                for (int j = 0; j < PTS; j++) {
+                    #pragma unroll
+                    for (int w = 0; w < PW; w++) limb_mac(S[j][w], v[j], T.alimb[w]);
+                }
+                if (++pending == 16) flush();
+            } else if constexpr (PW == 3) {
+                const Q alpha = {{T.alpha[0], T.alpha[1], T.alpha[2]}};
+                #pragma unroll
+                for (int j = 0; j < PTS; j++) {
+                    const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
+                    sum[j] = q_add<PW>(sum[j], q_mul<PW>(q_load<3>(P.ext[T.col - P.nbase], i), alpha));
+                }
+            }
         }
+        if (pending) flush();
+        const Q ck = {{P.csum[k][0], P.csum[k][1], P.csum[k][2]}};
         #pragma unroll
-        for (int j = 0; j < PTS; j++) acc[j] = q_add<PW>(acc[j], q_mul<PW>(sum[j], d[j][k]));
+        for (int j = 0; j < PTS; j++) acc[j] = q_add<PW>(acc[j], q_mul<PW>(q_sub<PW>(sum[j], ck), d[j][k]));
     }
     #pragma unroll
     for (int j = 0; j < PTS; j++) {

@@ -278,6 +278,8 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
     // terms sorted by point (the kernel multiplies a point's quotient factor into the SUM of its terms; the order of an exact sum is free)
     std::vector<msdeep::Term> terms;
     terms.reserve(nterms);
+    gl::Fq3 csum[msdeep::MAXPOINTS];
+    for (auto& c : csum) c = {0, 0, 0};
     unsigned term_start[msdeep::MAXPOINTS + 1];
     for (unsigned k = 0; k < npoints; k++) {
         term_start[k] = (unsigned)terms.size();
@@ -288,6 +290,14 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
             T.col = h_term_col[t]; T.point = k;
             memcpy(T.alpha, (const uint64_t*)h_term_alpha + (size_t)t * PW, PW * 8);
             memcpy(T.ood, (const uint64_t*)h_term_ood + (size_t)t * PW, PW * 8);
+            for (unsigned w = 0; w < PW; w++) {              // the limbs limb_mac multiplies an Fp column's value with
+                T.alimb[w][0] = (uint32_t)(T.alpha[w] & 0x3FFFFF); T.alimb[w][1] = (uint32_t)((T.alpha[w] >> 22) & 0x3FFFFF); T.alimb[w][2] = (uint32_t)(T.alpha[w] >> 44);
+            }
+            {                                                  // csum_k += alpha_t ood_t (Montgomery products, as the kernel's)
+                const gl::Fq3 a = {T.alpha[0], T.alpha[1], T.alpha[2]}, o = {T.ood[0], T.ood[1], T.ood[2]};
+                const gl::Fq3 pr = PW == 1 ? gl::Fq3{gl::mont_mul(a.c0, o.c0), 0, 0} : gl::mont_mul(a, o);
+                csum[k] = gl::add(csum[k], pr);
+            }
             terms.push_back(T);
         }
     }
@@ -311,6 +321,7 @@ extern "C" int ms_deep_compose(ms_ctx* ctx, int point_field, unsigned log_n, con
         for (unsigned k = 0; k < npoints; k++) memcpy(D.points[k], (const uint64_t*)h_points + (size_t)k * PW, PW * 8);
         D.out = (uint64_t*)d_q; D.h_mont = gl::to_mont(h); D.n = n; D.nbase = nbase; D.nterms = nterms; D.npoints = npoints;
         memcpy(D.term_start, term_start, sizeof term_start);
+        for (unsigned k = 0; k < npoints; k++) { D.csum[k][0] = csum[k].c0; D.csum[k][1] = csum[k].c1; D.csum[k][2] = csum[k].c2; }
         dim3 g((unsigned)((n + msdeep::NT - 1) / msdeep::NT));
         {
             // points per lane: as many as keep the shared inversion's operands in registers (4 x <= 3 points over Fp, 2 x <= 4 over Fq3)
@@ -379,6 +390,8 @@ extern "C" int ms_deep_rows(ms_ctx* ctx, int point_field, unsigned log_domain, c
     if (count == 0) return MS_OK;
     std::vector<msdeep::Term> terms;
     terms.reserve(nterms);
+    gl::Fq3 csum[msdeep::MAXPOINTS];
+    for (auto& c : csum) c = {0, 0, 0};
     unsigned term_start[msdeep::MAXPOINTS + 1];
     for (unsigned k = 0; k < npoints; k++) {
         term_start[k] = (unsigned)terms.size();
@@ -389,6 +402,14 @@ extern "C" int ms_deep_rows(ms_ctx* ctx, int point_field, unsigned log_domain, c
             T.col = h_term_col[t]; T.point = k;
             memcpy(T.alpha, (const uint64_t*)h_term_alpha + (size_t)t * PW, PW * 8);
             memcpy(T.ood, (const uint64_t*)h_term_ood + (size_t)t * PW, PW * 8);
+            for (unsigned w = 0; w < PW; w++) {              // the limbs limb_mac multiplies an Fp column's value with
+                T.alimb[w][0] = (uint32_t)(T.alpha[w] & 0x3FFFFF); T.alimb[w][1] = (uint32_t)((T.alpha[w] >> 22) & 0x3FFFFF); T.alimb[w][2] = (uint32_t)(T.alpha[w] >> 44);
+            }
+            {                                                  // csum_k += alpha_t ood_t (Montgomery products, as the kernel's)
+                const gl::Fq3 a = {T.alpha[0], T.alpha[1], T.alpha[2]}, o = {T.ood[0], T.ood[1], T.ood[2]};
+                const gl::Fq3 pr = PW == 1 ? gl::Fq3{gl::mont_mul(a.c0, o.c0), 0, 0} : gl::mont_mul(a, o);
+                csum[k] = gl::add(csum[k], pr);
+            }
             terms.push_back(T);
         }
     }
@@ -410,6 +431,7 @@ extern "C" int ms_deep_rows(ms_ctx* ctx, int point_field, unsigned log_domain, c
     for (unsigned k = 0; k < npoints; k++) memcpy(D.points[k], (const uint64_t*)h_points + (size_t)k * PW, PW * 8);
     D.out = (uint64_t*)d_out; D.h_mont = gl::to_mont(h); D.n = count; D.nbase = nbase; D.nterms = nterms; D.npoints = npoints;
     memcpy(D.term_start, term_start, sizeof term_start);
+        for (unsigned k = 0; k < npoints; k++) { D.csum[k][0] = csum[k].c0; D.csum[k][1] = csum[k].c1; D.csum[k][2] = csum[k].c2; }
     D.first = first; D.log_dom = log_domain; D.adjust = 1;
     memcpy(D.adj_alpha, h_degree_alpha, PW * 8);
     memcpy(D.adj_beta, h_degree_beta, PW * 8);
