@@ -272,7 +272,6 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
                 for (int i = 0; i < 6; i++) S[j][w][i] = 0;
             }
         }
-        unsigned pending = 0;                                                        // unreduced terms in S (wave-uniform)
         auto flush = [&]() {
             #pragma unroll
             for (int j = 0; j < PTS; j++) {
@@ -285,33 +284,37 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
                 }
                 sum[j] = q_add<PW>(sum[j], r);
             }
-            pending = 0;
         };
-        for (unsigned t = P.term_start[k]; t < P.term_start[k + 1]; t++) {          // wave-uniform bounds and terms
-            const Term& T = P.terms[t];
-            if (T.col < P.nbase) {
-                uint64_t v[PTS];
-                #pragma unroll
-                for (int j = 0; j < PTS; j++) {
-                    const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
-                    v[j] = P.base[T.col][i];
-                }
-                #pragma unroll
-                for (int j = 0; j < PTS; j++) {
+        // windows of at most sixteen terms (the limb columns' headroom); inside a window the loop is unrolled by four so that the loads of
+        // four terms are in flight together (one memory latency per four terms instead of one per term)
+        for (unsigned t0 = P.term_start[k]; t0 < P.term_start[k + 1]; t0 += 16) {  // wave-uniform bounds and terms
+            const unsigned t1 = t0 + 16 < P.term_start[k + 1] ? t0 + 16 : P.term_start[k + 1];
+            #pragma unroll 4
+            for (unsigned t = t0; t < t1; t++) {
+                const Term& T = P.terms[t];
+                if (T.col < P.nbase) {
+                    uint64_t v[PTS];
                     #pragma unroll
-                    for (int w = 0; w < PW; w++) limb_mac(S[j][w], v[j], T.alimb[w]);
-                }
-                if (++pending == 16) flush();
-            } else if constexpr (PW == 3) {
-                const Q alpha = {{T.alpha[0], T.alpha[1], T.alpha[2]}};
-                #pragma unroll
-                for (int j = 0; j < PTS; j++) {
-                    const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
-                    sum[j] = q_add<PW>(sum[j], q_mul<PW>(q_load<3>(P.ext[T.col - P.nbase], i), alpha));
+                    for (int j = 0; j < PTS; j++) {
+                        const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
+                        v[j] = P.base[T.col][i];
+                    }
+                    #pragma unroll
+                    for (int j = 0; j < PTS; j++) {
+                        #pragma unroll
+                        for (int w = 0; w < PW; w++) limb_mac(S[j][w], v[j], T.alimb[w]);
+                    }
+                } else if constexpr (PW == 3) {
+                    const Q alpha = {{T.alpha[0], T.alpha[1], T.alpha[2]}};
+                    #pragma unroll
+                    for (int j = 0; j < PTS; j++) {
+                        const size_t i = i0 + (size_t)j * NT < P.n ? i0 + (size_t)j * NT : 0;
+                        sum[j] = q_add<PW>(sum[j], q_mul<PW>(q_load<3>(P.ext[T.col - P.nbase], i), alpha));
+                    }
                 }
             }
+            flush();
         }
-        if (pending) flush();
         const Q ck = {{P.csum[k][0], P.csum[k][1], P.csum[k][2]}};
         #pragma unroll
         for (int j = 0; j < PTS; j++) acc[j] = q_add<PW>(acc[j], q_mul<PW>(q_sub<PW>(sum[j], ck), d[j][k]));

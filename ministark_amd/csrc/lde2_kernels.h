@@ -191,8 +191,11 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
 // network, and a last trip through LDS so that the stores are runs of consecutive words.
 // grid = (256 T / 64, columns, beta)          [64 / T rows per workgroup, 256 rows per coset]
 static constexpr int X2P = 65;                               // pitch of the second exchange (words): conflict-free both ways
-template <bool STREAM, int T, bool UNI>
+// NATURAL (T = 2, 4; one coset): the output X[k1 + 256 k0] goes to its natural position -- the forward transform of a 2^17 / 2^18-point
+// column in two passes (ms_ntt.cpp routes GpuFft there): a workgroup's 64 / T consecutive rows k1 give runs of 64 / T words per k0.
+template <bool STREAM, int T, bool UNI, bool NATURAL = false>
 __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
+    static_assert(!NATURAL || T <= 4, "natural-order stores: runs of 64 / T words, T = 2 or 4");
     constexpr int LOGT = T == 64 ? 6 : T == 32 ? 5 : T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
     constexpr int RSEL = 64 / T;                             // rows per workgroup
     constexpr int T1 = T > 16 ? T / 16 : 1, LOGT1 = T1 == 4 ? 2 : T1 == 2 ? 1 : 0;     // T >= 32: radix T = 16 x T1
@@ -285,6 +288,25 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             for (int tt = 0; tt < T; tt++) out[u][tt] = pin(glimb::to_canon(v[tt]));
         }
         __syncthreads();                                      // the second exchange has been read
+        if constexpr (NATURAL) {
+            // third trip, natural order: slot of (k0 part e = (w' 16 + b') T + s, row) is e (RSEL + 1) + row: the readers run along the rows
+            #pragma unroll
+            for (int u = 0; u < NPAIR; u++) {
+                const unsigned pr = threadIdx.x + NT * u;
+                const unsigned kk = pr & 127, rsel = pr >> 7;
+                #pragma unroll
+                for (int tt = 0; tt < T; tt++) xch[(kk * T + tt) * (RSEL + 1) + rsel] = out[u][tt];
+            }
+            __syncthreads();
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const unsigned idx = i * NT + threadIdx.x;    // < 8192 = 128 T x RSEL
+                const unsigned rsel = idx % RSEL, e = idx / RSEL;
+                const unsigned tt = e & (T - 1), bq = (e >> LOGT) & 15, wq = e >> (LOGT + 4);
+                const size_t k0 = (size_t)(wq + 8 * r) + 16 * bq + 256 * (size_t)tt;
+                NTT2_ST(dst + ((size_t)(row0 + rsel) + 256 * k0), (uint64_t)xch[e * (RSEL + 1) + rsel], 2);
+            }
+        } else {
         // third trip: chunk (row, x = bitrev3(w'), c = bitrev4(b')) holds the T outputs in bit-reversed order of t'; the slot
         // of word ad is ad + ad / 16 (16 lanes that write 16 different chunks then hit 16 different banks for every T)
         #pragma unroll
@@ -310,6 +332,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             const unsigned tt = idx & (T - 1), c = (idx >> LOGT) & 15, xq = (idx >> (LOGT + 4)) & 7, rsel = idx >> (LOGT + 7);
             const unsigned k1 = row0 + rsel;
             NTT2_ST(dst + ((size_t)(__brev(k1) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + c * T + tt), (uint64_t)xch[idx + (idx >> 4)], 2);
+        }
         }
         } else {
         // ---- T = 16 T1 (T1 = 2, 4): t = t1 + T1 t0, output s = s0 + 16 s1.  Radix 16 over t0 with t1 WAVE-UNIFORM (one (k, row, t1)

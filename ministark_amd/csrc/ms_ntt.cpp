@@ -498,6 +498,7 @@ static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst,
 
 // Transform `ncols` columns: src[c] -> dst[c] (may alias).  valid_rows < 256 means the
 // source only holds the first valid_rows/256 of the domain, the rest is implicit zeros.
+static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural);
 int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows, bool bitrev_out) {
     if (p->is252) {
         if (valid_rows != 256 || bitrev_out) return fail(MS_ERR_INVALID, "internal: Fp252 zero extension / fused bit reversal go through plan_run252_tiled");
@@ -523,6 +524,11 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
         HIPCHK(hipGetLastError());
         return MS_OK;
     }
+    // Forward transforms of 2^17 / 2^18-point Fp columns: TWO passes -- the coset-LDE kernels with a single coset and natural-order
+    // stores (256 x 512 / 256 x 1024: runs of 32 / 16 words in the second pass's stores; from 2^19 on the runs would be 64 bytes and
+    // the three-pass plan wins).  Columns of this size live in the Infinity Cache, where a pass costs a launch's latency, not bandwidth.
+    if (!p->inverse && p->V == 1 && valid_rows == 256 && !bitrev_out && (p->log_n == 17 || p->log_n == 18) && p->d_wr4[0] != nullptr)
+        return lde2_run(p, p->log_n, 0, src, dst, ncols, true);
     unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
     group = std::min(group, ncols);
     // uniform-factor plans on Fp columns: pass 1 stores whole lines in a row order that permutes the words inside every run of
@@ -772,7 +778,8 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
     return MS_OK;
 }
 // coefficients (2^log_n words per column, src) -> bit-reversed evaluations on the coset of N points (dst, N words per column)
-static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols) {
+// natural (log_b = 0, 2^17 / 2^18 points): the one coset's transform in natural order -- the forward NTT of the column in two passes
+static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural) {
     ms_ctx* ctx = fwd->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -807,6 +814,10 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
             const dim3 g(4 * T, nc, 1u << log_b), b(msntt2::NT);
 #define MS_RB(T_, UNI_) do { if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, T_, UNI_>), g, b, 0, st, P); \
                              else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, T_, UNI_>), g, b, 0, st, P); } while (0)
+            if (natural) {
+                if (stream_hint) { if (T == 4) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 4, true, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 2, false, true>), g, b, 0, st, P); }
+                else { if (T == 4) hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 4, true, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 2, false, true>), g, b, 0, st, P); }
+            } else
             switch (T) {
             case 64: MS_RB(64, true); break;
             case 32: MS_RB(32, true); break;
@@ -944,7 +955,7 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
         if (rc == MS_OK && lde2_applicable(fwd, V, log_n, log_blowup)) {
             // beta coset transforms of size n in two passes each, blocks land in the bit-reversed order
-            rc = lde2_run(fwd, log_n, log_blowup, (const void* const*)d_out, d_out, ncols);
+            rc = lde2_run(fwd, log_n, log_blowup, (const void* const*)d_out, d_out, ncols, false);
             if (rc == MS_OK && !bit_reversed) rc = bit_reverse_run(ctx, V, log_N, (const void* const*)d_out, d_out, ncols);
             return rc;
         }
@@ -992,7 +1003,7 @@ extern "C" int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_
         MSCHK(ctx_plan(ctx, V, log_domain, false, h, &fwd));
     }
     if (V != 4 && lde2_applicable(fwd, V, log_n, log_blowup)) {
-        MSCHK(lde2_run(fwd, log_n, log_blowup, d_in, d_out, ncols));
+        MSCHK(lde2_run(fwd, log_n, log_blowup, d_in, d_out, ncols, false));
         if (!bit_reversed) MSCHK(bit_reverse_run(ctx, V, log_domain, (const void* const*)d_out, d_out, ncols));
         return MS_OK;
     }
