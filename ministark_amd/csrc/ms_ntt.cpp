@@ -524,10 +524,11 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
         HIPCHK(hipGetLastError());
         return MS_OK;
     }
-    // Forward transforms of 2^17 / 2^18-point Fp columns: TWO passes -- the coset-LDE kernels with a single coset and natural-order
-    // stores (256 x 512 / 256 x 1024: runs of 32 / 16 words in the second pass's stores; from 2^19 on the runs would be 64 bytes and
-    // the three-pass plan wins).  Columns of this size live in the Infinity Cache, where a pass costs a launch's latency, not bandwidth.
-    if (!p->inverse && p->V == 1 && valid_rows == 256 && !bitrev_out && (p->log_n == 17 || p->log_n == 18) && p->d_wr4[0] != nullptr)
+    // Forward transforms of 2^18-point Fp columns: TWO passes -- the coset-LDE kernels with a single coset and natural-order stores
+    // (256 x 1024: runs of 16 words in the second pass's stores; from 2^19 on the runs would be 64 bytes and the three-pass plan wins).
+    // Measured (profiles/r04_c2_sweep.json): 2.48 -> 2.25 us per column over 64 columns.  At 2^17 the rows are too short for the uniform
+    // split of pass A's factor (T = 2) and its per-lane running product loses: 1.50 against 1.37 us -- stays on three passes.
+    if (!p->inverse && p->V == 1 && valid_rows == 256 && !bitrev_out && p->log_n == 18 && p->d_wr4[0] != nullptr)
         return lde2_run(p, p->log_n, 0, src, dst, ncols, true);
     unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
     group = std::min(group, ncols);
