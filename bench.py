@@ -26,6 +26,8 @@ Extra objects on the JSON line:
                  rocprofv3 PMC passes when bench is run with --traffic-json, else null.
   cpu_baseline : oracle/c (C/OpenMP restatement of the reference CPU path, kind "port")
                  timed on this box's host cores on one 2^24 column, same data.
+  lde_2_24     : the prover's own transform order at configs[4]'s size -- interpolate + bit-reversed coset evaluation of 2^22-row columns
+                 on the 2^24-point domain (two passes per coset since round 4), with its own roofline.      [N = 1 only]
   lde_commit   : configs[2] (C3): 2^20 rows x 32 columns, blow-up 8, fused LDE + SHA-256 row hashing + Merkle tree,
                  with its own roofline (LDE kernels against HBM; algorithmic bytes n s + beta n s per column,
                  SURVEY.md 8(d)) and cpu_baseline (oracle/c on the same matrix).                       [N = 1 only]
@@ -245,6 +247,36 @@ def bench_lde_commit(pl, with_cpu):
     return out
 
 
+def bench_lde_2_24(pl):
+    """The LDE the prover of configs[4] runs (src/prover.rs:50-51, src/matrix.rs:245): 2^22 rows x 8 columns, blow-up 4 -> 2^24-point
+    bit-reversed evaluations, in the order the prover asks for (natural in, bit-reversed out).  Since round 4 the coset transforms are
+    two passes each (lde2_kernels.h, rows of 16384 words); the iNTT in front of them is the three-pass 2^22-point plan."""
+    import numpy as np
+    from ministark_amd import GOLDILOCKS_FP, Matrix
+    log_n, log_b, ncols = 22, 2, 8
+    n, N = 1 << log_n, 1 << (log_n + log_b)
+    rng = np.random.default_rng(11)
+    P = (1 << 64) - (1 << 32) + 1
+    trace = Matrix.from_numpy(pl, [rng.integers(0, P, size=n, dtype=np.uint64) for _ in range(ncols)], GOLDILOCKS_FP)
+    keep = {}
+
+    def run():
+        keep.clear()
+        keep["lde"] = trace.lde(1 << log_b, 7, True)
+    wall, k = _profiled(pl, run, 5)
+    us = sum(k.values())
+    alg = float(ncols) * (n * 8 + N * 8)                        # n s + beta n s per column (SURVEY.md 8(d))
+    moved = float(ncols) * (3 * 2 * n * 8 + (n * 8 + N * 8) + 2 * N * 8)    # what the passes read + write when nothing is re-read from cache
+    for c in trace.columns:
+        c.free()
+    return {"workload": "2^22 rows x 8 columns (Fp), blow-up 4: interpolate + bit-reversed coset evaluation on the 2^24-point domain (configs[4]'s base-trace LDE)",
+            "wall_ms": round(wall * 1e3, 3), "kernel_us": k, "us_per_column": round(us / ncols, 1),
+            "roofline": {"bound": "hbm", "kernel": "ntt_pass1-3 (iNTT, 2^22 points) + lde2_pass_a + lde2_pass_b", "algorithmic_bytes": alg,
+                         "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_the_passes_move": moved, "moved_over_algorithmic": round(moved / alg, 2)}}
+
+
 def bench_prove(pl, with_cpu):
     """configs[4] on one GPU = BASELINE's "end-to-end prove time": ministark_amd/pipeline.py, 2^22 rows x 8 columns."""
     import numpy as np
@@ -426,7 +458,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed transforms before the warm-up steps (clock ramp)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
     ap.add_argument("--mode", choices=["ntt", "lde-commit"], default="ntt", help="lde-commit: only the column-sharded LDE + commitment (any N)")
     ap.add_argument("--no-extras", action="store_true", help="skip the lde_commit / prove / sharded objects")
     ap.add_argument("--log-rows", type=int, default=22, help="--mode lde-commit: rows of the trace (configs[4]: 2^22)")
@@ -665,6 +697,7 @@ def main():
             c.free()
         out["c2_sweep"] = bench_c2_sweep(pl)
         out["lde_commit"] = bench_lde_commit(pl, not args.no_cpu_baseline)
+        out["lde_2_24"] = bench_lde_2_24(pl)
         out["constraint_eval"] = bench_constraint_eval(pl, not args.no_cpu_baseline)
         out["prove"] = bench_prove(pl, not args.no_cpu_baseline)
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only

@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
 // network, and a last trip through LDS so that the stores are runs of consecutive words.
 // grid = (256 T / 64, columns, beta)          [64 / T rows per workgroup, 256 rows per coset]
 static constexpr int X2P = 65;                               // pitch of the second exchange (words): conflict-free both ways
-// NATURAL (T = 2, 4; one coset): the output X[k1 + 256 k0] goes to its natural position -- the forward transform of a 2^17 / 2^18-point
-// column in two passes (ms_ntt.cpp routes GpuFft there): a workgroup's 64 / T consecutive rows k1 give runs of 64 / T words per k0.
+// NATURAL (one coset): the output X[k1 + 256 k0] goes to its natural position -- the forward transform of a 2^18-point column in two
+// passes (T = 4; ms_ntt.cpp routes GpuFft there): a workgroup's 64 / T consecutive rows k1 give runs of 64 / T words per k0.
 template <bool STREAM, int T, bool UNI, bool NATURAL = false>
 __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     static_assert(!NATURAL || T <= 4, "natural-order stores: runs of 64 / T words, T = 2 or 4");

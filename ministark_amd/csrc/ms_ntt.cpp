@@ -816,8 +816,9 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
 #define MS_RB(T_, UNI_) do { if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, T_, UNI_>), g, b, 0, st, P); \
                              else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, T_, UNI_>), g, b, 0, st, P); } while (0)
             if (natural) {
-                if (stream_hint) { if (T == 4) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 4, true, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 2, false, true>), g, b, 0, st, P); }
-                else { if (T == 4) hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 4, true, true>), g, b, 0, st, P); else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 2, false, true>), g, b, 0, st, P); }
+                if (T != 4) return fail(MS_ERR_INVALID, "internal: natural-order two-pass transform is the 2^18-point plan");
+                if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 4, true, true>), g, b, 0, st, P);
+                else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 4, true, true>), g, b, 0, st, P);
             } else
             switch (T) {
             case 64: MS_RB(64, true); break;
