@@ -225,7 +225,15 @@ int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int out_field, si
  *                    positions (src/trace.rs:139-152, src/matrix.rs get_row)
  * ms_gather_digests  out[k] = digests[indices[k]] (32-byte records): the leaves / sibling leaves / nodes
  *                    a batched Merkle opening lists (MerkleTreeImpl::prove, src/merkle.rs:149-206)
+ * ms_merkle_view_ids the index walk of MerkleTreeImpl::prove itself (src/merkle.rs:149-206; host-only, no device work): for a tree of
+ *                    nleaves leaves and the queried leaf indices -> h_leaf_ids (the leaves to fetch: each queried leaf followed by its
+ *                    pair partner or its sibling; h_leaf_is_sibling[k] = 1 where entry k is a sibling that was NOT queried; at most
+ *                    2 nidx entries) and h_node_ids (the internal nodes of the batched opening in the reference's order; at most
+ *                    nidx * log2(nleaves) entries); the two counts come back through n_leaf_ids / n_node_ids.  Bindings that
+ *                    would walk the two queues in an interpreter call this instead.
  * Positions / indices are host arrays of u64 (they come from the channel); outputs are device buffers. */
+int ms_merkle_view_ids(size_t nleaves, const uint64_t* h_indices, size_t nidx, uint64_t* h_leaf_ids, unsigned char* h_leaf_is_sibling,
+                       size_t* n_leaf_ids, uint64_t* h_node_ids, size_t* n_node_ids);
 int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a, const void* d_b, const void* h_init, int inclusive, void* d_out);
 int ms_gather_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols,
                    const uint64_t* h_positions, size_t npos, void* d_out);

@@ -356,6 +356,34 @@ extern "C" int ms_gather_rows(ms_ctx* ctx, int field, size_t nrows, const void* 
     HIPCHK(hipGetLastError());
     return MS_OK;
 }
+// MerkleTreeImpl::prove's index walk (src/merkle.rs:149-206): two queues, leaves first, then the internal nodes level by level
+extern "C" int ms_merkle_view_ids(size_t nleaves, const uint64_t* h_indices, size_t nidx, uint64_t* h_leaf_ids, unsigned char* h_leaf_is_sibling,
+                                  size_t* n_leaf_ids, uint64_t* h_node_ids, size_t* n_node_ids) {
+    if ((nidx && !h_indices) || !h_leaf_ids || !h_leaf_is_sibling || !n_leaf_ids || !h_node_ids || !n_node_ids) return fail(MS_ERR_INVALID, "ms_merkle_view_ids: null argument");
+    if (nleaves < 2 || (nleaves & (nleaves - 1))) return fail(MS_ERR_INVALID, "number of leaves must be a power of two >= 2");
+    std::vector<uint64_t> idx(h_indices, h_indices + nidx);
+    for (uint64_t i : idx) if (i >= nleaves) return fail(MS_ERR_INVALID, "leaf index %llu out of bounds (%zu)", (unsigned long long)i, nleaves);   // Error::LeafIndexOutOfBounds
+    std::sort(idx.begin(), idx.end());
+    idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+    std::vector<uint64_t> queue;
+    size_t nl = 0, nn = 0;
+    for (size_t k = 0; k < idx.size(); k++) {
+        const uint64_t index = idx[k];
+        h_leaf_ids[nl] = index; h_leaf_is_sibling[nl++] = 0;
+        queue.push_back((nleaves + index) >> 1);
+        if (k + 1 < idx.size() && (index ^ 1) == idx[k + 1]) { h_leaf_ids[nl] = idx[++k]; h_leaf_is_sibling[nl++] = 0; continue; }
+        h_leaf_ids[nl] = index ^ 1; h_leaf_is_sibling[nl++] = 1;
+    }
+    for (size_t head = 0; head < queue.size(); head++) {
+        const uint64_t index = queue[head];
+        if (index > 2) queue.push_back(index >> 1);
+        if (head + 1 < queue.size() && (index ^ 1) == queue[head + 1]) { head++; continue; }
+        h_node_ids[nn++] = index ^ 1;
+    }
+    *n_leaf_ids = nl; *n_node_ids = nn;
+    return MS_OK;
+}
+
 extern "C" int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_digests, const uint64_t* h_indices, size_t count, void* d_out) {
     if (!ctx || !d_digests || !d_out || (count && !h_indices)) return fail(MS_ERR_INVALID, "ms_gather_digests: null argument");
     for (size_t k = 0; k < count; k++) if (h_indices[k] >= ndigests) return fail(MS_ERR_INVALID, "digest %llu out of range", (unsigned long long)h_indices[k]);

@@ -303,7 +303,7 @@ class ShardedTree:
         is fetched by the rank that holds it and collected."""
         pl, comm, G, r = self.planner, self.comm, self.comm.world, self.comm.rank
         n, per = self.nleaves, self.local.nleaves
-        leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices)
+        leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices, pl.lib)
         # where each digest lives: (owner, "leaf" | "node" | "top", local id)
         where = [(i // per, "leaf", i % per) for i in leaf_ids]
         for k in node_ids:

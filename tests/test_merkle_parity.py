@@ -117,3 +117,23 @@ def test_pow_grind_matches_sequential_search(kind):          # src/random.rs:48-
             nonce += 1
         assert got == nonce
     assert grind_proof_of_work(pl, seed, 0) == 1
+
+
+def test_view_index_walk_in_the_library_matches_the_queue_form():
+    """ms_merkle_view_ids (MerkleTreeImpl::prove's index walk, src/merkle.rs:149-206, as a host helper of the C ABI) against the two
+    queues written out in Python, on random and on clustered index sets, trees of 2 .. 2^14 leaves."""
+    from ministark_amd.api import merkle_view_ids, merkle_view_ids_py
+    lib = backends.planner("emu").lib
+    rng = np.random.default_rng(9)
+    for trial in range(1500):
+        n = 1 << int(rng.integers(1, 15))
+        k = int(rng.integers(1, 40))
+        if trial % 3 == 0:
+            base = int(rng.integers(0, n))
+            idx = [min(n - 1, base + int(d)) for d in rng.integers(0, 5, size=k)]
+        else:
+            idx = [int(x) for x in rng.integers(0, n, size=k)]
+        got, want = merkle_view_ids(n, idx, lib), merkle_view_ids_py(n, idx)
+        assert [list(x) for x in got] == [list(x) for x in want], (n, idx)
+    with pytest.raises(IndexError):
+        merkle_view_ids(8, [8], lib)
