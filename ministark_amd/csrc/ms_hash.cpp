@@ -55,16 +55,25 @@ extern "C" int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leave
     uint8_t* nodes = (uint8_t*)d_nodes;
     HIPCHK(hipMemsetAsync(nodes, 0, 32, ctx->stream));
     const uint8_t* src = (const uint8_t*)d_leaves;
-    for (size_t count = nleaves / 2; count >= 1; count >>= 1) {
+    for (size_t count = nleaves / 2; count >= 1;) {
         uint8_t* dst = nodes + count * 32;
         if (count <= (size_t)mssha::NT) {                        // the remaining levels in one launch
             ProfScope ps(ctx, "sha256_merkle_top", 96.0 * (2 * count - 1));
             hipLaunchKernelGGL(mssha::sha256_merkle_top, dim3(1), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
             break;
         }
+        if (count <= ((size_t)1 << 17)) {                        // log2(NT) + 1 levels at once: count / NT subtrees, one workgroup each
+            ProfScope ps(ctx, "sha256_merkle_top", 96.0 * (2 * count - count / mssha::NT));
+            hipLaunchKernelGGL(mssha::sha256_merkle_top, dim3((unsigned)(count / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
+            const size_t last = count / mssha::NT;               // the level the subtrees end in
+            src = nodes + last * 32;
+            count = last / 2;
+            continue;
+        }
         ProfScope ps(ctx, "sha256_merkle_level", 96.0 * count);
         hipLaunchKernelGGL(mssha::sha256_merge_level, dim3((unsigned)((count + mssha::NT - 1) / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, src, dst, count);
         src = dst;
+        count >>= 1;
     }
     HIPCHK(hipGetLastError());
     return MS_OK;

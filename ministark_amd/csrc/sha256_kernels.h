@@ -220,16 +220,20 @@ static __global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* _
     out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
 }
 
-// The top of the tree in ONE launch: levels of <= 256 parents are latency-bound as separate launches
-// (nine launches for the last 511 nodes).  One workgroup keeps the current level in LDS, every
-// level is also written to its slot of nodes[].  `src` holds 2*count digests, count <= 256.
+// The upper part of the tree in few launches: a level of <= 2^17 parents is latency-bound as a launch of its own (two dependent
+// compressions on one lane, 5-6 us, whatever its size), and a 2^24-leaf tree has seventeen of them.  Workgroup b takes the NT parents
+// [b NT, b NT + NT) of a level of `count` parents (count = NT: the top of the tree, one workgroup; count = k NT: k subtrees at once),
+// keeps the current level in LDS and climbs log2(NT) more levels to ONE node; every level is also written to its slot of nodes[]
+// (level of c nodes at nodes[c ..]).  `src` holds 2 * count digests.  count < NT: a single workgroup, the tree's last levels.
 static __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __restrict__ src, uint8_t* __restrict__ nodes, unsigned count) {
     __shared__ uint32_t lvl[2][NT * 8];
-    const unsigned t = threadIdx.x;
+    const unsigned t = threadIdx.x, b = blockIdx.x;
+    unsigned mine = count < (unsigned)NT ? count : (unsigned)NT;          // nodes of the current level this workgroup computes
+    size_t level = count;                                                 // nodes of the current level in the whole tree
     Sha s;
-    if (t < count) {
+    if (t < mine) {
         s.init();
-        const uint4* in = (const uint4*)(src + (size_t)t * 64);
+        const uint4* in = (const uint4*)(src + ((size_t)b * NT + t) * 64);
         #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint4 v = in[q];
@@ -240,17 +244,17 @@ static __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __
     }
     int cur = 0;
     for (;;) {
-        if (t < count) {
-            uint4* out = (uint4*)(nodes + ((size_t)count + t) * 32);
+        if (t < mine) {
+            uint4* out = (uint4*)(nodes + (level + (size_t)b * mine + t) * 32);
             out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
             out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
             #pragma unroll
             for (int q = 0; q < 8; q++) lvl[cur][t * 8 + q] = s.h[q];         // big-endian words, ready for the next schedule
         }
-        if (count == 1) break;
+        if (mine == 1) break;
         __syncthreads();
-        count >>= 1;
-        if (t < count) {
+        mine >>= 1; level >>= 1;
+        if (t < mine) {
             #pragma unroll
             for (int q = 0; q < 16; q++) s.w[q] = lvl[cur][t * 16 + q];
             s.init();
