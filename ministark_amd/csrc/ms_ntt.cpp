@@ -602,6 +602,8 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
                 Q.tw_lo = p->d_tw_lo; Q.tw_hi = p->d_tw_hi; Q.aux_lo = p->d_aux_lo; Q.aux_hi = p->d_aux_hi;
                 Q.log_n = p->log_n; Q.V = p->V; Q.valid_rows = valid_rows; Q.lo_bits = p->lo_bits; Q.log_s = p->log_s[q];
                 Q.tin4 = p->d_tin4; Q.tout4 = p->d_tout4; Q.r3 = p->lr[2];
+                // pass 1 of a uniform-factor plan with last radix 256 (four tiles per block of a row): XCD-aware tile order (ntt2_kernels.h)
+                Q.xcd_map = (q == 0 && p->uni && p->V == 1 && p->lr[2] == 8 && (n / msntt2::TILE) % 8 == 0) ? 1u : 0u;
                 Q.nfields = P.nfields;
                 for (unsigned f = 0; f < P.nfields; f++) Q.fields[f] = P.fields[f];
                 const dim3 g2((unsigned)(n * p->V / msntt2::TILE), nc), b2(msntt2::NT);

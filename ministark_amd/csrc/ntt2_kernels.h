@@ -87,6 +87,7 @@ struct Params {
     const uint64_t* aux_lo;
     const uint64_t* aux_hi;
     unsigned log_n, V, valid_rows, lo_bits, log_s, nfields, r3;   // r3 = log2 of the last radix (UNI kernels)
+    unsigned xcd_map;          // pass 1: take tiles in the XCD-aware order of first_pass_tile (0 = workgroup b takes tile b)
     DigitField fields[3];
 };
 
@@ -614,6 +615,16 @@ __global__ void __launch_bounds__(NT, 4) ntt2_last_pass_bitrev(Params P) {
 // (ntt2_mid_pass<.., PERM>) and writes the natural one -- in place, since the permutation never leaves a pass-2 tile.
 // (Pass 1 itself cannot run in place without a rendezvous of the four tiles that share a 512 KiB slab of the column; that was
 // built and measured in round 3 -- 72 against 56 us per column, profiles/r03_ntt3_inplace.txt -- and dropped.)
+// Which tile workgroup b of pass 1 takes.  Workgroups are dealt to the 8 XCDs round-robin (b % 8; observed, not promised -- this is an
+// ordering for speed, any order is correct).  Tile (j2, g) -- the g-th run of 64 words of block j2 of a row, four per block when the last
+// radix is 256 -- writes the 2 KiB runs j2 of output rows 64 g .. 64 g + 63: with b -> tile b the runs that are neighbours in memory
+// (j2, j2 + 1 of one g) are written by different XCDs at different times; here an XCD keeps one g and walks consecutive j2, so what its
+// L2 writes back is contiguous.  Bare access pattern 53.6 -> 49.8 us per 2^24 column (profiles/r04_ubench9_tile_maps.txt, map 5; the
+// in-place passes 2 and 3 are best left in launch order: 49.3 -> 52.2 under the same re-ordering).
+__device__ __forceinline__ unsigned first_pass_tile(unsigned b, unsigned ntiles) {
+    const unsigned x = b & 7, i = b >> 3, g = x & 3, j2 = (x >> 2) * (ntiles >> 3) + i;
+    return j2 * 4 + g;
+}
 template <bool STREAM, bool INV, bool COSET, int NA, bool UNI = false, bool PERM = false>
 __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * XPITCH];                // [b][a' - 8 round][word], pitch 68 words
@@ -623,7 +634,8 @@ __global__ void __launch_bounds__(NT, 4) ntt2_first_pass(Params P) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row_words = ((size_t)1 << (P.log_n - 8)) * V;
-    const size_t w0 = (size_t)NTT2_BX * TW;
+    const unsigned bx = P.xcd_map ? first_pass_tile(NTT2_BX, gridDim.x) : NTT2_BX;
+    const size_t w0 = (size_t)bx * TW;
     const unsigned j2 = UNI ? (unsigned)((w0 / V) >> P.r3) : 0;       // uniform: the block of R3 V words this tile lies in
 
     uint64_t x[2][16];

@@ -67,6 +67,9 @@ int main(int argc, char** argv) {
     msntt2::Params Q; memset(&Q, 0, sizeof Q);
     Q.wr4 = wr4; Q.twu4 = twu4; Q.sc4 = sc4; Q.g4 = gp; Q.tw_lo = tw_lo; Q.tw_hi = tw_hi; Q.aux_lo = aux_lo; Q.aux_hi = aux_hi;
     Q.log_n = log_n; Q.V = 1; Q.valid_rows = 256; Q.lo_bits = 12; Q.tin4 = tin4; Q.tout4 = tout4; Q.r3 = 8;
+#ifdef VAR_XCD
+    Q.xcd_map = 1;
+#endif
     const msntt::DigitField f1[2] = {{0, 8, 255}, {8, 0, 255}};
     const dim3 b2(msntt2::NT);
     unsigned scr_of = 0xFFFFFFFFu;      // chain modes: every column through scratch column scr_of

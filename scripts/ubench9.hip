@@ -102,7 +102,21 @@ __global__ void __launch_bounds__(512, 4) k_tile(Cols C) {
 
 // L8 / S8 with non-temporal loads and stores; MODE 1 = pass 1 (rows at stride 2^16 words in, 64 runs of 256 words out with the product's
 // permuted 16-byte stores -- ntt2_first_pass<.., PERM>), MODE 2 / 3 as above
-template <int MODE, int SPIN, bool NT>
+// MAP: which tile a workgroup takes (workgroup b runs on XCD b % 8): 0 = b; 1 = every XCD walks its own contiguous eighth of the tiles;
+// 2 = the 10-bit reversal of b (concurrent workgroups far apart); 3 = b with its low three bits moved to the top
+template <int MAP> __device__ __forceinline__ unsigned tile_of(unsigned b) {
+    if (MAP == 1) return (b & 7) * 128 + (b >> 3);
+    if (MAP == 2) return __brev(b) >> 22;
+    if (MAP == 3) return ((b & 7) << 7) | (b >> 3);
+    if (MAP == 4) { const unsigned x = b & 7, i = b >> 3, j2 = x * 32 + (i & 31), g = i >> 5; return j2 * 4 + g; }     // pass 1: an XCD walks consecutive j2 of one g
+    if (MAP == 5) { const unsigned x = b & 7, i = b >> 3, g = x & 3, j2 = (x >> 2) * 128 + i; return j2 * 4 + g; }      // pass 1: g fixed per XCD pair
+    if (MAP == 7) { const unsigned x = b & 7, i = b >> 3, g = x & 3, j2 = 2 * i + (x >> 2); return j2 * 4 + g; }                   // pass 1: two XCDs per g interleave consecutive j2
+    if (MAP == 8) { const unsigned x = b & 7, i = b >> 3, g = x >> 1, j2 = 2 * i + (x & 1); return j2 * 4 + g; }                    // the same with the XCD pairs adjacent
+    if (MAP == 9) { const unsigned x = b & 7, i = b >> 3, g = x & 3, j2 = (x >> 2) * 128 + ((i & 1) ? 127 - (i >> 1) : (i >> 1)); return j2 * 4 + g; }   // map 5 walking from both ends
+    if (MAP == 6) { const unsigned x = b & 7, i = b >> 3; return (i >> 2) * 32 + x * 4 + (i & 3); }                      // groups of 4 consecutive tiles per XCD
+    return b;
+}
+template <int MODE, int SPIN, bool NT, int MAP = 0>
 __global__ void __launch_bounds__(512, 4) k_tile_nt(Cols C) {
     const uint64_t* __restrict__ src = C.src[blockIdx.y];
     uint64_t* __restrict__ dst = C.dst[blockIdx.y];
@@ -110,8 +124,9 @@ __global__ void __launch_bounds__(512, 4) k_tile_nt(Cols C) {
     __shared__ uint64_t occ[8192];
     occ[tid] = tid;
     size_t rbase, rstride;
-    if (MODE == 1) { const unsigned j2 = blockIdx.x >> 2, g = blockIdx.x & 3; rbase = (size_t)j2 * 256 + 64 * g; rstride = 65536; }
-    else geom<MODE>(blockIdx.x, rbase, rstride);
+    const unsigned bx = tile_of<MAP>(blockIdx.x);
+    if (MODE == 1) { const unsigned j2 = bx >> 2, g = bx & 3; rbase = (size_t)j2 * 256 + 64 * g; rstride = 65536; }
+    else geom<MODE>(bx, rbase, rstride);
     uint64_t v[32];
     #pragma unroll
     for (int i = 0; i < 32; i++) { const uint64_t* p = src + rbase + (size_t)(w + 8 * i) * rstride + lane; v[i] = NT ? __builtin_nontemporal_load(p) : *p; }
@@ -121,7 +136,7 @@ __global__ void __launch_bounds__(512, 4) k_tile_nt(Cols C) {
     v[0] += occ[tid ^ 64] >> 20;
     if (MODE == 1) {
         typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
-        const unsigned j2 = blockIdx.x >> 2, g = blockIdx.x & 3, c3 = lane & 7, tl = lane >> 3;
+        const unsigned j2 = bx >> 2, g = bx & 3, c3 = lane & 7, tl = lane >> 3;
         #pragma unroll
         for (int i = 0; i < 32; i += 2) {
             const unsigned r = i >> 4, d = i & 15, t = 8 * w + tl;
@@ -299,6 +314,19 @@ int main() {
         timeit("pass 3 pattern, non-temporal,   17 units", [&] { hipLaunchKernelGGL((k_tile_nt<3, 17, true>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
         timeit("pass 3 pattern, non-temporal,    0 units", [&] { hipLaunchKernelGGL((k_tile_nt<3, 0, true>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
         timeit("pass 2 pattern, non-temporal,    0 units", [&] { hipLaunchKernelGGL((k_tile_nt<2, 0, true>), dim3(1024, NCOL), dim3(512), 0, 0, C2); });
+        timeit("pass 3 pattern, nt, 17 units, tile map 1 (an eighth of the tiles per XCD)", [&] { hipLaunchKernelGGL((k_tile_nt<3, 17, true, 1>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
+        timeit("pass 3 pattern, nt, 17 units, tile map 2 (bit-reversed)", [&] { hipLaunchKernelGGL((k_tile_nt<3, 17, true, 2>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
+        timeit("pass 1 pattern, nt, 17 units, tile map 1", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true, 1>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 1 pattern, nt, 17 units, tile map 2", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true, 2>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 1 pattern, nt, 17 units, tile map 4 (XCD: consecutive j2 of one g)", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true, 4>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 1 pattern, nt, 17 units, tile map 5 (g fixed per XCD)", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true, 5>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 1 pattern, nt, 17 units, tile map 7 (two XCDs per g, interleaved j2)", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true, 7>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 1 pattern, nt, 17 units, tile map 8 (adjacent XCD pairs per g)", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true, 8>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 1 pattern, nt, 17 units, tile map 6 (4 consecutive tiles per XCD)", [&] { hipLaunchKernelGGL((k_tile_nt<1, 17, true, 6>), dim3(1024, NCOL), dim3(512), 0, 0, C1); });
+        timeit("pass 3 pattern, nt, 17 units, tile map 6 (4 consecutive tiles per XCD)", [&] { hipLaunchKernelGGL((k_tile_nt<3, 17, true, 6>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
+        timeit("pass 3 pattern, nt, 17 units, tile map 3", [&] { hipLaunchKernelGGL((k_tile_nt<3, 17, true, 3>), dim3(1024, NCOL), dim3(512), 0, 0, C3); });
+        timeit("pass 2 pattern, nt, 17 units, tile map 1", [&] { hipLaunchKernelGGL((k_tile_nt<2, 17, true, 1>), dim3(1024, NCOL), dim3(512), 0, 0, C2); });
+        timeit("pass 2 pattern, nt, 17 units, tile map 2", [&] { hipLaunchKernelGGL((k_tile_nt<2, 17, true, 2>), dim3(1024, NCOL), dim3(512), 0, 0, C2); });
     }
     return 0;
 }
