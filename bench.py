@@ -159,11 +159,14 @@ def _profiled(pl, fn, reps, after_wall=None):
     hipEvents (a pair per kernel, ~150 launches per prover run, costs 15-20 % of the wall time); the kernel times come
     from a second set of runs with them."""
     fn(); pl.sync()                                            # plans, pool, specialised kernels
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    fn(); pl.sync()                                            # clocks, allocator
+    walls = []
+    for _ in range(reps):                                      # every call timed on its own (synced), the MEDIAN is reported:
+        t0 = time.perf_counter()                               # the host side of a box is noisy (10.3 .. 11.5 ms for the same proof)
         fn()
-    pl.sync()
-    wall = (time.perf_counter() - t0) / reps
+        pl.sync()
+        walls.append(time.perf_counter() - t0)
+    wall = sorted(walls)[len(walls) // 2]
     if after_wall:
         after_wall()
     pl.profile(True)
@@ -294,7 +297,7 @@ def bench_prove(pl, with_cpu):
         res.clear()
         res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, ce_blowup=ce))
     phases = {}
-    wall, k = _profiled(pl, run, 3, after_wall=lambda: phases.update(res["phases_ms"]))      # phases of a run without events
+    wall, k = _profiled(pl, run, 5, after_wall=lambda: phases.update(res["phases_ms"]))      # phases of a run without events
     n_lde, n_ce = n_t * blowup, n_t * ce
     # algorithmic bytes per SURVEY.md 8(d): LDEs n s + beta n s per column, in-place transforms 2 n s, row hashing n cols s + 32 n,
     # trees 96 n, constraint evaluation sum of columns + result (on the n ce points of the constraint-evaluation domain), FRI
