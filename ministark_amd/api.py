@@ -185,18 +185,53 @@ class DeviceBytes:
             pass
 
 
-def _gather_digests_launch(planner, digests, ndigests, ids):
+class GatherBatch:
+    """One device buffer for every gather of a phase (the query phase of a proof opens two trace trees and every FRI layer: some twenty
+    small gathers): each gather writes its slice, the first fetch downloads the buffer ONCE and every fetch reads its slice of the host
+    copy -- one device-to-host copy and one wait instead of twenty (each costs a round trip of 25-40 us however small it is)."""
+
+    def __init__(self, planner, capacity=1 << 20):
+        self.planner, self.capacity, self.used = planner, capacity, 0
+        self.buf = DeviceBytes(planner, capacity)
+        self._host = None
+
+    def reserve(self, nbytes):
+        """-> (device pointer, reader) for a slice of nbytes, or None when the batch is full or has already been fetched"""
+        nbytes = (nbytes + 31) & ~31
+        if self._host is not None or self.used + nbytes > self.capacity:
+            return None
+        off = self.used
+        self.used += nbytes
+
+        def read():
+            if self._host is None:
+                self._host = self.buf.to_numpy()
+            return self._host[off:off + nbytes]
+        return self.buf.ptr + off, read
+
+
+def _gather_slot(planner, nbytes, batch):
+    """(device pointer, function returning the bytes, keep-alive) for a gather's output: a slice of `batch` if there is room, else its own buffer"""
+    slot = batch.reserve(nbytes) if batch is not None else None
+    if slot is not None:
+        return slot[0], slot[1], batch
+    out = DeviceBytes(planner, nbytes)
+    return out.ptr, out.to_numpy, out
+
+
+def _gather_digests_launch(planner, digests, ndigests, ids, batch=None):
     """Launch the gather of the 32-byte records `ids` of a device digest array; returns a function that downloads them as a
-    list of bytes.  (Launch every gather of an opening first, fetch afterwards: one wait instead of one per call.)"""
+    list of bytes.  (Launch every gather of an opening first, fetch afterwards: one wait instead of one per call; with a
+    GatherBatch one download for the whole phase.)"""
     if not ids:
         return lambda: []
     idx = np.asarray(ids, dtype=np.uint64)
-    out = DeviceBytes(planner, 32 * len(ids))
+    ptr, read, keep = _gather_slot(planner, 32 * len(ids), batch)
     L = planner.lib
-    L.check(L.ms_gather_digests(planner.handle, ndigests, digests.ptr, idx.ctypes.data, len(ids), out.ptr))
+    L.check(L.ms_gather_digests(planner.handle, ndigests, digests.ptr, idx.ctypes.data, len(ids), ptr))
 
-    def fetch():
-        raw = out.to_numpy().tobytes()
+    def fetch(_keep=keep):
+        raw = read().tobytes()
         return [raw[32 * k:32 * k + 32] for k in range(len(ids))]
     return fetch
 
@@ -309,12 +344,12 @@ class MerkleTree:
         come back in one copy."""
         return self.prove_launch(indices)()
 
-    def prove_launch(self, indices):
+    def prove_launch(self, indices, batch=None):
         """`prove` in two halves: the device gathers are launched now, the returned function fetches and assembles the view."""
         n = self.nleaves
         leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices, self.planner.lib)
-        fetch_leaves = _gather_digests_launch(self.planner, self.leaves, n, leaf_ids)
-        fetch_nodes = _gather_digests_launch(self.planner, self.nodes, n, node_ids)
+        fetch_leaves = _gather_digests_launch(self.planner, self.leaves, n, leaf_ids, batch)
+        fetch_nodes = _gather_digests_launch(self.planner, self.nodes, n, node_ids, batch)
 
         def fetch():
             leaves, nodes = fetch_leaves(), fetch_nodes()
@@ -552,16 +587,16 @@ class Matrix:
         [len(positions), num_cols * words], Montgomery words, gathered on the device."""
         return self.get_rows_launch(positions)()
 
-    def get_rows_launch(self, positions):
+    def get_rows_launch(self, positions, batch=None):
         """Launches the gather and returns the function that fetches its result (callers start every gather of a phase first)."""
         pl, L = self.planner, self.planner.lib
         pos = np.asarray(positions, dtype=np.uint64)
         words = self.num_cols() * FIELD_WORDS[self.field]
         if len(pos) == 0:
             return lambda: np.zeros((0, words), dtype=np.uint64)
-        out = DeviceBytes(pl, len(pos) * words * 8)
-        L.check(L.ms_gather_rows(pl.handle, self.field, self.num_rows(), _ptr_array(self.columns), self.num_cols(), pos.ctypes.data, len(pos), out.ptr))
-        return lambda: out.to_numpy().view(np.uint64)[: len(pos) * words].reshape(len(pos), words)
+        ptr, read, keep = _gather_slot(pl, len(pos) * words * 8, batch)
+        L.check(L.ms_gather_rows(pl.handle, self.field, self.num_rows(), _ptr_array(self.columns), self.num_cols(), pos.ctypes.data, len(pos), ptr))
+        return lambda _keep=keep: np.array(read()[: len(pos) * words * 8]).view(np.uint64).reshape(len(pos), words)
 
     def hash_rows(self, hash="sha256"):
         """`hash_rows::<F, H>` (src/merkle.rs:412-436, src/matrix.rs:254-280): one digest per row ->
@@ -623,17 +658,28 @@ class Queries:
     """`Queries::new` (src/trace.rs:113-157): the rows of the base / extension / composition LDEs at the
     query positions and the batched Merkle openings of the three trees, all gathered on the device."""
 
-    def __init__(self, base_trace_lde, extension_trace_lde, composition_trace_lde, base_tree, extension_tree, composition_tree, positions):
+    def __init__(self, base_trace_lde, extension_trace_lde, composition_trace_lde, base_tree, extension_tree, composition_tree, positions,
+                 batch=None):
         positions = [int(p) for p in positions]
         none = lambda: None
-        launched = [base_tree.prove_launch(positions),                      # every gather is in flight before the first download
-                    extension_tree.prove_launch(positions) if extension_tree is not None else none,
-                    composition_tree.prove_launch(positions),
-                    base_trace_lde.get_rows_launch(positions),
-                    extension_trace_lde.get_rows_launch(positions) if extension_trace_lde is not None else none,
-                    composition_trace_lde.get_rows_launch(positions)]
+        deferred = batch is not None                                        # the caller's batch: it fetches when its other gathers are launched too
+        batch = batch if batch is not None else GatherBatch(base_trace_lde.planner)
+        launched = [base_tree.prove_launch(positions, batch),               # every gather is in flight before the first download
+                    extension_tree.prove_launch(positions, batch) if extension_tree is not None else none,
+                    composition_tree.prove_launch(positions, batch),
+                    base_trace_lde.get_rows_launch(positions, batch),
+                    extension_trace_lde.get_rows_launch(positions, batch) if extension_trace_lde is not None else none,
+                    composition_trace_lde.get_rows_launch(positions, batch)]
+        self._launched = launched
+        if not deferred:
+            self.fetch()
+
+    def fetch(self):
+        """downloads (once per batch) and assembles the six members; called by the constructor's users that passed their own batch"""
+        launched = self._launched
         (self.base_trace_proof, self.extension_trace_proof, self.composition_trace_proof, self.base_trace_values,
          self.extension_trace_values, self.composition_trace_values) = [f() for f in launched]
+        return self
 
 
 def apply_drp(evals, alpha, folding_factor, domain_offset=1):

@@ -169,7 +169,7 @@ def fold_positions(positions, folding_factor):
     return out
 
 
-def fri_layer_rows_launch(layer, folding_factor, positions):
+def fri_layer_rows_launch(layer, folding_factor, positions, batch=None):
     """Rows `positions` of `Matrix::from_arrays(evaluations.as_chunks::<N>())` (src/fri.rs:213-215): N consecutive
     evaluations each, gathered on the device (32-byte records of ms_gather_digests).  Returns a function that downloads
     them as numpy [len(positions), N * words]."""
@@ -180,9 +180,10 @@ def fri_layer_rows_launch(layer, folding_factor, positions):
         return lambda: layer.to_numpy().reshape(-1, words)[positions]      # rows shorter than a 32-byte record: tiny layers only
     per = words // 4
     ids = np.array([p * per + k for p in positions for k in range(per)], dtype=np.uint64)
-    out = DeviceBytes(pl, 32 * len(ids))
-    pl.lib.check(pl.lib.ms_gather_digests(pl.handle, len(layer) * FIELD_WORDS[layer.field] // 4, layer.ptr, ids.ctypes.data, len(ids), out.ptr))
-    return lambda: out.to_numpy().view(np.uint64).reshape(len(positions), words)
+    from .api import _gather_slot
+    ptr, read, keep = _gather_slot(pl, 32 * len(ids), batch)
+    pl.lib.check(pl.lib.ms_gather_digests(pl.handle, len(layer) * FIELD_WORDS[layer.field] // 4, layer.ptr, ids.ctypes.data, len(ids), ptr))
+    return lambda _keep=keep: np.array(read()[: 32 * len(ids)]).view(np.uint64).reshape(len(positions), words)
 
 
 def fri_layer_rows(layer, folding_factor, positions):
@@ -280,12 +281,15 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
     out["remainder_coeffs"] = rem.to_numpy()[: max(n // blowup, 1)]
     lap("FRI layers (commit + fold) + remainder")
     out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)   # prover.rs:160
-    out["queries"] = Queries(lde_t, None, comp_lde, tree_t, None, tree_c, draws.positions)                # prover.rs:163-173
+    from .api import GatherBatch
+    batch = GatherBatch(pl)                                                    # every gather of the phase into one buffer: ONE download
+    queries = Queries(lde_t, None, comp_lde, tree_t, None, tree_c, draws.positions, batch)                # prover.rs:163-173
     # fri_prover.into_proof(&query_positions) (prover.rs:161, fri.rs:148-165): per layer the folded positions' rows and Merkle view
     pos, launched = sorted(set(int(p) for p in draws.positions)), []
-    for layer, tree in zip(fri_layers, fri_trees):                            # all gathers first, then the downloads
+    for layer, tree in zip(fri_layers, fri_trees):                            # all gathers first, then the download
         pos = fold_positions(pos, folding)
-        launched.append((pos, fri_layer_rows_launch(layer, folding, pos), tree.prove_launch(pos)))
+        launched.append((pos, fri_layer_rows_launch(layer, folding, pos, batch), tree.prove_launch(pos, batch)))
+    out["queries"] = queries.fetch()
     out["fri_openings"] = [{"positions": p, "rows": rows(), "proof": proof()} for p, rows, proof in launched]
     lap("proof of work + queries")
     out["phases_ms"] = {k: round(v, 3) for k, v in phase.items()}
