@@ -286,6 +286,45 @@ def _allgather_words(planner, comm, words):
     return buf.to_numpy()[: nb * G].view(np.uint64).reshape(G, -1).copy()
 
 
+class OpeningBatch:
+    """The openings of a proof as ONE collective: every request (a Merkle view of a sharded tree, rows of a row-sharded matrix or FRI layer)
+    registers what each rank contributes; `execute` lets every rank gather its contributions into one device buffer, collects the buffers on
+    `root` in one exchange and one download, and returns the assembled results there (None elsewhere).  The sizes are functions of the
+    positions alone, so every rank computes every rank's byte counts without talking."""
+
+    def __init__(self, planner, comm, root=0):
+        self.planner, self.comm, self.root, self.reqs = planner, comm, root, []
+
+    def add(self, sizes, run, parse):
+        """sizes[q]: bytes rank q contributes; run(ptr): this rank's gathers into ptr .. ptr + sizes[rank]; parse(chunks): chunks[q] = rank q's bytes"""
+        self.reqs.append((list(sizes), run, parse))
+        return len(self.reqs) - 1
+
+    def execute(self):
+        pl, comm, G, r = self.planner, self.comm, self.comm.world, self.comm.rank
+        totals = [sum(sz[q] for sz, _, _ in self.reqs) for q in range(G)]
+        arena = DeviceBytes(pl, max(8, totals[r]))
+        off = 0
+        for sz, run, _ in self.reqs:
+            if sz[r]:
+                run(arena.ptr + off)
+                off += sz[r]
+        got = _collect(pl, comm, arena, totals, self.root)
+        if r != self.root:
+            return [None] * len(self.reqs)
+        raw = got.to_numpy()
+        base = np.concatenate([[0], np.cumsum(totals)]).astype(np.int64)
+        cur = [int(b) for b in base[:-1]]
+        out = []
+        for sz, _, parse in self.reqs:
+            chunks = []
+            for q in range(G):
+                chunks.append(raw[cur[q]:cur[q] + sz[q]])
+                cur[q] += sz[q]
+            out.append(parse(chunks))
+        return out
+
+
 class ShardedTree:
     """A Merkle tree whose leaves are spread over the ranks in row blocks: rank r holds the subtree over leaves [r n / G, (r + 1) n / G)
     (node G + r of the whole tree) and every rank the top levels (nodes 1 .. G - 1)."""
@@ -301,7 +340,13 @@ class ShardedTree:
     def prove(self, indices, root=0):
         """`MerkleTreeImpl::prove` (src/merkle.rs:149-206) -> the MerkleView of the whole tree on `root` (None elsewhere): every digest
         is fetched by the rank that holds it and collected."""
-        pl, comm, G, r = self.planner, self.comm, self.comm.world, self.comm.rank
+        batch = OpeningBatch(self.planner, self.comm, root)
+        self.request(batch, indices)
+        return batch.execute()[0]
+
+    def request(self, batch, indices):
+        """registers this tree's view of `indices` with an OpeningBatch; -> the request's index in the batch's results"""
+        pl, G, r = self.planner, self.comm.world, self.comm.rank
         n, per = self.nleaves, self.local.nleaves
         leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices, pl.lib)
         # where each digest lives: (owner, "leaf" | "node" | "top", local id)
@@ -309,70 +354,94 @@ class ShardedTree:
         for k in node_ids:
             lvl = 1 << (k.bit_length() - 1)
             if lvl < G:
-                where.append((root, "top", k))
+                where.append((batch.root, "top", k))
             else:
                 j, per_lvl = k - lvl, lvl // G
                 where.append((j // per_lvl, "node", per_lvl + j % per_lvl))
-        mine = [(kind, i) for owner, kind, i in where if owner == r]
-        parts = []
-        for kind, src, count in (("leaf", self.local.leaves, per), ("node", self.local.nodes, per), ("top", self.top.nodes if self.top else None, G)):
-            ids = [i for k, i in mine if k == kind]
-            if ids:
-                idx = np.asarray(ids, dtype=np.uint64)
-                out = DeviceBytes(pl, 32 * len(ids))
-                pl.lib.check(pl.lib.ms_gather_digests(pl.handle, count, src.ptr, idx.ctypes.data, len(ids), out.ptr))
-                parts.append((kind, out, len(ids)))
-        buf = DeviceBytes(pl, max(8, 32 * len(mine)))
-        off = 0
-        for kind, out, cnt in parts:                          # rank-local layout: leaves, then nodes, then top digests
-            pl.lib.check(pl.lib.ms_copy(pl.handle, buf.ptr + off, out.ptr, 32 * cnt))
-            off += 32 * cnt
-        nbytes = [32 * sum(1 for owner, _, _ in where if owner == q) for q in range(G)]
-        got = _collect(pl, comm, buf, nbytes, root)
-        if r != root:
-            return None
-        raw = got.to_numpy().tobytes()
-        offs = np.concatenate([[0], np.cumsum(nbytes)]).astype(np.int64)
-        # per owner the digests arrive grouped by kind (leaf, node, top), each group in id order
-        cursor = {}
-        for q in range(G):
-            base = int(offs[q])
-            for kind in ("leaf", "node", "top"):
-                cursor[(q, kind)] = base
-                base += 32 * sum(1 for owner, k, _ in where if owner == q and k == kind)
-        digests = []
-        for owner, kind, _ in where:
-            o = cursor[(owner, kind)]
-            digests.append(raw[o:o + 32])
-            cursor[(owner, kind)] = o + 32
-        leaves, nodes = digests[: len(leaf_ids)], digests[len(leaf_ids):]
-        return {"nodes": nodes, "initial_leaves": [leaves[k] for k in initial], "sibling_leaves": [leaves[k] for k in sibling],
-                "height": n.bit_length() - 1}
+        kinds = ("leaf", "node", "top")
+        count = {(q, kind): sum(1 for owner, k, _ in where if owner == q and k == kind) for q in range(G) for kind in kinds}
+        sizes = [32 * sum(count[(q, kind)] for kind in kinds) for q in range(G)]
+        srcs = {"leaf": (self.local.leaves, per), "node": (self.local.nodes, per), "top": (self.top.nodes if self.top else None, G)}
+
+        def run(ptr):                                        # this rank's digests: leaves, then nodes, then top levels, each in id order
+            off = 0
+            for kind in kinds:
+                ids = [i for owner, k, i in where if owner == r and k == kind]
+                if ids:
+                    idx = np.asarray(ids, dtype=np.uint64)
+                    src, cnt = srcs[kind]
+                    pl.lib.check(pl.lib.ms_gather_digests(pl.handle, cnt, src.ptr, idx.ctypes.data, len(ids), ptr + off))
+                    off += 32 * len(ids)
+
+        def parse(chunks):
+            cursor = {}
+            for q in range(G):
+                base = 0
+                for kind in kinds:
+                    cursor[(q, kind)] = base
+                    base += 32 * count[(q, kind)]
+            digests = []
+            for owner, kind, _ in where:
+                o = cursor[(owner, kind)]
+                digests.append(chunks[owner][o:o + 32].tobytes())
+                cursor[(owner, kind)] = o + 32
+            leaves, nodes = digests[: len(leaf_ids)], digests[len(leaf_ids):]
+            return {"nodes": nodes, "initial_leaves": [leaves[k] for k in initial], "sibling_leaves": [leaves[k] for k in sibling],
+                    "height": n.bit_length() - 1}
+        return batch.add(sizes, run, parse)
 
 
-def _sharded_rows(planner, comm, columns, field, positions, per, root=0):
-    """Rows `positions` (global row numbers, any order) of a matrix whose rows are spread over the ranks in blocks of `per`:
-    -> numpy [len(positions), words] on `root` in the order given (None elsewhere)."""
-    r, G = comm.rank, comm.world
+def _rows_request(batch, columns, field, positions, per):
+    """rows `positions` (global row numbers, any order) of a matrix whose rows are spread over the ranks in blocks of `per` -> numpy
+    [len(positions), words] in the order given"""
+    pl, G, r = batch.planner, batch.comm.world, batch.comm.rank
     positions = [int(p) for p in positions]
     words = len(columns) * FIELD_WORDS[field]
-    mine = [p - r * per for p in positions if p // per == r]
-    buf = DeviceBytes(planner, max(8, len(mine) * words * 8))
-    if mine:
-        pos = np.asarray(mine, dtype=np.uint64)
-        planner.lib.check(planner.lib.ms_gather_rows(planner.handle, field, per, _ptr_array(columns), len(columns), pos.ctypes.data, len(pos), buf.ptr))
-    nbytes = [sum(1 for p in positions if p // per == q) * words * 8 for q in range(G)]
-    got = _collect(planner, comm, buf, nbytes, root)
-    if r != root:
-        return None
-    flat = got.to_numpy()[: len(positions) * words * 8].view(np.uint64).reshape(-1, words) if positions else np.zeros((0, words), dtype=np.uint64)
-    nxt = {q: int(sum(nbytes[:q]) // (words * 8)) for q in range(G)}
-    out = np.zeros((len(positions), words), dtype=np.uint64)
-    for k, p in enumerate(positions):
-        q = p // per
-        out[k] = flat[nxt[q]]
-        nxt[q] += 1
-    return out
+    sizes = [sum(1 for p in positions if p // per == q) * words * 8 for q in range(G)]
+
+    def run(ptr):
+        pos = np.asarray([p - r * per for p in positions if p // per == r], dtype=np.uint64)
+        pl.lib.check(pl.lib.ms_gather_rows(pl.handle, field, per, _ptr_array(columns), len(columns), pos.ctypes.data, len(pos), ptr))
+
+    def parse(chunks):
+        rows = [np.array(c).view(np.uint64).reshape(-1, words) for c in chunks]
+        nxt = [0] * G
+        out = np.zeros((len(positions), words), dtype=np.uint64)
+        for k, p in enumerate(positions):
+            q = p // per
+            out[k] = rows[q][nxt[q]]
+            nxt[q] += 1
+        return out
+    return batch.add(sizes, run, parse)
+
+
+def _fri_rows_request(batch, layer_shard, folding, positions, per):
+    """rows `positions` of Matrix::from_arrays(evaluations.as_chunks::<N>()) (src/fri.rs:213-215) of a row-sharded layer: `per` rows of
+    `folding` evaluations on each rank.  A row is `folding` consecutive words = folding / 4 32-byte records of the shard, fetched with the
+    digest gather (as pipeline.fri_layer_rows_launch does on one device); folding factor 2: picked on the host."""
+    pl, G, r = batch.planner, batch.comm.world, batch.comm.rank
+    rec = folding // 4
+    sizes = [sum(1 for p in positions if p // per == q) * folding * 8 for q in range(G)]
+
+    def run(ptr):
+        mine = [p - r * per for p in positions if p // per == r]
+        if folding % 4:
+            picked = np.ascontiguousarray(layer_shard.to_numpy().reshape(-1, folding)[mine])
+            pl.lib.check(pl.lib.ms_upload(pl.handle, ptr, picked.ctypes.data, picked.nbytes))
+        else:
+            ids = np.asarray([p * rec + k for p in mine for k in range(rec)], dtype=np.uint64)
+            pl.lib.check(pl.lib.ms_gather_digests(pl.handle, per * rec, layer_shard.ptr, ids.ctypes.data, len(ids), ptr))
+
+    def parse(chunks):
+        rows = [np.array(c).view(np.uint64).reshape(-1, folding) for c in chunks]
+        nxt = [0] * G
+        out = np.zeros((len(positions), folding), dtype=np.uint64)
+        for k, p in enumerate(positions):
+            q = p // per
+            out[k] = rows[q][nxt[q]]
+            nxt[q] += 1
+        return out
+    return batch.add(sizes, run, parse)
 
 
 def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, draws, blowup=4, folding=8, max_remainder_coeffs=64,
@@ -519,53 +588,31 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
         out["remainder_coeffs"] = rem.to_numpy()[: max(n // blowup, 1)]
         out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)
     positions = [int(p) for p in draws.positions]
-    q = {"base_trace_proof": tree_b.prove(positions), "extension_trace_proof": None, "composition_trace_proof": tree_c.prove(positions),
-         "base_trace_values": _sharded_rows(pl, comm, base_shard, GOLDILOCKS_FP, positions, rows), "extension_trace_values": None,
-         "composition_trace_values": _sharded_rows(pl, comm, comp_shard, GOLDILOCKS_FP, positions, rows)}
-    pos, openings = sorted(set(positions)), []
+    batch = OpeningBatch(pl, comm)                              # every opening of the proof: one exchange, one download
+    kq = {"base_trace_proof": tree_b.request(batch, positions), "composition_trace_proof": tree_c.request(batch, positions),
+          "base_trace_values": _rows_request(batch, base_shard, GOLDILOCKS_FP, positions, rows),
+          "composition_trace_values": _rows_request(batch, comp_shard, GOLDILOCKS_FP, positions, rows)}
+    pos, kfri, local_fri = sorted(set(positions)), [], []
     for k in range(len(draws.fri_alphas)):
         pos = fold_positions(pos, folding)
-        entry = None
         if k < len(layers) and layers[k][2]:                     # a sharded layer: rows of `folding` evaluations, owners by row block
             lay, tree, _, size = layers[k]
-            per = size // G // folding
-            rows_k = _fri_rows_sharded(pl, comm, lay, folding, pos, per)
-            proof = tree.prove(pos)
-            entry = {"positions": pos, "rows": rows_k, "proof": proof}
-        elif r == 0:
-            from .pipeline import fri_layer_rows
-            lay, tree, _, size = layers[k]
-            entry = {"positions": pos, "rows": fri_layer_rows(lay, folding, pos), "proof": tree.prove(pos)}
-        openings.append(entry)
+            kfri.append((pos, _fri_rows_request(batch, lay, folding, pos, size // G // folding), tree.request(batch, pos)))
+        else:
+            kfri.append((pos, None, None))
+            if r == 0:                                           # a layer that was collected on rank 0: the single-device gathers
+                from .pipeline import fri_layer_rows_launch
+                lay, tree, _, size = layers[k]
+                local_fri.append((k, fri_layer_rows_launch(lay, folding, pos), tree.prove_launch(pos)))
+    res = batch.execute()
+    q, openings = None, None
+    if r == 0:
+        q = {name: res[k] for name, k in kq.items()}
+        q["extension_trace_proof"] = q["extension_trace_values"] = None
+        openings = [{"positions": p, "rows": res[kr], "proof": res[kp]} if kr is not None else None for p, kr, kp in kfri]
+        for k, rows_f, proof_f in local_fri:
+            openings[k] = {"positions": kfri[k][0], "rows": rows_f(), "proof": proof_f()}
     if r == 0:
         out["queries"], out["fri_openings"] = q, openings
     lap("remainder + proof of work + openings")
-    return out
-
-
-def _fri_rows_sharded(planner, comm, layer_shard, folding, positions, per, root=0):
-    """rows `positions` of Matrix::from_arrays(evaluations.as_chunks::<N>()) (src/fri.rs:213-215) of a row-sharded layer: `per` rows of
-    `folding` evaluations on each rank -> numpy [len(positions), folding] on root.  A row is `folding` consecutive words = folding / 4
-    32-byte records of the shard, fetched with the digest gather (as pipeline.fri_layer_rows_launch does on one device)."""
-    r, G = comm.rank, comm.world
-    rec = folding // 4
-    mine = [p - r * per for p in positions if p // per == r]
-    buf = DeviceBytes(planner, max(8, len(mine) * folding * 8))
-    if mine and folding % 4:                                  # rows shorter than a 32-byte record (folding factor 2): picked on the host
-        picked = np.ascontiguousarray(layer_shard.to_numpy().reshape(-1, folding)[mine])
-        planner.lib.check(planner.lib.ms_upload(planner.handle, buf.ptr, picked.ctypes.data, picked.nbytes))
-    elif mine:
-        ids = np.asarray([p * rec + k for p in mine for k in range(rec)], dtype=np.uint64)
-        planner.lib.check(planner.lib.ms_gather_digests(planner.handle, per * rec, layer_shard.ptr, ids.ctypes.data, len(ids), buf.ptr))
-    nbytes = [sum(1 for p in positions if p // per == q) * folding * 8 for q in range(G)]
-    got = _collect(planner, comm, buf, nbytes, root)
-    if r != root:
-        return None
-    flat = got.to_numpy()[: len(positions) * folding * 8].view(np.uint64).reshape(-1, folding)
-    nxt = {q: int(sum(nbytes[:q]) // (folding * 8)) for q in range(G)}
-    out = np.zeros((len(positions), folding), dtype=np.uint64)
-    for k, p in enumerate(positions):
-        q = p // per
-        out[k] = flat[nxt[q]]
-        nxt[q] += 1
     return out
