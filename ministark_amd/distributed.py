@@ -587,6 +587,7 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
         rem = Matrix([cur.clone()]).bit_reverse_rows().into_polynomials(Radix2EvaluationDomain(n)).columns[0]
         out["remainder_coeffs"] = rem.to_numpy()[: max(n // blowup, 1)]
         out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)
+    lap("remainder + proof of work")
     positions = [int(p) for p in draws.positions]
     batch = OpeningBatch(pl, comm)                              # every opening of the proof: one exchange, one download
     kq = {"base_trace_proof": tree_b.request(batch, positions), "composition_trace_proof": tree_c.request(batch, positions),
@@ -604,7 +605,9 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
                 from .pipeline import fri_layer_rows_launch
                 lay, tree, _, size = layers[k]
                 local_fri.append((k, fri_layer_rows_launch(lay, folding, pos), tree.prove_launch(pos)))
+    lap("openings: index walks + requests")
     res = batch.execute()
+    lap("openings: gathers + exchange + download")
     q, openings = None, None
     if r == 0:
         q = {name: res[k] for name, k in kq.items()}
@@ -614,5 +617,5 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
             openings[k] = {"positions": kfri[k][0], "rows": rows_f(), "proof": proof_f()}
     if r == 0:
         out["queries"], out["fri_openings"] = q, openings
-    lap("remainder + proof of work + openings")
+    lap("openings: assembly")
     return out
