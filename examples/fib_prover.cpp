@@ -175,7 +175,8 @@ int main(int argc, char** argv) {
         const uint64_t nonce = grind_proof_of_work(pl, last_root, grinding_bits);
         std::vector<size_t> positions(num_queries);
         for (auto& p : positions) p = (size_t)(splitmix(seed) % N);
-        Queries<Fp> q(base_lde, nullptr, comp_lde, base_tree, nullptr, comp_tree, positions);
+        GatherArena arena(pl);                                // every gather of this phase lands in one buffer, downloaded once
+        Queries<Fp> q(base_lde, nullptr, comp_lde, base_tree, nullptr, comp_tree, positions, &arena);
         std::set<size_t> uniq(positions.begin(), positions.end());
         std::vector<size_t> pos(uniq.begin(), uniq.end());
         size_t opened = 0;
@@ -185,9 +186,10 @@ int main(int argc, char** argv) {
             for (size_t l = 0; l < layers.size(); l++) {
                 pos = fold_positions(pos, fold);
                 if (l == 0) pos0 = pos;
-                row_gathers.push_back(fri_layer_rows_launch(layers[l], fold, pos));
-                view_gathers.push_back(trees[l].prove_launch(pos));
+                row_gathers.push_back(fri_layer_rows_launch(layers[l], fold, pos, &arena));
+                view_gathers.push_back(trees[l].prove_launch(pos, &arena));
             }
+            q.fetch();
             for (size_t l = 0; l < layers.size(); l++) {
                 auto rows = row_gathers[l].fetch<uint64_t>();
                 auto view = view_gathers[l].fetch();

@@ -66,11 +66,11 @@ inline std::vector<size_t> fold_positions(const std::vector<size_t>& positions, 
 // rows `positions` of Matrix::from_arrays(evaluations.as_chunks::<N>()) (src/fri.rs:213-215): N consecutive evaluations each,
 // gathered on the device as 32-byte records (FriProver::into_proof, src/fri.rs:148-165)
 template <class F>
-inline Pending fri_layer_rows_launch(const GpuVec<F>& layer, unsigned folding_factor, const std::vector<size_t>& positions) {
+inline Pending fri_layer_rows_launch(const GpuVec<F>& layer, unsigned folding_factor, const std::vector<size_t>& positions, GatherArena* arena = nullptr) {
     const size_t words = (size_t)folding_factor * F::words;
     if (words % 4) throw std::invalid_argument("fri_layer_rows_launch: rows shorter than a 32-byte record");
     Planner& pl = layer.planner();
-    Pending out(pl, positions.size() * words * 8);
+    Pending out(pl, positions.size() * words * 8, arena);
     if (!out.bytes()) return out;
     const size_t per = words / 4;
     std::vector<uint64_t> ids;
@@ -91,28 +91,40 @@ inline std::vector<uint64_t> fri_layer_rows(const GpuVec<F>& layer, unsigned fol
     return fri_layer_rows_launch(layer, folding_factor, positions).template fetch<uint64_t>();
 }
 
-// Queries::new: rows of the three LDE matrices at the query positions + batched openings of the three trees
+// Queries::new: rows of the three LDE matrices at the query positions + batched openings of the three trees.  With an arena
+// the constructor only launches the gathers (into the arena) and fetch() fills the fields, so that a prover can put the
+// FRI layer openings into the same arena and download everything once.
 template <class FqT>
 struct Queries {
     std::vector<uint64_t> base_trace_values, extension_trace_values, composition_trace_values;
     MerkleTree::MerkleView base_trace_proof, extension_trace_proof, composition_trace_proof;
     Queries(const Matrix<Fp>& base_lde, const Matrix<FqT>* extension_lde, const Matrix<FqT>& composition_lde,
-            const MerkleTree& base_tree, const MerkleTree* extension_tree, const MerkleTree& composition_tree, const std::vector<size_t>& positions) {
+            const MerkleTree& base_tree, const MerkleTree* extension_tree, const MerkleTree& composition_tree, const std::vector<size_t>& positions,
+            GatherArena* arena = nullptr) : has_ext_tree_(extension_tree), has_ext_lde_(extension_lde) {
         std::vector<uint64_t> pos(positions.begin(), positions.end());
         // every gather first, then the downloads: one wait for the device instead of eight
-        auto bp = base_tree.prove_launch(positions);
-        MerkleTree::PendingView ep;
-        if (extension_tree) ep = extension_tree->prove_launch(positions);
-        auto cp = composition_tree.prove_launch(positions);
-        Pending bv = base_lde.get_rows_launch(pos), ev, cv = composition_lde.get_rows_launch(pos);
-        if (extension_lde) ev = extension_lde->get_rows_launch(pos);
-        base_trace_proof = bp.fetch();
-        if (extension_tree) extension_trace_proof = ep.fetch();
-        composition_trace_proof = cp.fetch();
-        base_trace_values = bv.template fetch<uint64_t>();
-        if (extension_lde) extension_trace_values = ev.template fetch<uint64_t>();
-        composition_trace_values = cv.template fetch<uint64_t>();
+        bp_ = base_tree.prove_launch(positions, arena);
+        if (extension_tree) ep_ = extension_tree->prove_launch(positions, arena);
+        cp_ = composition_tree.prove_launch(positions, arena);
+        bv_ = base_lde.get_rows_launch(pos, arena);
+        cv_ = composition_lde.get_rows_launch(pos, arena);
+        if (extension_lde) ev_ = extension_lde->get_rows_launch(pos, arena);
+        if (!arena) fetch();
     }
+    void fetch() {
+        if (fetched_) return;
+        fetched_ = true;
+        base_trace_proof = bp_.fetch();
+        if (has_ext_tree_) extension_trace_proof = ep_.fetch();
+        composition_trace_proof = cp_.fetch();
+        base_trace_values = bv_.template fetch<uint64_t>();
+        if (has_ext_lde_) extension_trace_values = ev_.template fetch<uint64_t>();
+        composition_trace_values = cv_.template fetch<uint64_t>();
+    }
+private:
+    MerkleTree::PendingView bp_, ep_, cp_;
+    Pending bv_, ev_, cv_;
+    bool has_ext_tree_, has_ext_lde_, fetched_ = false;
 };
 
 // PublicCoin::grind_proof_of_work(bits): the smallest nonce >= 1 with `bits` leading zero bits of SHA-256(seed || nonce_be)

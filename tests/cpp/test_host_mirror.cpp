@@ -213,6 +213,20 @@ int main() {
         REQUIRE(verify(tc.root(), q.composition_trace_proof, positions));
         auto bad = q.base_trace_proof; bad.nodes.at(0)[0] ^= 1;
         REQUIRE(!verify(tb.root(), bad, positions));
+        // the same openings through a shared arena (one download), including a gather that does not fit and falls back
+        for (size_t cap : {(size_t)1 << 20, (size_t)1024}) {
+            ms::GatherArena arena(pl, cap);
+            ms::Queries<ms::Fq3> qa(base, nullptr, comp, tb, nullptr, tc, positions, &arena);
+            REQUIRE(qa.base_trace_values.empty());                     // deferred until fetch()
+            auto extra = tb.prove_launch({3, 9}, &arena);
+            qa.fetch();
+            REQUIRE(qa.base_trace_values == q.base_trace_values && qa.composition_trace_values == q.composition_trace_values);
+            REQUIRE(qa.base_trace_proof.nodes == q.base_trace_proof.nodes && qa.base_trace_proof.initial_leaves == q.base_trace_proof.initial_leaves && qa.base_trace_proof.sibling_leaves == q.base_trace_proof.sibling_leaves);
+            REQUIRE(qa.composition_trace_proof.nodes == q.composition_trace_proof.nodes && qa.composition_trace_proof.sibling_leaves == q.composition_trace_proof.sibling_leaves);
+            REQUIRE(verify(tb.root(), extra.fetch(), {3, 9}));
+            auto late = tb.prove_launch({700}, &arena);                  // reserved after the first download: fetched incrementally
+            REQUIRE(verify(tb.root(), late.fetch(), {700}));
+        }
     }
     {   // DeepPolyComposer (src/composer.rs:43-188), Fq = Fp: the DEEP polynomial Q satisfies, at a random r,
         //   Q(r) * prod_k (r - z_k) = (a + b r) * sum_t alpha_t (P_t(r) - P_t(z_t)) * prod_{k != t} (r - z_k)
