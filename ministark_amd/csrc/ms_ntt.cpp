@@ -544,7 +544,8 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
     // over 8 columns.  Off by default: with concurrent kernels the per-kernel durations of a trace no longer add up to the
     // wall time, and the gain is under 2 %.  Never while per-launch profiling is on (its events sit on one stream).
     static const bool two_streams = getenv("MS_NTT_STREAMS") != nullptr && atoi(getenv("MS_NTT_STREAMS")) == 2;
-    const bool two = two_streams && !ctx->profiling && ncols >= 2 && group >= 2 && p->log_n >= 20;
+    static const unsigned two_min_log = getenv("MS_NTT_STREAMS_MIN_LOG") ? (unsigned)atoi(getenv("MS_NTT_STREAMS_MIN_LOG")) : 20u;
+    const bool two = two_streams && !ctx->profiling && ncols >= 2 && group >= 2 && p->log_n >= two_min_log;
     if (two) {
         if (!ctx->stream2) {
             HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));

@@ -34,7 +34,7 @@
 
 namespace msntt {
 
-static constexpr int MAXC = 64;        // columns per launch (grid.y): small columns need many per launch to fill 2048 workgroup slots
+static constexpr int MAXC = 128;       // columns per launch (grid.y): small columns need many per launch to fill 2048 workgroup slots
 static constexpr int TILE = 4096;      // words per workgroup tile
 static constexpr int NT = 256;         // threads per workgroup
 static constexpr int LDS_PAD_CS = 144; // c-stride (words) of the mid-pass exchange layout (half tile + 16)

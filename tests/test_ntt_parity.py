@@ -544,3 +544,14 @@ def test_plan_outlives_its_context_safely(kind):
     assert lib.ms_ntt_execute(raw2) != 0                  # an error, reported
     assert lib.ms_ntt_plan_destroy(raw) == 0 and lib.ms_ntt_plan_destroy(raw2) == 0      # no-ops
     f.handle = None; f2.handle = None
+
+
+# A batch larger than one launch holds (msntt::MAXC = 128 columns per launch): the groups must tile the batch exactly.
+def test_batch_wider_than_a_launch_emu():
+    _run("emu", GOLDILOCKS_FP, 12, False, 7, ncols=131)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,inverse,ncols", [(10, False, 260), (12, False, 131), (14, True, 129), (16, False, 130)])
+def test_batch_wider_than_a_launch_hip(log_n, inverse, ncols):
+    _run("hip", GOLDILOCKS_FP, log_n, inverse, 7, ncols=ncols)
