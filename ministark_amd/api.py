@@ -171,9 +171,12 @@ class DeviceBytes:
         planner.lib.check(planner.lib.ms_alloc(planner.handle, max(nbytes, 32), ctypes.byref(p)))
         self.ptr = p.value
 
-    def to_numpy(self):
-        out = np.empty(self.nbytes, dtype=np.uint8)
-        self.planner.lib.check(self.planner.lib.ms_download(self.planner.handle, out.ctypes.data, self.ptr, self.nbytes))
+    def to_numpy(self, nbytes=None):
+        """the first `nbytes` bytes (default: all) on the host"""
+        nbytes = self.nbytes if nbytes is None else nbytes
+        out = np.empty(nbytes, dtype=np.uint8)
+        if nbytes:
+            self.planner.lib.check(self.planner.lib.ms_download(self.planner.handle, out.ctypes.data, self.ptr, nbytes))
         return out
 
     def __del__(self):
@@ -204,10 +207,14 @@ class GatherBatch:
         self.used += nbytes
 
         def read():
-            if self._host is None:
-                self._host = self.buf.to_numpy()
-            return self._host[off:off + nbytes]
+            return self.fetch()[off:off + nbytes]
         return self.buf.ptr + off, read
+
+    def fetch(self):
+        """the used part of the buffer on the host: ONE wait and one copy of `used` bytes (not of the capacity); closes the batch"""
+        if self._host is None:
+            self._host = self.buf.to_numpy(self.used)
+        return self._host
 
 
 def _gather_slot(planner, nbytes, batch):
@@ -223,16 +230,15 @@ def _gather_digests_launch(planner, digests, ndigests, ids, batch=None):
     """Launch the gather of the 32-byte records `ids` of a device digest array; returns a function that downloads them as a
     list of bytes.  (Launch every gather of an opening first, fetch afterwards: one wait instead of one per call; with a
     GatherBatch one download for the whole phase.)"""
-    if not ids:
+    if len(ids) == 0:
         return lambda: []
-    idx = np.asarray(ids, dtype=np.uint64)
+    idx = np.ascontiguousarray(ids, dtype=np.uint64)
     ptr, read, keep = _gather_slot(planner, 32 * len(ids), batch)
     L = planner.lib
     L.check(L.ms_gather_digests(planner.handle, ndigests, digests.ptr, idx.ctypes.data, len(ids), ptr))
 
     def fetch(_keep=keep):
-        raw = read().tobytes()
-        return [raw[32 * k:32 * k + 32] for k in range(len(ids))]
+        return np.ascontiguousarray(read()[: 32 * len(ids)]).view("V32").tolist()      # a list of 32-byte `bytes`, built in one C loop
     return fetch
 
 
@@ -251,18 +257,23 @@ def merkle_view_ids(n, indices, lib=None):
     interpreter -- eight trees per proof); without it, the same two queues in Python (`merkle_view_ids_py`, the comparison in the tests)."""
     if lib is None:
         return merkle_view_ids_py(n, indices)
-    idx = np.asarray([int(i) for i in indices], dtype=np.uint64)
-    for i in idx:
-        if i >= n:
-            raise IndexError(f"leaf index {int(i)} out of bounds ({n})")         # Error::LeafIndexOutOfBounds
-    leaf = np.empty(2 * max(1, idx.size), dtype=np.uint64)
-    sib = np.empty(2 * max(1, idx.size), dtype=np.uint8)
-    node = np.empty(max(1, idx.size) * max(1, n.bit_length()), dtype=np.uint64)
+    leaf, initial, sibling, node = _merkle_view_ids_arrays(n, indices, lib)
+    return leaf.tolist(), initial.tolist(), sibling.tolist(), node.tolist()
+
+
+def _merkle_view_ids_arrays(n, indices, lib):
+    """merkle_view_ids through the library, as numpy arrays (what the gathers take: no list round trip)"""
+    idx = np.asarray(indices, dtype=np.uint64)
+    if idx.size and int(idx.max()) >= n:
+        raise IndexError(f"leaf index {int(idx.max())} out of bounds ({n})")     # Error::LeafIndexOutOfBounds
+    m = max(1, idx.size)
+    leaf = np.empty(2 * m, dtype=np.uint64)
+    sib = np.empty(2 * m, dtype=np.uint8)
+    node = np.empty(m * max(1, n.bit_length()), dtype=np.uint64)
     nl, nn = ctypes.c_size_t(0), ctypes.c_size_t(0)
     lib.check(lib.ms_merkle_view_ids(n, idx.ctypes.data, idx.size, leaf.ctypes.data, sib.ctypes.data, ctypes.byref(nl), node.ctypes.data, ctypes.byref(nn)))
     flags = sib[: nl.value]
-    pos = np.arange(nl.value)
-    return leaf[: nl.value].tolist(), pos[flags == 0].tolist(), pos[flags == 1].tolist(), node[: nn.value].tolist()
+    return leaf[: nl.value], np.flatnonzero(flags == 0), np.flatnonzero(flags), node[: nn.value]
 
 
 def merkle_view_ids_py(n, indices):
@@ -347,13 +358,14 @@ class MerkleTree:
     def prove_launch(self, indices, batch=None):
         """`prove` in two halves: the device gathers are launched now, the returned function fetches and assembles the view."""
         n = self.nleaves
-        leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices, self.planner.lib)
+        leaf_ids, initial, sibling, node_ids = _merkle_view_ids_arrays(n, [int(i) for i in indices], self.planner.lib)
+        initial, sibling = initial.tolist(), sibling.tolist()
         fetch_leaves = _gather_digests_launch(self.planner, self.leaves, n, leaf_ids, batch)
         fetch_nodes = _gather_digests_launch(self.planner, self.nodes, n, node_ids, batch)
 
         def fetch():
             leaves, nodes = fetch_leaves(), fetch_nodes()
-            return {"nodes": [nodes[k] for k in range(len(node_ids))],
+            return {"nodes": nodes,
                     "initial_leaves": [leaves[k] for k in initial],
                     "sibling_leaves": [leaves[k] for k in sibling],
                     "height": n.bit_length() - 1}

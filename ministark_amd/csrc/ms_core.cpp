@@ -151,26 +151,55 @@ int pool_free(ms_ctx* ctx, void* d_ptr) {
     HIPCHK(hipFree(d_ptr));
     return MS_OK;
 }
-int stage_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
-    static constexpr size_t RING = (size_t)1 << 20;
-    if (!bytes) return MS_OK;
-    if (!ctx->stage) {
-        void* p = nullptr;
-        if (hipHostMalloc(&p, RING, 0) == hipSuccess) { ctx->stage = (char*)p; ctx->stage_bytes = RING; } else (void)hipGetLastError();
+static constexpr size_t STAGE_RING = (size_t)1 << 20;
+static void stage_init(ms_ctx* ctx) {
+    if (ctx->stage) return;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, STAGE_RING, 0) == hipSuccess) { ctx->stage = (char*)p; ctx->stage_bytes = STAGE_RING; } else (void)hipGetLastError();
+}
+// a slot of the ring for `need` bytes; on wrap everything that still reads the ring (copies, kernels) has to be done first
+static int stage_slot(ms_ctx* ctx, size_t need, char** slot) {
+    if (ctx->stage_off + need > ctx->stage_bytes) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->stage_off = 0;
     }
+    *slot = ctx->stage + ctx->stage_off;
+    ctx->stage_off += need;
+    return MS_OK;
+}
+int stage_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!bytes) return MS_OK;
+    stage_init(ctx);
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (!ctx->stage || need > ctx->stage_bytes / 2) {            // large or no pinned memory: pageable copy, wait for it
         HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         return MS_OK;
     }
-    if (ctx->stage_off + need > ctx->stage_bytes) {              // wrap: every copy out of the ring has to be done first
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        ctx->stage_off = 0;
+    char* slot = nullptr;
+    MSCHK(stage_slot(ctx, need, &slot));
+    memcpy(slot, h_src, bytes);
+    HIPCHK(hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MS_OK;
+}
+// Small index lists (query positions, digest indices): the kernel reads them where they are -- pinned host memory is mapped into
+// the device's address space -- so the call costs no copy command at all (a hipMemcpyAsync is 6-10 us of host time, more than the
+// gather kernel it feeds; twenty of them per proof).  *d_view is valid for kernels enqueued on the context's stream before the
+// ring wraps (stage_slot waits for the stream then).  Falls back to a pooled device copy for lists that do not fit.
+int stage_view(ms_ctx* ctx, const void* h_src, size_t bytes, const void** d_view, LockedPoolGuard& pooled) {
+    stage_init(ctx);
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (!ctx->stage || need > ctx->stage_bytes / 8) {
+        void* d = nullptr;
+        MSCHK(pooled.alloc(bytes, &d));
+        MSCHK(stage_upload(ctx, d, h_src, bytes));
+        *d_view = d;
+        return MS_OK;
     }
-    memcpy(ctx->stage + ctx->stage_off, h_src, bytes);
-    HIPCHK(hipMemcpyAsync(d_dst, ctx->stage + ctx->stage_off, bytes, hipMemcpyHostToDevice, ctx->stream));
-    ctx->stage_off += need;
+    char* slot = nullptr;
+    MSCHK(stage_slot(ctx, need, &slot));
+    memcpy(slot, h_src, bytes);
+    *d_view = slot;
     return MS_OK;
 }
 extern "C" int ms_alloc(ms_ctx* ctx, size_t bytes, void** d_ptr) {

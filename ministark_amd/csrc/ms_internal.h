@@ -113,6 +113,8 @@ struct LockedPoolGuard {
     LockedPoolGuard(const LockedPoolGuard&) = delete; LockedPoolGuard& operator=(const LockedPoolGuard&) = delete;
 };
 
+int stage_view(ms_ctx* ctx, const void* h_src, size_t bytes, const void** d_view, LockedPoolGuard& pooled);   // the caller holds ctx->mu
+
 struct ms_ntt_plan {
     ms_ctx* ctx = nullptr;
     // ms_ntt_plan_create hands out a HANDLE: a copy of the context's cached plan for (field, size, direction, offset)

@@ -342,10 +342,9 @@ extern "C" int ms_gather_rows(ms_ctx* ctx, int field, size_t nrows, const void* 
     if (npos == 0) return MS_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    void* d_pos = nullptr;
+    const void* d_pos = nullptr;
     LockedPoolGuard pooled(ctx);
-    MSCHK(pooled.alloc(npos * 8, &d_pos));
-    MSCHK(stage_upload(ctx, d_pos, h_positions, npos * 8));
+    MSCHK(stage_view(ctx, h_positions, npos * 8, &d_pos, pooled));
     msscan::GatherRowsParams P;
     memset(&P, 0, sizeof P);
     for (unsigned c = 0; c < ncols; c++) { if (!d_cols[c]) return fail(MS_ERR_INVALID, "null column %u", c); P.cols[c] = (const uint64_t*)d_cols[c]; }
@@ -390,10 +389,9 @@ extern "C" int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_dig
     if (count == 0) return MS_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    void* d_idx = nullptr;
+    const void* d_idx = nullptr;
     LockedPoolGuard pooled(ctx);
-    MSCHK(pooled.alloc(count * 8, &d_idx));
-    MSCHK(stage_upload(ctx, d_idx, h_indices, count * 8));
+    MSCHK(stage_view(ctx, h_indices, count * 8, &d_idx, pooled));
     { ProfScope ps(ctx, "gather_digests", 64.0 * count);
       hipLaunchKernelGGL(msscan::gather_records, dim3(stream_grid(count * 4)), dim3(msscan::NT), 0, ctx->stream,
                          (const uint64_t*)d_digests, (const uint64_t*)d_idx, (uint64_t*)d_out, count, 4u); }

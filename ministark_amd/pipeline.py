@@ -179,7 +179,7 @@ def fri_layer_rows_launch(layer, folding_factor, positions, batch=None):
     if words % 4:
         return lambda: layer.to_numpy().reshape(-1, words)[positions]      # rows shorter than a 32-byte record: tiny layers only
     per = words // 4
-    ids = np.array([p * per + k for p in positions for k in range(per)], dtype=np.uint64)
+    ids = (np.asarray(positions, dtype=np.uint64)[:, None] * np.uint64(per) + np.arange(per, dtype=np.uint64)).ravel()
     from .api import _gather_slot
     ptr, read, keep = _gather_slot(pl, 32 * len(ids), batch)
     pl.lib.check(pl.lib.ms_gather_digests(pl.handle, len(layer) * FIELD_WORDS[layer.field] // 4, layer.ptr, ids.ctypes.data, len(ids), ptr))
@@ -280,17 +280,32 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
     rem = Matrix([cur.clone()]).bit_reverse_rows().into_polynomials(Radix2EvaluationDomain(n)).columns[0]
     out["remainder_coeffs"] = rem.to_numpy()[: max(n // blowup, 1)]
     lap("FRI layers (commit + fold) + remainder")
+    fine, tf = {}, time.perf_counter()
+
+    def sub(name):                                                             # host-side split of the last phase (no synchronisation)
+        nonlocal tf
+        now = time.perf_counter()
+        fine[name] = round((now - tf) * 1e3, 3)
+        tf = now
+
     out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)   # prover.rs:160
+    sub("proof of work")
     from .api import GatherBatch
     batch = GatherBatch(pl)                                                    # every gather of the phase into one buffer: ONE download
     queries = Queries(lde_t, None, comp_lde, tree_t, None, tree_c, draws.positions, batch)                # prover.rs:163-173
+    sub("trace openings: index walks + gather launches")
     # fri_prover.into_proof(&query_positions) (prover.rs:161, fri.rs:148-165): per layer the folded positions' rows and Merkle view
     pos, launched = sorted(set(int(p) for p in draws.positions)), []
     for layer, tree in zip(fri_layers, fri_trees):                            # all gathers first, then the download
         pos = fold_positions(pos, folding)
         launched.append((pos, fri_layer_rows_launch(layer, folding, pos, batch), tree.prove_launch(pos, batch)))
+    sub("FRI openings: index walks + gather launches")
+    batch.fetch()
+    sub("wait + download")
     out["queries"] = queries.fetch()
     out["fri_openings"] = [{"positions": p, "rows": rows(), "proof": proof()} for p, rows, proof in launched]
+    sub("assembly")
+    out["openings_ms"] = fine
     lap("proof of work + queries")
     out["phases_ms"] = {k: round(v, 3) for k, v in phase.items()}
     if keep:
