@@ -28,7 +28,7 @@ import ctypes
 
 import numpy as np
 
-from .api import FIELD_WORDS, GOLDILOCKS_FP, GL_GENERATOR, DeviceBytes, GpuVec, Matrix, MerkleTree, _ptr_array, merkle_view_ids
+from .api import FIELD_WORDS, GOLDILOCKS_FP, GL_GENERATOR, DeviceBytes, GpuVec, Matrix, MerkleTree, _ptr_array, _merkle_view_ids_arrays
 
 COMM_ID_BYTES = 128
 
@@ -348,45 +348,40 @@ class ShardedTree:
         """registers this tree's view of `indices` with an OpeningBatch; -> the request's index in the batch's results"""
         pl, G, r = self.planner, self.comm.world, self.comm.rank
         n, per = self.nleaves, self.local.nleaves
-        leaf_ids, initial, sibling, node_ids = merkle_view_ids(n, indices, pl.lib)
-        # where each digest lives: (owner, "leaf" | "node" | "top", local id)
-        where = [(i // per, "leaf", i % per) for i in leaf_ids]
-        for k in node_ids:
-            lvl = 1 << (k.bit_length() - 1)
-            if lvl < G:
-                where.append((batch.root, "top", k))
-            else:
-                j, per_lvl = k - lvl, lvl // G
-                where.append((j // per_lvl, "node", per_lvl + j % per_lvl))
-        kinds = ("leaf", "node", "top")
-        count = {(q, kind): sum(1 for owner, k, _ in where if owner == q and k == kind) for q in range(G) for kind in kinds}
-        sizes = [32 * sum(count[(q, kind)] for kind in kinds) for q in range(G)]
-        srcs = {"leaf": (self.local.leaves, per), "node": (self.local.nodes, per), "top": (self.top.nodes if self.top else None, G)}
+        leaf_ids, initial, sibling, node_ids = _merkle_view_ids_arrays(n, [int(i) for i in indices], pl.lib)
+        leaf_ids, node_ids = leaf_ids.astype(np.int64), node_ids.astype(np.int64)
+        nl = len(leaf_ids)
+        # where each digest lives: owner rank, kind (0 = leaf of the owner's subtree, 1 = node of it, 2 = replicated top level), local id
+        lvl = np.int64(1) << (np.frexp(node_ids.astype(np.float64))[1].astype(np.int64) - 1)        # the level's first node (ids < 2^53: exact)
+        top = lvl < G
+        per_lvl = np.maximum(lvl // G, 1)
+        j = node_ids - lvl
+        owner = np.concatenate([leaf_ids // per, np.where(top, batch.root, j // per_lvl)])
+        kind = np.concatenate([np.zeros(nl, dtype=np.int64), np.where(top, 2, 1)])
+        local = np.concatenate([leaf_ids % per, np.where(top, node_ids, per_lvl + j % per_lvl)]).astype(np.uint64)
+        # a rank's contribution: its leaves, then its nodes, then (on `root`) the top levels, each in the order of the walk
+        key = owner * 3 + kind
+        order = np.argsort(key, kind="stable")
+        count = np.bincount(key, minlength=3 * G).reshape(G, 3)
+        sizes = (32 * count.sum(axis=1)).tolist()
+        srcs = ((self.local.leaves, per), (self.local.nodes, per), (self.top.nodes if self.top else None, G))
 
-        def run(ptr):                                        # this rank's digests: leaves, then nodes, then top levels, each in id order
+        def run(ptr):
             off = 0
-            for kind in kinds:
-                ids = [i for owner, k, i in where if owner == r and k == kind]
-                if ids:
-                    idx = np.asarray(ids, dtype=np.uint64)
-                    src, cnt = srcs[kind]
-                    pl.lib.check(pl.lib.ms_gather_digests(pl.handle, cnt, src.ptr, idx.ctypes.data, len(ids), ptr + off))
+            for k in range(3):
+                ids = np.ascontiguousarray(local[key == 3 * r + k])
+                if len(ids):
+                    src, cnt = srcs[k]
+                    pl.lib.check(pl.lib.ms_gather_digests(pl.handle, cnt, src.ptr, ids.ctypes.data, len(ids), ptr + off))
                     off += 32 * len(ids)
 
         def parse(chunks):
-            cursor = {}
-            for q in range(G):
-                base = 0
-                for kind in kinds:
-                    cursor[(q, kind)] = base
-                    base += 32 * count[(q, kind)]
-            digests = []
-            for owner, kind, _ in where:
-                o = cursor[(owner, kind)]
-                digests.append(chunks[owner][o:o + 32].tobytes())
-                cursor[(owner, kind)] = o + 32
-            leaves, nodes = digests[: len(leaf_ids)], digests[len(leaf_ids):]
-            return {"nodes": nodes, "initial_leaves": [leaves[k] for k in initial], "sibling_leaves": [leaves[k] for k in sibling],
+            got = np.concatenate([np.asarray(c, dtype=np.uint8) for c in chunks]).reshape(-1, 32)      # (owner, kind, walk) order = `order`
+            digests = np.empty_like(got)
+            digests[order] = got
+            digests = digests.view("V32").ravel().tolist()                                              # 32-byte `bytes`, one C loop
+            leaves, nodes = digests[:nl], digests[nl:]
+            return {"nodes": nodes, "initial_leaves": [leaves[k] for k in initial.tolist()], "sibling_leaves": [leaves[k] for k in sibling.tolist()],
                     "height": n.bit_length() - 1}
         return batch.add(sizes, run, parse)
 
