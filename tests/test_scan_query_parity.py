@@ -185,3 +185,28 @@ def test_running_evaluation_252(kind):
 def test_long_column_rows_per_lane_emu():
     # columns of >= 2^20 rows take 16 rows per lane (4 below): both instantiations must agree with the loop
     _scan_case("emu", (1 << 20) + 5, False, True, False, False, seed=5, mask_every=7)
+
+
+# The gathers read their index lists from the library's pinned staging ring (1 MiB): enough launches to wrap it several times without
+# any download in between, then a list too long for a ring slot (pooled device copy instead), every result checked.
+@pytest.mark.parametrize("kind", KINDS)
+def test_index_lists_outlive_the_staging_ring(kind):
+    from ministark_amd.api import GatherBatch
+    pl = backends.planner(kind)
+    n, ncols = 1 << 12, 3
+    cols = [cref.random_elements(n, 900 + c) for c in range(ncols)]
+    m = Matrix([GpuVec.from_numpy(pl, c, FP) for c in cols])
+    rng = np.random.default_rng(5)
+    batch = GatherBatch(pl, capacity=8 << 20)
+    pending = []
+    for _ in range(700):                                 # 700 lists of 256 positions = 1.4 MiB of indices, 4.2 MiB of rows
+        pos = rng.integers(0, n, size=256).tolist()
+        pending.append((pos, m.get_rows_launch(pos, batch)))
+    for pos, fetch in pending:
+        got = np.asarray(fetch()).reshape(len(pos), ncols)
+        for c in range(ncols):
+            assert np.array_equal(got[:, c], cols[c][pos])
+    long_pos = rng.integers(0, n, size=40000).tolist()   # 320 KB of indices: more than a slot of the ring
+    got = np.asarray(m.get_rows(long_pos)).reshape(len(long_pos), ncols)
+    for c in range(ncols):
+        assert np.array_equal(got[:, c], cols[c][long_pos])
