@@ -184,7 +184,7 @@ def bench_c2_sweep(pl):
     from ministark_amd import GOLDILOCKS_FP, GpuFft, GpuIfft, GpuVec, Radix2EvaluationDomain
     rng = np.random.default_rng(5)
     out = {"workload": "configs[1] sweep: forward / inverse coset NTT (offset 7), Fp, in place, per column", "peak_GBps": HBM_PEAK_GBS, "sizes": {}}
-    for log_n, ncol in ((17, 64), (18, 64), (19, 64), (20, 32), (21, 32), (22, 16), (23, 16), (24, 8)):
+    for log_n, ncol in ((14, 256), (15, 256), (16, 128), (17, 64), (18, 64), (19, 64), (20, 32), (21, 32), (22, 16), (23, 16), (24, 8)):
         n = 1 << log_n
         cols = [GpuVec.from_numpy(pl, rng.integers(0, P_GOLDILOCKS, size=n, dtype=np.uint64), GOLDILOCKS_FP) for _ in range(ncol)]
         row = {"columns": ncol}

@@ -59,13 +59,16 @@ extern "C" int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leave
         uint8_t* dst = nodes + count * 32;
         if (count <= (size_t)mssha::NT) {                        // the remaining levels in one launch
             ProfScope ps(ctx, "sha256_merkle_top", 96.0 * (2 * count - 1));
-            hipLaunchKernelGGL(mssha::sha256_merkle_top, dim3(1), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
+            hipLaunchKernelGGL(mssha::sha256_merkle_top<1>, dim3(1), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
             break;
         }
         if (count <= ((size_t)1 << 17)) {                        // log2(NT) + 1 levels at once: count / NT subtrees, one workgroup each
-            ProfScope ps(ctx, "sha256_merkle_top", 96.0 * (2 * count - count / mssha::NT));
-            hipLaunchKernelGGL(mssha::sha256_merkle_top, dim3((unsigned)(count / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
-            const size_t last = count / mssha::NT;               // the level the subtrees end in
+            // more subtrees than CUs: two parents per lane, so that every wave keeps a SIMD to itself (sha256_kernels.h)
+            const unsigned per = count / mssha::NT > 256 && count % (2 * mssha::NT) == 0 ? 2u : 1u;
+            ProfScope ps(ctx, "sha256_merkle_top", 96.0 * (2 * count - count / (per * mssha::NT)));
+            if (per == 2) hipLaunchKernelGGL(mssha::sha256_merkle_top<2>, dim3((unsigned)(count / (2 * mssha::NT))), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
+            else hipLaunchKernelGGL(mssha::sha256_merkle_top<1>, dim3((unsigned)(count / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
+            const size_t last = count / (per * mssha::NT);       // the level the subtrees end in
             src = nodes + last * 32;
             count = last / 2;
             continue;

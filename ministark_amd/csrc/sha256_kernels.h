@@ -225,15 +225,19 @@ static __global__ void __launch_bounds__(NT) sha256_merge_level(const uint8_t* _
 // [b NT, b NT + NT) of a level of `count` parents (count = NT: the top of the tree, one workgroup; count = k NT: k subtrees at once),
 // keeps the current level in LDS and climbs log2(NT) more levels to ONE node; every level is also written to its slot of nodes[]
 // (level of c nodes at nodes[c ..]).  `src` holds 2 * count digests.  count < NT: a single workgroup, the tree's last levels.
+// PER = 2 (the widest of these levels, 2^17 parents: 256 workgroups instead of 512): a lane computes TWO adjacent parents and their parent
+// without leaving its registers.  With 512 workgroups every SIMD hosts two waves for all nine levels -- a wave with one live lane still
+// takes its issue slots -- and a level costs 8.4 us instead of the 5.2 us of a wave that has its SIMD to itself (scripts/merkle_top_probe.py).
+template <int PER>
 static __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __restrict__ src, uint8_t* __restrict__ nodes, unsigned count) {
     __shared__ uint32_t lvl[2][NT * 8];
     const unsigned t = threadIdx.x, b = blockIdx.x;
     unsigned mine = count < (unsigned)NT ? count : (unsigned)NT;          // nodes of the current level this workgroup computes
     size_t level = count;                                                 // nodes of the current level in the whole tree
     Sha s;
-    if (t < mine) {
+    auto first = [&](size_t node) {                                       // parent `node` of the level of `count` parents, from src, written to its slot
         s.init();
-        const uint4* in = (const uint4*)(src + ((size_t)b * NT + t) * 64);
+        const uint4* in = (const uint4*)(src + node * 64);
         #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint4 v = in[q];
@@ -241,13 +245,30 @@ static __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __
         }
         s.compress();
         s.compress_pad64();
-    }
+    };
+    auto put = [&](size_t slot) {
+        uint4* out = (uint4*)(nodes + slot * 32);
+        out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
+        out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
+    };
+    if constexpr (PER == 2) {                                            // count is a multiple of 2 NT here
+        const size_t n0 = (size_t)b * 2 * NT + 2 * t;
+        first(n0); put(level + n0);
+        uint32_t left[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) left[q] = s.h[q];
+        first(n0 + 1); put(level + n0 + 1);
+        #pragma unroll
+        for (int q = 0; q < 8; q++) { s.w[8 + q] = s.h[q]; s.w[q] = left[q]; }
+        level >>= 1;
+        s.init();
+        s.compress();
+        s.compress_pad64();
+    } else if (t < mine) first((size_t)b * NT + t);
     int cur = 0;
     for (;;) {
         if (t < mine) {
-            uint4* out = (uint4*)(nodes + (level + (size_t)b * mine + t) * 32);
-            out[0] = make_uint4(bswap32(s.h[0]), bswap32(s.h[1]), bswap32(s.h[2]), bswap32(s.h[3]));
-            out[1] = make_uint4(bswap32(s.h[4]), bswap32(s.h[5]), bswap32(s.h[6]), bswap32(s.h[7]));
+            put(level + (size_t)b * mine + t);
             #pragma unroll
             for (int q = 0; q < 8; q++) lvl[cur][t * 8 + q] = s.h[q];         // big-endian words, ready for the next schedule
         }

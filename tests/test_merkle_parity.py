@@ -69,6 +69,13 @@ def test_commit_2_20_x_32_hip():
     _commit("hip", GOLDILOCKS_FP, 20, 32)
 
 
+# every shape of the upper levels (sha256_merkle_top): one workgroup only (<= 2^9 leaves), subtrees of 256 parents on <= 256
+# workgroups (2^10 .. 2^17 leaves), two parents per lane at 2^17 parents (2^18 leaves and more), all nodes compared
+@pytest.mark.parametrize("kind,log_rows", [("emu", 18)] + [pytest.param("hip", d, marks=pytest.mark.gpu) for d in (9, 10, 13, 18, 19, 21)])
+def test_upper_levels_of_tall_trees(kind, log_rows):
+    _commit(kind, GOLDILOCKS_FP, log_rows, 1)
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("field,ff", [(GOLDILOCKS_FP, 2), (GOLDILOCKS_FP, 8), (GOLDILOCKS_FQ3, 4), (GOLDILOCKS_FQ3, 16)])
 def test_fri_layer_commit_row_major(kind, field, ff):       # src/fri.rs:213-216
