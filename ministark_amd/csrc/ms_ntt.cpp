@@ -543,6 +543,7 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
     // alternates between a memory phase and an arithmetic phase per workgroup); measured 162 -> 159 us per 2^24 column
     // over 8 columns.  Off by default: with concurrent kernels the per-kernel durations of a trace no longer add up to the
     // wall time, and the gain is under 2 %.  Never while per-launch profiling is on (its events sit on one stream).
+    // Columns below 2^20 points lose with it (round 4, MS_NTT_STREAMS_MIN_LOG=12: 2^16 x 128 0.67 -> 0.88 us per column, 2^17 x 64 1.40 -> 1.60).
     static const bool two_streams = getenv("MS_NTT_STREAMS") != nullptr && atoi(getenv("MS_NTT_STREAMS")) == 2;
     static const unsigned two_min_log = getenv("MS_NTT_STREAMS_MIN_LOG") ? (unsigned)atoi(getenv("MS_NTT_STREAMS_MIN_LOG")) : 20u;
     const bool two = two_streams && !ctx->profiling && ncols >= 2 && group >= 2 && p->log_n >= two_min_log;
