@@ -154,6 +154,25 @@ class _stdout_to_stderr:
         os.close(self.saved)
 
 
+_LINE_OUT = None
+
+
+def _claim_stdout():
+    """From here on file descriptor 1 IS stderr for everything in this process -- torch's own RCCL prints the same banner at its
+    first collective, C stdio flushes at exit -- and the one JSON line goes out through a private duplicate of the real stdout."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    out = _LINE_OUT if _LINE_OUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def _profiled(pl, fn, reps, after_wall=None):
     """-> (wall seconds per call, {kernel: microseconds per call}).  The wall clock is taken WITHOUT the per-launch
     hipEvents (a pair per kernel, ~150 launches per prover run, costs 15-20 % of the wall time); the kernel times come
@@ -470,6 +489,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(_spawn_ranks(args.gpus))
+    _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -549,11 +569,11 @@ def main():
     if args.mode == "lde-commit":
         r = run_sharded()
         if rank == 0:
-            print(json.dumps({"metric": "column-sharded LDE + commitment (configs[4]), algorithmic GB/s of the LDE phase", "value": r["lde_GBps"],
+            _emit({"metric": "column-sharded LDE + commitment (configs[4]), algorithmic GB/s of the LDE phase", "value": r["lde_GBps"],
                               "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["total_ms"],
                               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                               "config": {"workload": r["workload"], "parallelism": f"columns x{world}, rows x{world} after the exchange"},
-                              "sharded_lde_commit": r}), flush=True)
+                              "sharded_lde_commit": r})
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -603,7 +623,7 @@ def main():
         def bail():
             if rank == 0 and state["line"] is not None:
                 state["line"]["sharded_lde_commit"] = {"error": "timed out after 180 s (collective did not complete)", "n_gpus": world}
-                print(json.dumps(state["line"]), flush=True)
+                _emit(state["line"])
             os._exit(0 if state["line"] is not None or rank != 0 else 1)
         timer = threading.Timer(180.0, bail)
         timer.daemon = True
@@ -718,7 +738,7 @@ def main():
         out["cpu_baseline"] = {"value": round(alg_bytes_col / best / 1e9, 3), "unit": "GB/s", "cores": cref.num_threads(),
                                "kind": "port", "ms_per_transform": round(best * 1e3, 2),
                                "sample": f"{reps} x one 2^{log_n} column, forward coset NTT, oracle/c (C/OpenMP restatement, not the reference binary)"}
-    print(json.dumps(out), flush=True)
+    _emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
