@@ -76,6 +76,7 @@ extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->land) (void)hipHostFree(ctx->land);
     for (auto m : ctx->jit_modules) (void)hipModuleUnload(m);
     if (ctx->stream2) { (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     (void)hipStreamDestroy(ctx->stream);
@@ -227,6 +228,20 @@ extern "C" int ms_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t byt
 }
 extern "C" int ms_download(ms_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    static constexpr size_t LAND = (size_t)256 << 10;
+    if (bytes && bytes <= LAND) {                                 // small: through the pinned landing buffer
+        std::lock_guard<std::mutex> lk(ctx->land_mu);
+        if (!ctx->land) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, LAND, 0) == hipSuccess) ctx->land = (char*)p; else (void)hipGetLastError();
+        }
+        if (ctx->land) {
+            HIPCHK(hipMemcpyAsync(ctx->land, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            memcpy(h_dst, ctx->land, bytes);
+            return MS_OK;
+        }
+    }
     HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MS_OK;

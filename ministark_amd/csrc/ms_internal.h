@@ -60,6 +60,10 @@ struct ms_ctx {
     // device is then truly asynchronous and the call does not drain the stream (stage_upload)
     char* stage = nullptr;
     size_t stage_bytes = 0, stage_off = 0;
+    // pinned landing buffer of the small downloads (roots, out-of-domain values, the gathers of an opening): a copy into pinned memory
+    // + memcpy is 12 us where the same copy into the caller's pageable buffer is 20 us (scripts/download_latency.hip)
+    char* land = nullptr;
+    std::mutex land_mu;
     void* comm = nullptr;                    // ncclComm_t once ms_comm_init has run
     int comm_rank = 0, comm_size = 1;
     void* prog_buf = nullptr;                // device copy of the current constraint program + constants
