@@ -64,7 +64,9 @@ extern "C" int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leave
         }
         if (count <= ((size_t)1 << 17)) {                        // log2(NT) + 1 levels at once: count / NT subtrees, one workgroup each
             // more subtrees than CUs: two parents per lane, so that every wave keeps a SIMD to itself (sha256_kernels.h)
-            const unsigned per = count / mssha::NT > 256 && count % (2 * mssha::NT) == 0 ? 2u : 1u;
+            // Measured per tree (scripts/merkle_top_probe.py, same box): 2^18 leaves 123 -> 105 us, 2^21 120 -> 108; 2^23 / 2^24 leaves 116 -> 119
+            // (after the long level launches of a big tree the 512-workgroup form is the faster one), hence the bound on the tree's size.
+            const unsigned per = nleaves <= ((size_t)1 << 21) && count / mssha::NT > 256 && count % (2 * mssha::NT) == 0 ? 2u : 1u;
             ProfScope ps(ctx, "sha256_merkle_top", 96.0 * (2 * count - count / (per * mssha::NT)));
             if (per == 2) hipLaunchKernelGGL(mssha::sha256_merkle_top<2>, dim3((unsigned)(count / (2 * mssha::NT))), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);
             else hipLaunchKernelGGL(mssha::sha256_merkle_top<1>, dim3((unsigned)(count / mssha::NT)), dim3(mssha::NT), 0, ctx->stream, src, nodes, (unsigned)count);

@@ -253,11 +253,22 @@ static __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __
     };
     if constexpr (PER == 2) {                                            // count is a multiple of 2 NT here
         const size_t n0 = (size_t)b * 2 * NT + 2 * t;
+        uint4 second[4];                                                  // both messages are requested before the first compression:
+        const uint4* in2 = (const uint4*)(src + (n0 + 1) * 64);          // the level below was written by another launch, its lines come from memory
+        #pragma unroll
+        for (int q = 0; q < 4; q++) second[q] = in2[q];
         first(n0); put(level + n0);
         uint32_t left[8];
         #pragma unroll
         for (int q = 0; q < 8; q++) left[q] = s.h[q];
-        first(n0 + 1); put(level + n0 + 1);
+        s.init();
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            s.w[4 * q] = bswap32(second[q].x); s.w[4 * q + 1] = bswap32(second[q].y); s.w[4 * q + 2] = bswap32(second[q].z); s.w[4 * q + 3] = bswap32(second[q].w);
+        }
+        s.compress();
+        s.compress_pad64();
+        put(level + n0 + 1);
         #pragma unroll
         for (int q = 0; q < 8; q++) { s.w[8 + q] = s.h[q]; s.w[q] = left[q]; }
         level >>= 1;

@@ -9,7 +9,7 @@ from ministark_amd.api import DeviceBytes
 
 pl = Planner(0)
 L = pl.lib
-for log_leaves in (9, 13, 18, 21):
+for log_leaves in (9, 13, 18, 21, 23, 24):
     n = 1 << log_leaves
     leaves = DeviceBytes(pl, 32 * n); nodes = DeviceBytes(pl, 32 * n)
     host = np.random.default_rng(log_leaves).integers(0, 256, size=32 * n, dtype=np.uint8)
