@@ -241,7 +241,41 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
             run = q_mul<PW>(run, d[j][k]);
         }
     }
-    Q inv = q_inv<PW>(run);
+    // The inversion (a Fermat power: ~73 dependent products for Fp, the largest single item of this kernel when it serves only the
+    // PTS * npoints denominators of one lane) is pooled over the workgroup: lane l of ONE wave inverts the product of the four waves'
+    // lane-l products and hands each its own inverse back (nine more products on that wave, two barriers) -- a quarter of the
+    // inversions.  The inverting wave rotates with the workgroup so that the serial chains spread over a CU's SIMDs.
+    __shared__ uint64_t pool[NT * PW];
+    {
+        const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        #pragma unroll
+        for (int w = 0; w < PW; w++) pool[(wv * PW + w) * 64 + lane] = run.w[w];
+        __syncthreads();
+        if (wv == (blockIdx.x & 3)) {
+            Q a[4];
+            #pragma unroll
+            for (int v = 0; v < 4; v++) {
+                a[v] = q_zero<PW>();
+                #pragma unroll
+                for (int w = 0; w < PW; w++) a[v].w[w] = pool[(v * PW + w) * 64 + lane];
+            }
+            const Q p1 = q_mul<PW>(a[0], a[1]), p2 = q_mul<PW>(p1, a[2]);
+            Q t = q_inv<PW>(q_mul<PW>(p2, a[3]));
+            Q r[4];
+            r[3] = q_mul<PW>(t, p2); t = q_mul<PW>(t, a[3]);      // t = 1 / (a0 a1 a2)
+            r[2] = q_mul<PW>(t, p1); t = q_mul<PW>(t, a[2]);      // t = 1 / (a0 a1)
+            r[1] = q_mul<PW>(t, a[0]); r[0] = q_mul<PW>(t, a[1]);
+            #pragma unroll
+            for (int v = 0; v < 4; v++) {
+                #pragma unroll
+                for (int w = 0; w < PW; w++) pool[(v * PW + w) * 64 + lane] = r[v].w[w];
+            }
+        }
+        __syncthreads();
+    }
+    Q inv = q_zero<PW>();
+    #pragma unroll
+    for (int w = 0; w < PW; w++) inv.w[w] = pool[((threadIdx.x >> 6) * PW + w) * 64 + (threadIdx.x & 63)];
     #pragma unroll
     for (int j = PTS - 1; j >= 0; j--) {
         #pragma unroll

@@ -439,7 +439,9 @@ extern "C" int ms_deep_rows(ms_ctx* ctx, int point_field, unsigned log_domain, c
         ProfScope ps(ctx, "deep_rows", 8.0 * count * (nbase + 3.0 * next + PW));
         auto blocks = [&](unsigned pts) { return dim3((unsigned)((count + (size_t)msdeep::NT * pts - 1) / ((size_t)msdeep::NT * pts))); };
         if (PW == 1) {
-            if (npoints <= 3 && count >= 4096) hipLaunchKernelGGL((msdeep::deep_points<1, 4, 3>), blocks(4), dim3(msdeep::NT), 0, ctx->stream, D);
+            // two rows per lane: with the inversion pooled over the workgroup (deep_kernels.h) more rows per lane no longer pay for
+            // themselves -- 2^24 rows x 9 columns: 466 us against 494 with four and 622 with one (scripts/deep_rows_probe.py)
+            if (npoints <= 3 && count >= 4096) hipLaunchKernelGGL((msdeep::deep_points<1, 2, 3>), blocks(2), dim3(msdeep::NT), 0, ctx->stream, D);
             else hipLaunchKernelGGL((msdeep::deep_points<1, 1, msdeep::MAXPOINTS>), blocks(1), dim3(msdeep::NT), 0, ctx->stream, D);
         } else {
             if (npoints <= 4 && count >= 4096) hipLaunchKernelGGL((msdeep::deep_points<3, 2, 4>), blocks(2), dim3(msdeep::NT), 0, ctx->stream, D);
