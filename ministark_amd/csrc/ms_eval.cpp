@@ -149,6 +149,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         static const bool off = getenv("MS_EVAL_JIT") && !strcmp(getenv("MS_EVAL_JIT"), "0");
         if (off) return nullptr;
         const std::string src = jit_source(pr, cnt, is252, maxp, maxq);
+        if (const char* dump = getenv("MS_EVAL_DUMP")) { if (FILE* f = fopen(dump, "a")) { fputs(src.c_str(), f); fputs("\n// ----\n", f); fclose(f); } }
         const std::string& key = src;
         auto it = ctx->jit_cache.find(key);
         if (it != ctx->jit_cache.end()) return it->second;
@@ -159,6 +160,12 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
             hipModule_t mod = nullptr;
             if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, "ms_eval_jit") == hipSuccess) ctx->jit_modules.push_back(mod);
             else { fn = nullptr; (void)hipGetLastError(); }
+            if (fn && getenv("MS_EVAL_DEBUG")) {
+                int regs = 0, spill = 0;
+                (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn);
+                (void)hipFuncGetAttribute(&spill, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn);
+                fprintf(stderr, "[ministark_hip] specialised constraint kernel: %u instructions, %d vector registers, %d bytes of scratch per lane\n", cnt, regs, spill);
+            }
         } else if (getenv("MS_EVAL_DEBUG")) fprintf(stderr, "[ministark_hip] constraint kernel compilation failed, using the interpreter:\n%s\n", log.c_str());
         ctx->jit_cache[key] = fn;
         return fn;
