@@ -22,8 +22,9 @@ Extra objects on the JSON line:
                  one column transform / summed average duration of its kernel launches,
                  measured live with hipEvents on the library's stream; `kernels` lists
                  each launch (avg_us, its own bytes moved) for comparison with
-                 profiles/*kernel_stats*.  `traffic` = HBM bytes per transform from the
-                 rocprofv3 PMC passes when bench is run with --traffic-json, else null.
+                 profiles/*kernel_stats*.  `traffic` = HBM bytes per transform, MEASURED IN THE
+                 RUN at N = 1 (two short child runs under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE: _measure_traffic) and
+                 otherwise taken from the summary of the same passes under profiles/ (--traffic-json); `traffic_source` says which.
   cpu_baseline : oracle/c (C/OpenMP restatement of the reference CPU path, kind "port")
                  timed on this box's host cores on one 2^24 column, same data.
   lde_2_24     : the prover's own transform order at configs[4]'s size -- interpolate + bit-reversed coset evaluation of 2^22-row columns
@@ -171,6 +172,56 @@ def _emit(obj):
     out = _LINE_OUT if _LINE_OUT is not None else sys.stdout
     out.write(json.dumps(obj) + "\n")
     out.flush()
+
+
+def _measure_traffic(log_n):
+    """HBM bytes of ONE forward coset transform, measured now: two short child runs of this script under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE, then WRITE_SIZE: separate passes, no tracing domains, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), reduced per
+    launch and per column like scripts/summarise_profiles.py does (FETCH_SIZE doubled: gfx950 tallies a coalesced stream at 64 B per request;
+    units of 1024 B).  -> (bytes, per-kernel dict) or None when rocprofv3 is absent, this process is itself being profiled, or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("MS_BENCH_NO_PMC") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    per = {}
+    work = tempfile.mkdtemp(prefix="ms_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cols", "2", "--log-n", str(log_n), "--no-cpu-baseline", "--no-extras", "--settle", "0.3"]
+            env = dict(os.environ, MS_BENCH_NO_PMC="1", TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            hits = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not hits:
+                return None
+            for row in csv.DictReader(open(hits[0])):
+                name = row["Kernel_Name"]
+                # the three launches of the forward coset transform (the variants of the child run are off with --no-extras ... they are not:
+                # subgroup / inverse plans run too and are told apart by their template arguments, as in scripts/summarise_profiles.py)
+                if "msntt2" not in name or row["Counter_Name"] != counter:
+                    continue
+                if not any(t in name for t in ("ntt2_first_pass<true, false, true, 16", "ntt2_mid_pass<true, false, false, 0", "ntt2_mid_pass<true, false, true, 0",
+                                               "ntt2_first_pass<false, false, true, 16", "ntt2_mid_pass<false, false, false, 0", "ntt2_mid_pass<false, false, true, 0")):
+                    continue
+                cols = max(1.0, float(row["Grid_Size"]) / (((1 << log_n) // 16384) * 512))
+                per.setdefault(name, {}).setdefault(counter, []).append(float(row["Counter_Value"]) / cols)
+        total, kernels = 0.0, {}
+        for name, c in per.items():
+            if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                return None
+            fb = 2 * 1024 * sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+            wb = 1024 * sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+            kernels[name.split("(")[0].replace("void ", "")] = {"fetch_bytes_per_column": round(fb), "write_bytes_per_column": round(wb)}
+            total += fb + wb
+        return (total, kernels) if len(per) == 3 else None
+    except Exception:                                            # noqa: BLE001 -- an extra: the line falls back to the tracked summary
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def _profiled(pl, fn, reps, after_wall=None):
@@ -659,10 +710,15 @@ def main():
                         "GBps": round(alg_bytes_col / us_col / 1e3, 1),
                         "frac_of_hbm_peak": round(alg_bytes_col / us_col / 1e3 / HBM_PEAK_GBS, 3)})
     achieved = alg_bytes_col / us_per_transform / 1e3 if us_per_transform else 0.0
-    # HBM bytes per transform are not measured in this run: they come from the separate rocprofv3 PMC passes
-    # (FETCH_SIZE / WRITE_SIZE, scripts/collect_profiles.sh) whose summary is the file named in `traffic_source`
-    traffic, traffic_source = None, None
-    if args.traffic_json and os.path.exists(args.traffic_json):
+    # HBM bytes per transform: measured now by two short PMC child runs (FETCH_SIZE, WRITE_SIZE; default single-GPU run only), else
+    # from the summary of the same passes under profiles/ (scripts/collect_profiles.sh), named in `traffic_source`
+    traffic, traffic_source, traffic_kernels = None, None, None
+    if world == 1 and not args.no_extras:
+        measured = _measure_traffic(log_n)
+        if measured is not None:
+            traffic, traffic_kernels = measured
+            traffic_source = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child runs of 2 columns x 2 steps), per launch and column"
+    if traffic is None and args.traffic_json and os.path.exists(args.traffic_json):
         traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_transform")
         traffic_source = os.path.relpath(args.traffic_json, ROOT)
     out = {
@@ -674,7 +730,7 @@ def main():
         "field_ops_per_s": round(field_ops * total_cols * args.steps / elapsed, 1),
         "us_per_transform": round(elapsed / args.steps / args.cols * 1e6, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_kernels": traffic_kernels,
                      "algorithmic_bytes_per_transform": alg_bytes_col,
                      "us_per_transform_events": round(us_per_transform, 2), "kernels": kernels},
     }
