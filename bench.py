@@ -194,9 +194,16 @@ def _measure_traffic(log_n):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cols", "2", "--log-n", str(log_n), "--no-cpu-baseline", "--no-extras", "--settle", "0.3"]
             env = dict(os.environ, MS_BENCH_NO_PMC="1", TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=120)
+            except subprocess.TimeoutExpired:                    # the profiler AND the run under it: the whole process group it leads
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                return None
             hits = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not hits:
+            if rc != 0 or not hits:
                 return None
             for row in csv.DictReader(open(hits[0])):
                 name = row["Kernel_Name"]
