@@ -2,7 +2,7 @@
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from ministark_amd import GOLDILOCKS_FP, Matrix, Planner
+from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3, Matrix, Planner
 
 if os.environ.get("MS_LIB"):                      # a second build of the library (before / after timings)
     from ministark_amd import _lib
@@ -12,7 +12,9 @@ else:
 log_n, log_b, ncols = int(os.environ.get("LOGN", 20)), int(os.environ.get("LOGB", 3)), int(os.environ.get("NCOLS", 32))
 rng = np.random.default_rng(3)
 P = (1 << 64) - (1 << 32) + 1
-trace = Matrix.from_numpy(pl, [rng.integers(0, P, size=1 << log_n, dtype=np.uint64) for _ in range(ncols)], GOLDILOCKS_FP)
+FIELD = GOLDILOCKS_FQ3 if os.environ.get("FQ3") else GOLDILOCKS_FP          # FQ3=1: extension-field columns (three words per element)
+V = 3 if os.environ.get("FQ3") else 1
+trace = Matrix.from_numpy(pl, [rng.integers(0, P, size=V << log_n, dtype=np.uint64) for _ in range(ncols)], FIELD)
 for _ in range(3):
     lde = trace.lde(1 << log_b, 7, True); del lde
 pl.sync()
