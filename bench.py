@@ -393,9 +393,8 @@ def bench_prove(pl, with_cpu):
         c.free()
     out["native_host"] = _native_prove(log_t)
     if with_cpu:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import cref
-        from tests.test_pipeline_parity import _c5_oracle_chain
+        from oracle.prover_chain import c5_oracle_chain as _c5_oracle_chain
         cols = [cref.random_elements(n_t, 77 + c) for c in range(ncols)]                    # the same size: the whole chain once
         t0 = time.perf_counter()
         _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp, ce)

@@ -529,7 +529,7 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
     // Measured (profiles/r04_c2_sweep.json): 2.48 -> 2.25 us per column over 64 columns.  At 2^17 the rows are too short for the uniform
     // split of pass A's factor (T = 2) and its per-lane running product loses: 1.50 against 1.37 us -- stays on three passes.
     if (!p->inverse && p->V == 1 && valid_rows == 256 && !bitrev_out && p->log_n == 18 && p->d_wr4[0] != nullptr)
-        return lde2_run(p, p->log_n, 0, src, dst, ncols, true);
+        return lde2_run(p->base ? p->base : p, p->log_n, 0, src, dst, ncols, true);   // the CACHED plan owns (and frees) the tables: a handle is a copy
     unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
     group = std::min(group, ncols);
     // uniform-factor plans on Fp columns: pass 1 stores whole lines in a row order that permutes the words inside every run of

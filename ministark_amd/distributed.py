@@ -99,6 +99,10 @@ class RcclComm:
         for c in my_cols:
             if len(c) != nrows or c.field != field:
                 raise ValueError("column of the wrong length or field")
+        if self.world == 1:                                     # one rank owns every column and every row: the shard IS the columns
+            if len(my_cols) != total_cols:
+                raise ValueError(f"rank 0 of 1 owns {total_cols} of {total_cols} columns, {len(my_cols)} given")
+            return list(my_cols)
         shard = [GpuVec(pl, nrows // self.world, field) for _ in range(total_cols)]
         L.check(L.ms_cols_to_rows_alltoall(pl.handle, field, nrows, _ptr_array(my_cols), len(my_cols), total_cols, _ptr_array(shard)))
         return shard
@@ -254,6 +258,8 @@ def _sharded_root(planner, comm, tree, hash):
 def _collect(planner, comm, buf, nbytes_of, root=0):
     """Device buffers of nbytes_of[rank] bytes on every rank -> on `root` one DeviceBytes holding them in rank order (None elsewhere)."""
     r, G = comm.rank, comm.world
+    if G == 1 and buf is not None:                              # nothing to collect: the caller's buffer is the result
+        return buf
     offs = np.concatenate([[0], np.cumsum(nbytes_of)]).astype(np.int64)
     out, ops = None, []
     if r == root:
@@ -496,8 +502,11 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
     comp_cols_local = []
     comp_owned = owned_columns(ce_blowup, r, G)
     if r == 0:
-        ev = GpuVec(pl, n_ce)
-        L.check(L.ms_copy(pl.handle, ev.ptr, evals_all.ptr, n_ce * 8))
+        if G == 1 and isinstance(evals_all, GpuVec) and len(evals_all) == n_ce:
+            ev = evals_all                                      # the evaluator's own output column
+        else:
+            ev = GpuVec(pl, n_ce)
+            L.check(L.ms_copy(pl.handle, ev.ptr, evals_all.ptr, n_ce * 8))
         comp_poly = Matrix([ev]).bit_reverse_rows().into_polynomials(ce_dom).columns[0]
         comp_all = Matrix.from_chunks(comp_poly, ce_blowup).columns
         ops = [(XCHG_SEND, c % G, comp_all[c].ptr, n_t * 8) for c in range(ce_blowup) if c % G != 0]
@@ -541,12 +550,13 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
     roots, layers = [], []                                       # layers: (evaluations, tree, sharded?, size)
     for alpha in draws.fri_alphas:
         if sharded and (n // G) // folding < 2:
-            whole = _collect(pl, comm, cur, [n // G * 8] * G, 0)
             sharded = False
-            cur = None
-            if r == 0:
-                cur = GpuVec(pl, n)
-                L.check(L.ms_copy(pl.handle, cur.ptr, whole.ptr, n * 8))
+            if G > 1:
+                whole = _collect(pl, comm, cur, [n // G * 8] * G, 0)
+                cur = None
+                if r == 0:
+                    cur = GpuVec(pl, n)
+                    L.check(L.ms_copy(pl.handle, cur.ptr, whole.ptr, n * 8))
         al = np.array([gl_to_mont(alpha)], dtype=np.uint64)
         if sharded:
             tree = ShardedTree(pl, comm, MerkleTree.from_fri_layer(cur, folding, hash), hash)
@@ -563,7 +573,7 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
             layers.append((cur, tree, False, n))
             cur = apply_drp(cur, al, folding, 1)
         n //= folding
-    if sharded:
+    if sharded and G > 1:
         whole = _collect(pl, comm, cur, [n // G * 8] * G, 0)
         cur = None
         if r == 0:

@@ -246,6 +246,40 @@ __global__ void __launch_bounds__(512, 4) k_tile256(Cols C, unsigned log_stride)
     for (int i = 0; i < 32; i++) st_nt(dst, ((r0 + 8 * i) << log_stride) + c, v[i]);
 }
 
+// ---- is the L2 write-back at all?  every workgroup stores the SAME 64 KiB of its own TIMES times (waiting for the acknowledgements in between) --
+template <int TIMES, bool NTST>
+__global__ void __launch_bounds__(512, 4) k_rewrite(uint64_t* buf) {
+    uint64_t* mine = buf + (size_t)blockIdx.x * 8192;
+    const unsigned t = threadIdx.x;
+    for (int r = 0; r < TIMES; r++) {
+        #pragma unroll
+        for (int i = 0; i < 16; i++) { if (NTST) st_nt(mine, t + 512 * i, (uint64_t)r + i); else st_def(mine, t + 512 * i, (uint64_t)r + i); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+// and does a line another CU of the same XCD stored come back from L2?  phase 1 stores 64 KiB per workgroup, team barrier, phase 2 loads the
+// 64 KiB of the NEXT team member (default or nt loads): FETCH_SIZE should be ~0 if the stored lines are kept.
+template <int TEAMS, bool NTLD>
+__global__ void __launch_bounds__(512, 4) k_handoff(Ctl* ctl, uint64_t* buf, uint64_t* sink, int rounds) {
+    unsigned xcc, team, m;
+    if (!join_team<TEAMS>(ctl, xcc, team, m)) return;
+    const unsigned T = xcc * TEAMS + team;
+    unsigned* ctr = &ctl->bar[T * 32];
+    const unsigned t = threadIdx.x;
+    uint64_t acc = 0;
+    unsigned gen = 0;
+    for (int r = 0; r < rounds; r++) {
+        uint64_t* mine = buf + ((size_t)(r * 8 * TEAMS + T) * 16 + m) * 8192;
+        const uint64_t* other = buf + ((size_t)(r * 8 * TEAMS + T) * 16 + ((m + 5) & 15)) * 8192;
+        #pragma unroll
+        for (int i = 0; i < 16; i++) st_def(mine, t + 512 * i, (uint64_t)r + i + t);
+        team_barrier(ctr, ++gen);
+        #pragma unroll
+        for (int i = 0; i < 16; i++) acc += NTLD ? ld_nt(other, t + 512 * i) : *(const uint64_t*)((const char*)other + ((t + 512 * i) << 3));
+    }
+    if (acc == 0x123456789abcull) sink[0] = acc;
+}
+
 static uint64_t *IN[NCOL], *SCR[NCOL], *OUT[NCOL], *STAGE;
 static Ctl* CTL;
 static int g_launches = 10, g_reps = 7;
@@ -302,6 +336,18 @@ static void tile256(unsigned log_stride, const char* what) {
     timeit(nm, [&] { hipLaunchKernelGGL((k_tile256<SPIN>), dim3(1024, NCOL), dim3(512), 0, 0, C, log_stride); });
 }
 
+template <int TIMES, bool NTST>
+static void rewrite() {
+    char nm[200];
+    snprintf(nm, sizeof nm, "rewrite: 2048 workgroups store their own 64 KiB %d times, %s stores (128 MiB distinct bytes; x8 'columns')", TIMES, NTST ? "nt" : "default");
+    timeit(nm, [&] { hipLaunchKernelGGL((k_rewrite<TIMES, NTST>), dim3(2048), dim3(512), 0, 0, SCR[0]); });
+}
+template <int TEAMS, bool NTLD>
+static void handoff() {
+    char nm[200];
+    snprintf(nm, sizeof nm, "handoff: store 64 KiB, team barrier, load a team mate's 64 KiB (%s loads), %d teams/XCD, 8 rounds", NTLD ? "nt" : "default", TEAMS);
+    timeit(nm, [&] { reset_ctl(); hipLaunchKernelGGL((k_handoff<TEAMS, NTLD>), dim3(8 * TEAMS * 16), dim3(512), 0, 0, CTL, SCR[0], SCR[1], 8); });
+}
 struct Variant { const char* id; void (*fn)(); };
 static void ref16_0() { tile256<0>(16, "pass 1 / 3 of the shipped plan"); }
 static void ref16_8() { tile256<8>(16, "pass 1 / 3 of the shipped plan"); }
@@ -317,6 +363,10 @@ static const Variant VARIANTS[] = {
     {"B_def_grp_8", rowsB<0, false, 1, 1>}, {"B_nt_grp_8", rowsB<0, true, 1, 1>}, {"B_def_ord_8", rowsB<0, false, 0, 1>},
     {"B_def_grp_16", rowsB<0, false, 1, 2>}, {"B_nt_grp_16", rowsB<0, true, 1, 2>},
     {"B_def_grp_8_w", rowsB<10, false, 1, 1>}, {"B_def_grp_16_w", rowsB<10, false, 1, 2>},
+    {"A64_t1_ip_0", teamA<64, 0, 0, 1, true>}, {"A32_t2_ip_0", teamA<32, 0, 0, 2, true>}, {"A32_t1_ip_0", teamA<32, 0, 0, 1, true>},
+    {"A64_t1_slab_0", teamA<64, 0, 0, 1, false>}, {"A32_t1_slab_0", teamA<32, 0, 0, 1, false>},
+    {"rewrite1_def", rewrite<1, false>}, {"rewrite8_def", rewrite<8, false>}, {"rewrite8_nt", rewrite<8, true>},
+    {"handoff_t1_def", handoff<1, false>}, {"handoff_t1_nt", handoff<1, true>}, {"handoff_t4_def", handoff<4, false>},
     {"Bteam_t4_0", teamB<0, 4>}, {"Bteam_t2_0", teamB<0, 2>}, {"Bteam_t4_w", teamB<10, 4>},
 };
 

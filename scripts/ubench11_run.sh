@@ -6,8 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 OUT=$R/gpurun_out
 mkdir -p $OUT
-timeout 300 $R/scripts/ubench11 > $OUT/ubench11.txt 2>&1
-echo "timing exit $?" >> $OUT/ubench11.txt
+if [ -z "${UB11_SKIP_TIMING:-}" ]; then timeout 300 $R/scripts/ubench11 > $OUT/ubench11.txt 2>&1; echo "timing exit $?" >> $OUT/ubench11.txt; fi
 VARS=${@:-"ref16_0 ref12_0 A64_t4_ip_0 A64_t2_ip_0 A32_t4_ip_0 A64_t4_slab_0 A64_t4_ip_w B_def_grp_8 B_nt_grp_8 B_def_ord_8 B_def_grp_16 Bteam_t4_0"}
 : > $OUT/ubench11_traffic.txt
 for v in $VARS; do
@@ -20,7 +19,7 @@ d, v, ctr = sys.argv[1:4]
 hits = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
 if not hits:
     print(f"{v} {ctr} MISSING"); sys.exit(0)
-vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(hits[0])) if r["Counter_Name"] == ctr and ("k_team" in r["Kernel_Name"] or "k_rows" in r["Kernel_Name"] or "k_tile" in r["Kernel_Name"])]
+vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(hits[0])) if r["Counter_Name"] == ctr and any(k in r["Kernel_Name"] for k in ("k_team", "k_rows", "k_tile", "k_rewrite", "k_handoff"))]
 if not vals:
     print(f"{v} {ctr} no kernel rows"); sys.exit(0)
 mult = 2 * 1024 if ctr == "FETCH_SIZE" else 1024         # gfx950: FETCH_SIZE tallies 64 B per request of a coalesced stream

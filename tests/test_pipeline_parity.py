@@ -140,76 +140,7 @@ def test_prover_pipeline_c1_shape(kind):
 
 
 # ---- the C5 shape (fib-like trace, ProofOptions::new(32, 4, 8, 8, 64)) against the C oracle, at size on the GPU ------------
-def _c5_oracle_chain(cols, log_t, blowup, folding, draws, comp_expr, ce_blowup=None):
-    """The same transcript on the CPU: oracle/c for every transform, hash, evaluation and the DEEP composition.
-    ce_blowup: the AIR's ce_blowup_factor (constraint-evaluation domain = trace_len * ce_blowup points, src/air.rs:55-59)."""
-    import hashlib
-    from oracle import cref
-    ce_blowup = blowup if ce_blowup is None else ce_blowup
-    log_b = blowup.bit_length() - 1
-    log_l = log_t + log_b
-    log_ce = log_t + ce_blowup.bit_length() - 1
-    n_t, n_l = 1 << log_t, 1 << log_l
-    R = lambda v: np.array([cref.lib().oracle_gl_to_mont(int(v) % cref.GL_P)], dtype=np.uint64)
-    out = {}
-    polys = [cref.ntt(c.copy(), log_t, 1, True, 1) for c in cols]
-    lde_nat = [cref.lde(c, log_t, log_b, 1, 7, False) for c in cols]
-    lde_br = [cref.bit_reverse(c.copy(), log_l) for c in lde_nat]
-    out["base_root"] = cref.sha256_merkle(cref.sha256_rows(lde_br, 1))[1].tobytes()
-    ch = np.array([R(c)[0] for c in draws.challenges], dtype=np.uint64).reshape(-1, 1)
-    hints = np.array([R(c)[0] for c in draws.hints], dtype=np.uint64).reshape(-1, 1)
-    # the constraint-evaluation coset h<w_(n ce)> in natural order: every (blowup / ce_blowup)-th point of the LDE coset
-    ce_nat = [np.ascontiguousarray(c[::blowup // ce_blowup]) for c in lde_nat]
-    comp_nat = cref.eval_expr(comp_expr, log_ce, ce_blowup, 7, ce_nat, [], ch, hints, False)     # prover.rs:97-107 (eval_cpu::eval)
-    out["comp_evals_br"] = cref.bit_reverse(comp_nat.copy(), log_ce)
-    comp_poly = cref.ntt(comp_nat.copy(), log_ce, 1, True, 7)                                  # prover.rs:111-112
-    comp_polys = [np.ascontiguousarray(comp_poly[c::ce_blowup]) for c in range(ce_blowup)]    # prover.rs:113-121
-    out["comp_polys"] = comp_polys
-
-    def evaluate_br(coeffs):                                                                 # bit_reversed_evaluate on the LDE coset
-        a = np.zeros(n_l, dtype=np.uint64)
-        a[:len(coeffs)] = coeffs
-        return cref.bit_reverse(cref.ntt(a, log_l, 1, False, 7), log_l)
-    comp_lde = [evaluate_br(p) for p in comp_polys]
-    out["composition_root"] = cref.sha256_merkle(cref.sha256_rows(comp_lde, 1))[1].tobytes()
-    # DEEP (composer.rs:43-188), Fq = Fp
-    g = GL.root_of_unity(n_t)
-    z = draws.z
-    pt = lambda off: (z * pow(g, off, GL.p)) % GL.p
-    z_n = pow(z, ce_blowup, GL.p)
-    exec_ood = [cref.horner_eval(polys[c], 1, R(pt(o))) for c, o in draws.trace_args]
-    comp_ood = [cref.horner_eval(p, 1, R(z_n)) for p in comp_polys]
-    out["ood"] = ([GL.from_mont(int(v[0])) for v in exec_ood], [GL.from_mont(int(v[0])) for v in comp_ood])
-    terms = []
-    for c in range(len(polys)):
-        zs = [R(pt(o))[0] for (cc, o) in draws.trace_args if cc == c]
-        al = [R(a)[0] for (cc, o), a in zip(draws.trace_args, draws.deep.execution_trace) if cc == c]
-        terms.append((np.array(zs, dtype=np.uint64), np.array(al, dtype=np.uint64)))
-    for c in range(ce_blowup):
-        terms.append((R(z_n), R(draws.deep.composition_trace[c])))
-    deep_poly = cref.deep_compose(polys + comp_polys, [1] * (len(polys) + ce_blowup), terms, n_t, 1,
-                                  (R(draws.deep.degree[0]), R(draws.deep.degree[1])))
-    out["deep_poly"] = deep_poly
-    layer = evaluate_br(deep_poly)
-    out["fri_roots"], n, fri_layers = [], n_l, []
-    for alpha in draws.fri_alphas:
-        fri_layers.append(layer)
-        rows = [np.ascontiguousarray(layer[k::folding]) for k in range(folding)]              # rows of `folding` consecutive evaluations
-        out["fri_roots"].append(cref.sha256_merkle(cref.sha256_rows(rows, 1))[1].tobytes())
-        layer = cref.fri_fold(layer, n.bit_length() - 1, 1, folding, R(alpha), 1)
-        n //= folding
-    out["remainder"] = layer
-    out["fri_layers"] = fri_layers
-    # FriProver::set_remainder (fri.rs:232-248)
-    log_r = n.bit_length() - 1
-    out["remainder_coeffs"] = cref.ntt(cref.bit_reverse(layer.copy(), log_r), log_r, 1, True, 1)[: max(n // blowup, 1)]
-    seed = out["fri_roots"][-1]
-    nonce = 1
-    while int.from_bytes(hashlib.sha256(seed + nonce.to_bytes(8, "big")).digest()[:8], "big") >> (64 - 8):
-        nonce += 1
-    out["nonce"] = nonce
-    out["lde_br"], out["comp_lde"] = lde_br, comp_lde
-    return out
+from oracle.prover_chain import c5_oracle_chain as _c5_oracle_chain   # noqa: E402  (the chain lives with the oracle: bench.py times it too)
 
 
 def _run_c5(kind, log_t, seed, air="fib"):
@@ -275,3 +206,127 @@ def test_prover_pipeline_c5_at_size_hip():
 def test_prover_pipeline_additive_air_hip():
     """The second shape: 8 additive transitions evaluated on the whole LDE domain (ce_blowup = 4, four composition columns)."""
     _run_c5("hip", 20, 0xADD, air="additive")
+
+
+# ---- C1 at its REAL shape (BASELINE configs[0]; examples/brainfuck/main.rs:92-105, air.rs:26-27): 512 rows, 17 Fp + 9 Fq3 columns,
+# blow-up 16, FRI folding factor 16 -- against oracle/c (the big-integer oracle above needs minutes at this size) ----------------
+def _mw(v):
+    """canonical Fq3 tuple / int -> Montgomery words"""
+    return np.array([GL.to_mont(c) for c in (v if isinstance(v, tuple) else (v,))], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_prover_pipeline_c1_real_shape(kind):
+    from oracle import cref
+    from oracle.pyref import deep as od
+    pl = backends.planner(kind)
+    rng = np.random.default_rng(512)
+    log_n, log_b = 9, 4
+    n, N, log_N = 1 << log_n, 1 << (log_n + log_b), log_n + log_b
+    rq = lambda: tuple(int(x) for x in rng.integers(0, 1 << 62, size=3))
+    base = [cref.random_elements(n, 900 + c) for c in range(NBASE)]
+    ext = [cref.random_elements(n, 950 + c, 3) for c in range(NEXT)]
+    challenges = [rq() for _ in range(4)]
+    trace_dom, lde_dom = Radix2EvaluationDomain(n), Radix2EvaluationDomain(N, OFFSET)
+    mat = lambda cols, f: Matrix([GpuVec.from_numpy(pl, c, f) for c in cols])
+    eq = lambda vec, want: np.array_equal(vec.to_numpy(), want)
+
+    # ---- base / extension trace: interpolate, bit-reversed LDE, commitments (prover.rs:50-79)
+    base_polys, ext_polys = mat(base, FP).interpolate(trace_dom), mat(ext, FQ3F).interpolate(trace_dom)
+    base_lde, ext_lde = base_polys.bit_reversed_evaluate(lde_dom), ext_polys.bit_reversed_evaluate(lde_dom)
+    base_tree, ext_tree = MerkleTree.from_matrix(base_lde), MerkleTree.from_matrix(ext_lde)
+    o_base_polys = [cref.ntt(c, log_n, 1, True, 1) for c in base]
+    o_ext_polys = [cref.ntt(c, log_n, 3, True, 1) for c in ext]
+    assert all(eq(g, w) for g, w in zip(base_polys.columns, o_base_polys)) and all(eq(g, w) for g, w in zip(ext_polys.columns, o_ext_polys))
+    o_base_nat = [cref.lde(c, log_n, log_b, 1, OFFSET, False) for c in base]
+    o_ext_nat = [cref.lde(c, log_n, log_b, 3, OFFSET, False) for c in ext]
+    o_base_lde = [cref.bit_reverse(c, log_N, 1) for c in o_base_nat]
+    o_ext_lde = [cref.bit_reverse(c, log_N, 3) for c in o_ext_nat]
+    assert all(eq(g, w) for g, w in zip(base_lde.columns, o_base_lde)) and all(eq(g, w) for g, w in zip(ext_lde.columns, o_ext_lde))
+    o_base_nodes = cref.sha256_merkle(cref.sha256_rows(o_base_lde, 1))
+    o_ext_nodes = cref.sha256_merkle(cref.sha256_rows(o_ext_lde, 3))
+    assert base_tree.root() == o_base_nodes[1].tobytes() and ext_tree.root() == o_ext_nodes[1].tobytes()
+
+    # ---- constraint evaluation over the LDE coset: 9 permutation-style constraints over a zerofier (prover.rs:98-107)
+    x = E.X()
+    b = lambda c, o=0: E.Trace(c, o)
+    e = lambda c, o=0: E.Trace(NBASE + c, o)
+    expr = None
+    for k in range(NEXT):
+        t = (e(k, 1) - e(k) * (E.Challenge(k % 4) - b(k) * E.Challenge((k + 1) % 4) - b(k + 8, 1))) * (x - 1) / (x ** n - 1)
+        expr = t if expr is None else expr + t * E.Challenge(k % 4)
+    prog = E.compile_expr(expr, NBASE, True)
+    ch = np.array([_mw(c) for c in challenges], dtype=np.uint64)
+    base_nat, ext_nat = base_lde.clone().bit_reverse_rows(), ext_lde.clone().bit_reverse_rows()
+    comp_evals = E.eval(prog, pl, ch, ch[:1], BLOWUP, OFFSET, N, base_nat.columns, ext_nat.columns)
+    o_comp_evals = cref.eval_expr(expr, log_N, BLOWUP, OFFSET, o_base_nat, o_ext_nat, ch, ch[:1], True)
+    assert eq(comp_evals, o_comp_evals)
+
+    # ---- composition trace: coefficients, chunks(ce_blowup), LDE, commitment (prover.rs:110-124)
+    comp_poly = Matrix([comp_evals]).into_polynomials(lde_dom).columns[0]
+    comp_polys = Matrix.from_chunks(comp_poly, BLOWUP)
+    comp_lde = comp_polys.bit_reversed_evaluate(lde_dom)
+    comp_tree = MerkleTree.from_matrix(comp_lde)
+    o_comp_poly = cref.ntt(o_comp_evals, log_N, 3, True, OFFSET)
+    o_comp_polys = [np.ascontiguousarray(o_comp_poly.reshape(-1, 3)[c::BLOWUP]).ravel() for c in range(BLOWUP)]
+    assert all(eq(g, w) for g, w in zip(comp_polys.columns, o_comp_polys))
+
+    def evaluate_br(coeffs):
+        a = np.zeros(3 * N, dtype=np.uint64)
+        a[:len(coeffs)] = coeffs
+        return cref.bit_reverse(cref.ntt(a, log_N, 3, False, OFFSET), log_N, 3)
+    o_comp_lde = [evaluate_br(p) for p in o_comp_polys]
+    o_comp_nodes = cref.sha256_merkle(cref.sha256_rows(o_comp_lde, 3))
+    assert comp_tree.root() == o_comp_nodes[1].tobytes()
+
+    # ---- DEEP composition (composer.rs:43-188)
+    z = rq()
+    args = [(c, o) for c in range(NBASE + NEXT) for o in (0, 1)]
+    composer = DeepPolyComposer(args, n, z, base_polys, ext_polys, comp_polys)
+    got_exec, got_comp = composer.get_ood_evals()
+    g, g_inv = trace_dom.group_gen, trace_dom.group_gen_inv
+    z_n = od.qpow(z, BLOWUP)
+    o_polys, o_Vs = o_base_polys + o_ext_polys, [1] * NBASE + [3] * NEXT
+    want_exec = [tuple(int(v) for v in cref.from_mont(cref.horner_eval(o_polys[c], o_Vs[c], _mw(od.point_for(z, g, g_inv, o))))) for c, o in args]
+    want_comp = [tuple(int(v) for v in cref.from_mont(cref.horner_eval(p, 3, _mw(z_n)))) for p in o_comp_polys]
+    assert [tuple(v) for v in got_exec] == want_exec and [tuple(v) for v in got_comp] == want_comp
+    ea, ca, degree = [rq() for _ in args], [rq() for _ in range(BLOWUP)], (rq(), rq())
+    deep_poly = composer.into_deep_poly(DeepCompositionCoeffs(ea, ca, degree))
+    terms = []
+    for c in range(NBASE + NEXT):
+        zs = [_mw(od.point_for(z, g, g_inv, o)) for (cc, o) in args if cc == c]
+        al = [_mw(a) for (cc, o), a in zip(args, ea) if cc == c]
+        terms.append((np.concatenate(zs), np.concatenate(al)))
+    for c in range(BLOWUP):
+        terms.append((_mw(z_n), _mw(ca[c])))
+    o_deep_poly = cref.deep_compose(o_polys + o_comp_polys, o_Vs + [3] * BLOWUP, terms, n, 3, (_mw(degree[0]), _mw(degree[1])))
+    assert eq(deep_poly, o_deep_poly)
+    layer = Matrix([deep_poly]).into_bit_reversed_evaluations(lde_dom).columns[0]
+    o_layer = evaluate_br(o_deep_poly)
+    assert eq(layer, o_layer)
+
+    # ---- FRI layers (fri.rs:179-231): commit, fold by 16 until the remainder is at most 64 evaluations
+    size, alphas, k = N, [rq() for _ in range(4)], 0
+    while size > 64:
+        tree = MerkleTree.from_fri_layer(layer, FOLD)
+        rows = [np.ascontiguousarray(o_layer.reshape(-1, 3)[j::FOLD]).ravel() for j in range(FOLD)]     # Matrix::from_arrays(as_chunks)
+        assert tree.root() == cref.sha256_merkle(cref.sha256_rows(rows, 3))[1].tobytes()
+        layer = apply_drp(layer, _mw(alphas[k]), FOLD, 1)
+        o_layer = cref.fri_fold(o_layer, size.bit_length() - 1, 3, FOLD, _mw(alphas[k]), 1)
+        assert eq(layer, o_layer)
+        size //= FOLD
+        k += 1
+    assert k == 2 and size == 32
+
+    # ---- queries (trace.rs:113-157): rows and batched openings of the three trees
+    positions = [int(p) for p in rng.integers(0, N, size=30)] + [0, N - 1]
+    q = Queries(base_lde, ext_lde, comp_lde, base_tree, ext_tree, comp_tree, positions)
+    for rows, o_cols, V in ((q.base_trace_values, o_base_lde, 1), (q.extension_trace_values, o_ext_lde, 3), (q.composition_trace_values, o_comp_lde, 3)):
+        for r, p in zip(rows, positions):
+            assert np.array_equal(np.asarray(r, dtype=np.uint64).ravel(), np.concatenate([c[V * p:V * p + V] for c in o_cols]))
+    for proof, nodes, cols, V in ((q.base_trace_proof, o_base_nodes, o_base_lde, 1), (q.extension_trace_proof, o_ext_nodes, o_ext_lde, 3),
+                                  (q.composition_trace_proof, o_comp_nodes, o_comp_lde, 3)):
+        leaves = [bytes(l) for l in cref.sha256_rows(cols, V)]
+        node_list = [bytes(x) for x in nodes]
+        assert proof == omerkle.prove(leaves, node_list, positions)
+        assert omerkle.verify(node_list[1], proof, positions)
