@@ -366,7 +366,7 @@ static const Variant VARIANTS[] = {
     {"A64_t1_ip_0", teamA<64, 0, 0, 1, true>}, {"A32_t2_ip_0", teamA<32, 0, 0, 2, true>}, {"A32_t1_ip_0", teamA<32, 0, 0, 1, true>},
     {"A64_t1_slab_0", teamA<64, 0, 0, 1, false>}, {"A32_t1_slab_0", teamA<32, 0, 0, 1, false>},
     {"rewrite1_def", rewrite<1, false>}, {"rewrite8_def", rewrite<8, false>}, {"rewrite8_nt", rewrite<8, true>},
-    {"handoff_t1_def", handoff<1, false>}, {"handoff_t1_nt", handoff<1, true>}, {"handoff_t4_def", handoff<4, false>},
+    {"handoff_t1_def", handoff<1, false>}, {"handoff_t1_nt", handoff<1, true>},
     {"Bteam_t4_0", teamB<0, 4>}, {"Bteam_t2_0", teamB<0, 2>}, {"Bteam_t4_w", teamB<10, 4>},
 };
 
