@@ -231,6 +231,143 @@ def _measure_traffic(log_n):
         shutil.rmtree(work, ignore_errors=True)
 
 
+# ---- the bounding resources of the OTHER roofline objects, measured in the run ----------------------------------------------------------
+# One child process per counter pass runs every object's workload once warm and once between two marker launches (a k_fill over
+# _PMC_MARK words: no workload launches that grid); the parent cuts the counter rows at the markers.  Three passes: FETCH_SIZE,
+# WRITE_SIZE (separate, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled on gfx950, units of 1024 B) and the SQ
+# counters.  SQ_INSTS_VALU counts wave instructions of the whole chip; a vector instruction holds its SIMD's issue slot for one quad cycle
+# (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU in quad cycles, profiles/r04_ntt_sq_counters.csv), so the chip issues at most
+# 1024 SIMDs x 2.4 GHz / 4 = 6.144e11 wave instructions per second; SQ_BUSY_CYCLES is summed over the 32 shader engines.
+_PMC_MARK = 4242
+_PMC_SQ = ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4
+_PMC_OBJECTS = ("lde_commit", "lde_2_24", "constraint_eval.fib_air_fp", "constraint_eval.mixed_17fp_9fq3", "constraint_eval.fib_air_fp252", "prove")
+
+
+def _pmc_child_main(pl):
+    """--pmc-child: every object's workload, warm once, then once between markers (order = _PMC_OBJECTS)."""
+    import ctypes
+    from ministark_amd import GOLDILOCKS_FP, GpuVec
+    mark = GpuVec(pl, _PMC_MARK, GOLDILOCKS_FP)
+    one = np.array([1], dtype=np.uint64)
+    seen = []
+
+    def marker():
+        pl.lib.check(pl.lib.ms_fill(pl.handle, GOLDILOCKS_FP, _PMC_MARK, mark.ptr, one.ctypes.data))
+
+    def pmc(name, run):
+        run(); pl.sync()
+        marker()
+        run(); pl.sync()
+        marker()
+        pl.sync()
+        seen.append(name)
+    bench_lde_commit(pl, False, pmc=pmc)
+    bench_lde_2_24(pl, pmc=pmc)
+    bench_constraint_eval(pl, False, pmc=pmc)
+    bench_prove(pl, False, pmc=pmc)
+    if tuple(seen) != _PMC_OBJECTS:
+        raise SystemExit(f"pmc child: objects {seen}")
+
+
+def _measure_objects():
+    """-> {object: {kernel: {counter: sum over the launches of ONE run of the workload}}} or None (no rocprofv3, being profiled, a pass failed)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("MS_BENCH_NO_PMC") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    res = {name: {} for name in _PMC_OBJECTS}
+    mark_grid = ((_PMC_MARK + 255) // 256) * 256
+    work = tempfile.mkdtemp(prefix="ms_pmc_obj_", dir="/tmp")
+    try:
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), _PMC_SQ):
+            out = os.path.join(work, counters[0])
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child"]
+            env = dict(os.environ, MS_BENCH_NO_PMC="1", TMPDIR="/tmp")
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                return None
+            hits = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not hits:
+                return None
+            rows = list(csv.DictReader(open(hits[0])))
+            rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+            window, inside, last_id = -1, False, None
+            for r in rows:
+                name = r["Kernel_Name"]
+                if "k_fill" in name and int(float(r["Grid_Size"])) == mark_grid:
+                    if r.get("Dispatch_Id") != last_id:             # one marker launch has a row per counter
+                        last_id = r.get("Dispatch_Id")
+                        inside = not inside
+                        if inside:
+                            window += 1
+                    continue
+                if not inside or not 0 <= window < len(_PMC_OBJECTS):
+                    continue
+                k = name.split("(")[0].replace("void ", "")
+                d = res[_PMC_OBJECTS[window]].setdefault(k, {})
+                d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            if window != len(_PMC_OBJECTS) - 1 or inside:
+                return None
+        return res
+    except Exception:                                            # noqa: BLE001 -- an extra: the objects then say why their fields are null
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def _attach_resources(roof, counters, kernel_us_total, elements, only=None, per="element"):
+    """Fill a roofline object from the measured counters: HBM traffic next to the algorithmic bytes, and the vector ALU next to HBM
+    ("report VALU utilisation and instruction counts next to GB/s").  only: substrings of the kernel names that belong
+    to this object (None = every launch of the workload)."""
+    if counters is None:
+        roof["traffic_source"] = "not measured (rocprofv3 absent, the run itself profiled, or a counter pass failed)"
+        return roof
+    sel = {k: v for k, v in counters.items() if only is None or any(t in k for t in only)}
+    tot = lambda c: sum(v.get(c, 0.0) for v in sel.values())
+    fetch, write = 2.0 * 1024 * tot("FETCH_SIZE"), 1024.0 * tot("WRITE_SIZE")
+    insts, active, busy = tot("SQ_INSTS_VALU"), tot("SQ_ACTIVE_INST_VALU"), tot("SQ_BUSY_CYCLES")
+    roof["traffic"] = fetch + write
+    roof["traffic_fetch_bytes"], roof["traffic_write_bytes"] = fetch, write
+    roof["traffic_over_algorithmic"] = round((fetch + write) / roof["algorithmic_bytes"], 2) if roof.get("algorithmic_bytes") else None
+    roof["traffic_source"] = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (three child runs of every object's workload, cut at marker launches)"
+    t = kernel_us_total * 1e-6
+    roof["hbm_frac_of_traffic"] = round((fetch + write) / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None
+    roof["valu_insts_per_" + per] = round(insts * 64.0 / elements, 1) if elements else None
+    roof["valu_busy"] = round((active * 4.0 / 1024) / (busy / 32.0), 3) if busy else None
+    roof["frac_of_valu_issue_peak"] = round(insts / t / VALU_ISSUE_PEAK, 4) if t > 0 else None
+    roof["bound_measured"] = ("valu" if (roof["frac_of_valu_issue_peak"] or 0) > (roof["hbm_frac_of_traffic"] or 0) else "hbm")
+    roof["counters_by_kernel"] = {
+        k[-60:]: {"valu_insts_per_" + per: round(v.get("SQ_INSTS_VALU", 0.0) * 64.0 / elements, 1) if elements else None,
+                  "valu_quad_cycles_per_inst": round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_INSTS_VALU"], 3) if v.get("SQ_INSTS_VALU") else None,
+                  "valu_busy": round((v.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024) / (v["SQ_BUSY_CYCLES"] / 32.0), 3) if v.get("SQ_BUSY_CYCLES") else None,
+                  "fetch_bytes": 2.0 * 1024 * v.get("FETCH_SIZE", 0.0), "write_bytes": 1024.0 * v.get("WRITE_SIZE", 0.0)}
+        for k, v in sorted(sel.items())}
+    return roof
+
+
+def _attach_all(obj, pmc):
+    """Every roofline object of the line carries a note ("_res") of what its counters are; they are measured AFTER all timed work (a
+    counter session leaves the device in the profiler's clock state for a while: measured first, the objects timed after it ran up to
+    three times slower) and attached here."""
+    if isinstance(obj, dict):
+        note = obj.pop("_res", None)
+        if note is not None:
+            name, us, elements, only, per = note
+            _attach_resources(obj, None if pmc is None else pmc.get(name), us, elements, only=only, per=per)
+        for v in list(obj.values()):
+            _attach_all(v, pmc)
+
+
 def _profiled(pl, fn, reps, after_wall=None):
     """-> (wall seconds per call, {kernel: microseconds per call}).  The wall clock is taken WITHOUT the per-launch
     hipEvents (a pair per kernel, ~150 launches per prover run, costs 15-20 % of the wall time); the kernel times come
@@ -286,7 +423,7 @@ def bench_c2_sweep(pl):
     return out
 
 
-def bench_lde_commit(pl, with_cpu):
+def bench_lde_commit(pl, with_cpu, pmc=None):
     """configs[2] (C3): 2^20 rows x 32 columns, blow-up 8, coset NTT + Merkle commit on one GPU."""
     import numpy as np
     from ministark_amd import GOLDILOCKS_FP, Matrix, MerkleTree
@@ -302,6 +439,11 @@ def bench_lde_commit(pl, with_cpu):
         state.clear()
         lde = trace.lde(1 << log_b, 7, True)
         state["root"] = MerkleTree.from_matrix(lde).root()
+    if pmc is not None:
+        pmc("lde_commit", run)
+        for c in trace.columns:
+            c.free()
+        return None
     wall, k = _profiled(pl, run, 3)
     lde_us = sum(v for name, v in k.items() if name.startswith(("ntt", "lde2")))     # iNTT passes + the two passes per coset
     lde_bytes = float(ncols) * (n * 8 + N * 8)
@@ -314,6 +456,8 @@ def bench_lde_commit(pl, with_cpu):
            "commit": {"bound": "integer ALU (SHA-256)", "algorithmic_bytes": hash_bytes,
                       "compressions_per_s": round((N * (ncols * 8 // 64 + 1) + 2 * N) / (sum(v for nm, v in k.items() if nm.startswith("sha256")) * 1e-6), 0)},
            "root": state["root"].hex()}
+    out["roofline"]["_res"] = ("lde_commit", lde_us, float(ncols) * N, ("msntt", "mslde2"), "output_point")
+    out["commit"]["_res"] = ("lde_commit", sum(v for nm, v in k.items() if nm.startswith("sha256")), float(N) * (ncols * 8 // 64 + 1) + 2.0 * N, ("mssha",), "compression")
     if with_cpu:
         from oracle import cref
         t0 = time.perf_counter()
@@ -327,7 +471,7 @@ def bench_lde_commit(pl, with_cpu):
     return out
 
 
-def bench_lde_2_24(pl):
+def bench_lde_2_24(pl, pmc=None):
     """The LDE the prover of configs[4] runs (src/prover.rs:50-51, src/matrix.rs:245): 2^22 rows x 8 columns, blow-up 4 -> 2^24-point
     bit-reversed evaluations, in the order the prover asks for (natural in, bit-reversed out).  Since round 4 the coset transforms are
     two passes each (lde2_kernels.h, rows of 16384 words); the iNTT in front of them is the three-pass 2^22-point plan."""
@@ -343,21 +487,29 @@ def bench_lde_2_24(pl):
     def run():
         keep.clear()
         keep["lde"] = trace.lde(1 << log_b, 7, True)
+    if pmc is not None:
+        pmc("lde_2_24", run)
+        keep.clear()
+        for c in trace.columns:
+            c.free()
+        return None
     wall, k = _profiled(pl, run, 5)
     us = sum(k.values())
     alg = float(ncols) * (n * 8 + N * 8)                        # n s + beta n s per column
     moved = float(ncols) * (3 * 2 * n * 8 + (n * 8 + N * 8) + 2 * N * 8)    # what the passes read + write when nothing is re-read from cache
     for c in trace.columns:
         c.free()
-    return {"workload": "2^22 rows x 8 columns (Fp), blow-up 4: interpolate + bit-reversed coset evaluation on the 2^24-point domain (configs[4]'s base-trace LDE)",
-            "wall_ms": round(wall * 1e3, 3), "kernel_us": k, "us_per_column": round(us / ncols, 1),
-            "roofline": {"bound": "hbm", "kernel": "ntt_pass1-3 (iNTT, 2^22 points) + lde2_pass_a + lde2_pass_b", "algorithmic_bytes": alg,
-                         "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "bytes_the_passes_move": moved, "moved_over_algorithmic": round(moved / alg, 2)}}
+    out = {"workload": "2^22 rows x 8 columns (Fp), blow-up 4: interpolate + bit-reversed coset evaluation on the 2^24-point domain (configs[4]'s base-trace LDE)",
+           "wall_ms": round(wall * 1e3, 3), "kernel_us": k, "us_per_column": round(us / ncols, 1),
+           "roofline": {"bound": "hbm", "kernel": "ntt_pass1-3 (iNTT, 2^22 points) + lde2_pass_a + lde2_pass_b", "algorithmic_bytes": alg,
+                        "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "bytes_the_passes_move": moved, "moved_over_algorithmic": round(moved / alg, 2)}}
+    out["roofline"]["_res"] = ("lde_2_24", us, float(ncols) * N, None, "output_point")
+    return out
 
 
-def bench_prove(pl, with_cpu):
+def bench_prove(pl, with_cpu, pmc=None):
     """configs[4] on one GPU = BASELINE's "end-to-end prove time": ministark_amd/pipeline.py, 2^22 rows x 8 columns."""
     import numpy as np
     from ministark_amd import GOLDILOCKS_FP, Matrix, pipeline
@@ -373,6 +525,12 @@ def bench_prove(pl, with_cpu):
     def run():
         res.clear()
         res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, ce_blowup=ce))
+    if pmc is not None:
+        pmc("prove", run)
+        res.clear()
+        for c in trace.columns:
+            c.free()
+        return None
     phases = {}
     wall, k = _profiled(pl, run, 5, after_wall=lambda: phases.update(res["phases_ms"]))      # phases of a run without events
     n_lde, n_ce = n_t * blowup, n_t * ce
@@ -389,6 +547,7 @@ def bench_prove(pl, with_cpu):
                         "achieved": round(alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
            "base_root": res["base_root"].hex(), "nonce": res["nonce"]}
+    out["roofline"]["_res"] = ("prove", kernel_ms * 1e3, float(n_t) * ncols, None, "trace_cell")
     for c in trace.columns:
         c.free()
     out["native_host"] = _native_prove(log_t)
@@ -430,7 +589,7 @@ def _native_prove(log_rows, reps=5):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def bench_constraint_eval(pl, with_cpu):
+def bench_constraint_eval(pl, with_cpu, pmc=None):
     """configs[3] (C4): constraint composition evaluation on 2^23 points, three AIRs:
     (i) the reference's fib AIR, 8 Fp columns; (ii) 17 Fp + 9 Fq3 columns (the brainfuck shape); (iii) the fib AIR over the
     252-bit field.  Algorithmic bytes = sum over columns of n s_col + n s_Fq for the result (x is generated on the fly)."""
@@ -468,6 +627,10 @@ def bench_constraint_eval(pl, with_cpu):
 
         def run():
             res["out"] = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, dbase, dext)
+        if pmc is not None:
+            pmc("constraint_eval." + key, run)
+            del dbase, dext, res
+            continue
         wall, k = _profiled(pl, run, 5)
         us = sum(k.values())
         alg = float(bytes_per_point) * n
@@ -475,6 +638,7 @@ def bench_constraint_eval(pl, with_cpu):
                "roofline": {"bound": "hbm" if key == "fib_air_fp" else "integer ALU (extension-field / 252-bit products) over an HBM stream",
                             "algorithmic_bytes": alg, "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}}
+        obj["roofline"]["_res"] = ("constraint_eval." + key, us, float(n), None, "point")
         if with_cpu:
             from oracle import cref
             m = 1 << cpu_log                                   # bounded sample: the first 2^cpu_log points of the same columns
@@ -491,7 +655,7 @@ def bench_constraint_eval(pl, with_cpu):
                 obj["cpu_baseline"]["matches_device"] = bool(np.array_equal(res["out"].to_numpy(), want))
         out[key] = obj
         del dbase, dext, res
-    return out
+    return None if pmc is not None else out
 
 
 def _spawn_ranks(n):
@@ -540,6 +704,7 @@ def main():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
     ap.add_argument("--mode", choices=["ntt", "lde-commit"], default="ntt", help="lde-commit: only the column-sharded LDE + commitment (any N)")
     ap.add_argument("--no-extras", action="store_true", help="skip the lde_commit / prove / sharded objects")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: every object's workload between marker launches, under rocprofv3 --pmc")
     ap.add_argument("--log-rows", type=int, default=22, help="--mode lde-commit: rows of the trace (configs[4]: 2^22)")
     ap.add_argument("--total-cols", type=int, default=32, help="--mode lde-commit: columns of the trace, sharded over the ranks")
     args = ap.parse_args()
@@ -582,6 +747,10 @@ def main():
         pl = Planner(local_rank if on_gpu else 0, _lib.Lib(lib_path))     # the simulator has one device
     else:
         pl = Planner(local_rank)
+    if args.pmc_child:                                           # under rocprofv3 --pmc (see _measure_objects): no line, no timing
+        _pmc_child_main(pl)
+        pl.sync()
+        return
 
     def reduce_max(x):
         if dist is None:
@@ -718,15 +887,7 @@ def main():
     achieved = alg_bytes_col / us_per_transform / 1e3 if us_per_transform else 0.0
     # HBM bytes per transform: measured now by two short PMC child runs (FETCH_SIZE, WRITE_SIZE; default single-GPU run only), else
     # from the summary of the same passes under profiles/ (scripts/collect_profiles.sh), named in `traffic_source`
-    traffic, traffic_source, traffic_kernels = None, None, None
-    if world == 1 and not args.no_extras:
-        measured = _measure_traffic(log_n)
-        if measured is not None:
-            traffic, traffic_kernels = measured
-            traffic_source = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child runs of 2 columns x 2 steps), per launch and column"
-    if traffic is None and args.traffic_json and os.path.exists(args.traffic_json):
-        traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_transform")
-        traffic_source = os.path.relpath(args.traffic_json, ROOT)
+    traffic, traffic_source, traffic_kernels = None, None, None      # filled in at the END of the run (counter sessions disturb what is timed after them)
     out = {
         "metric": "2^24-point Goldilocks NTT algorithmic bandwidth", "value": round(value, 2), "unit": "GB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -800,6 +961,17 @@ def main():
         out["cpu_baseline"] = {"value": round(alg_bytes_col / best / 1e9, 3), "unit": "GB/s", "cores": cref.num_threads(),
                                "kind": "port", "ms_per_transform": round(best * 1e3, 2),
                                "sample": f"{reps} x one 2^{log_n} column, forward coset NTT, oracle/c (C/OpenMP restatement, not the reference binary)"}
+    if world == 1 and not args.no_extras:                        # counters last: nothing is timed after a profiler session
+        pl.sync()
+        measured = _measure_traffic(log_n)
+        if measured is not None:
+            traffic, traffic_kernels = measured
+            traffic_source = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child runs of 2 columns x 2 steps), per launch and column"
+        _attach_all({k: out[k] for k in ("lde_commit", "lde_2_24", "constraint_eval", "prove") if isinstance(out.get(k), dict)}, _measure_objects())
+    if traffic is None and args.traffic_json and os.path.exists(args.traffic_json):
+        traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_transform")
+        traffic_source = os.path.relpath(args.traffic_json, ROOT)
+    out["roofline"].update({"traffic": traffic, "traffic_source": traffic_source, "traffic_kernels": traffic_kernels})
     _emit(out)
     if dist is not None:
         dist.destroy_process_group()

@@ -190,6 +190,15 @@ int ms_sha256_rows_row_major(ms_ctx* ctx, int field, size_t nrows, unsigned ncol
  * d_x_lde may be NULL (x generated on the fly from h_domain_offset; a caller-supplied x array
  * disables the rewrites that rely on x_i = offset * w^i); d_out has 2^log_n elements of out_field.
  * At most 16 periodic columns.  Asynchronous. */
+/* The opcodes as values: the ONE table the three lowerings of the expression DAG are generated from (scripts/gen_opcodes.py writes the
+ * marked blocks of ministark_amd/expr.py, ministark_amd/csrc/host/expr.hpp and rust/src/eval_hip.rs; tests/test_opcode_tables.py
+ * re-runs it in check mode and compares the kernels' own enum, csrc/eval_kernels.h, with it). */
+enum ms_eval_op {
+    MS_OP_X_P = 0, MS_OP_CONST_P = 1, MS_OP_CONST_Q = 2, MS_OP_TRACE_P = 3, MS_OP_TRACE_Q = 4, MS_OP_PERIODIC_P = 5, MS_OP_PERIODIC_Q = 6,
+    MS_OP_NEG_P = 7, MS_OP_NEG_Q = 8, MS_OP_ADD_PP = 9, MS_OP_ADD_QQ = 10, MS_OP_ADD_QP = 11, MS_OP_MUL_PP = 12, MS_OP_MUL_QQ = 13,
+    MS_OP_MUL_QP = 14, MS_OP_INV_P = 15, MS_OP_INV_Q = 16, MS_OP_POW_P = 17, MS_OP_POW_Q = 18, MS_OP_EMBED = 19, MS_OP_STORE_Q = 20,
+    MS_OP_STORE_P = 21, MS_OP_PUBLIC_COUNT = 22
+};
 int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
                     unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
                     const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,

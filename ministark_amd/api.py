@@ -263,6 +263,10 @@ def merkle_view_ids(n, indices, lib=None):
 
 def _merkle_view_ids_arrays(n, indices, lib):
     """merkle_view_ids through the library, as numpy arrays (what the gathers take: no list round trip)"""
+    if not isinstance(indices, np.ndarray) or indices.dtype.kind != "u":          # validated as Python ints: a negative index is out of
+        for i in indices:                                                         # bounds, not an OverflowError of the conversion below
+            if not 0 <= int(i) < n:
+                raise IndexError(f"leaf index {int(i)} out of bounds ({n})")     # Error::LeafIndexOutOfBounds
     idx = np.asarray(indices, dtype=np.uint64)
     if idx.size and int(idx.max()) >= n:
         raise IndexError(f"leaf index {int(idx.max())} out of bounds ({n})")     # Error::LeafIndexOutOfBounds

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
     // PTS * npoints denominators of one lane) is pooled over the workgroup: lane l of ONE wave inverts the product of the four waves'
     // lane-l products and hands each its own inverse back (nine more products on that wave, two barriers) -- a quarter of the
     // inversions.  The inverting wave rotates with the workgroup so that the serial chains spread over a CU's SIMDs.
+    static_assert(NT == 256, "the pooled inversion is written for four waves of 64 lanes (a[4], blockIdx.x & 3)");
     __shared__ uint64_t pool[NT * PW];
     {
         const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -76,7 +76,7 @@ extern "C" int ms_ctx_destroy(ms_ctx* ctx) {
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     if (ctx->prog_buf) (void)hipFree(ctx->prog_buf);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
-    if (ctx->land) (void)hipHostFree(ctx->land);
+    { std::lock_guard<std::mutex> lk(ctx->land_mu); if (ctx->land) (void)hipHostFree(ctx->land); ctx->land = nullptr; }
     for (auto m : ctx->jit_modules) (void)hipModuleUnload(m);
     if (ctx->stream2) { (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     (void)hipStreamDestroy(ctx->stream);
@@ -222,18 +222,24 @@ extern "C" int ms_copy(ms_ctx* ctx, void* d_dst, const void* d_src, size_t bytes
 }
 extern "C" int ms_upload(ms_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    if (bytes && (!d_dst || !h_src)) return fail(MS_ERR_INVALID, "ms_upload: null argument");
+    if (!bytes) return MS_OK;
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MS_OK;
 }
 extern "C" int ms_download(ms_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     if (!ctx) return fail(MS_ERR_INVALID, "null context");
+    if (bytes && (!h_dst || !d_src)) return fail(MS_ERR_INVALID, "ms_download: null argument");
+    if (!bytes) return MS_OK;
+    HIPCHK(hipSetDevice(ctx->device));                            // several contexts (devices) may live in one process
     static constexpr size_t LAND = (size_t)256 << 10;
-    if (bytes && bytes <= LAND) {                                 // small: through the pinned landing buffer
+    if (bytes <= LAND) {                                          // small: through the pinned landing buffer
         std::lock_guard<std::mutex> lk(ctx->land_mu);
         if (!ctx->land) {
             void* p = nullptr;
-            if (hipHostMalloc(&p, LAND, 0) == hipSuccess) ctx->land = (char*)p; else (void)hipGetLastError();
+            if (hipHostMalloc(&p, LAND, hipHostMallocPortable) == hipSuccess) ctx->land = (char*)p; else (void)hipGetLastError();
         }
         if (ctx->land) {
             HIPCHK(hipMemcpyAsync(ctx->land, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));

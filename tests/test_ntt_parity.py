@@ -555,3 +555,39 @@ def test_batch_wider_than_a_launch_emu():
 @pytest.mark.parametrize("log_n,inverse,ncols", [(10, False, 260), (12, False, 131), (14, True, 129), (16, False, 130)])
 def test_batch_wider_than_a_launch_hip(log_n, inverse, ncols):
     _run("hip", GOLDILOCKS_FP, log_n, inverse, 7, ncols=ncols)
+
+
+@pytest.mark.gpu
+def test_two_pass_2_18_handles_do_not_leak_hip():
+    """Handles of the 2^18 two-pass forward route (a fresh GpuFft per Matrix.evaluate) use the CACHED plan's tables: creating and
+    destroying many of them neither rebuilds nor leaks device memory (round-4 advisor finding, ms_ntt.cpp plan_run)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+
+    def free_bytes():
+        assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
+        return free_b.value
+    pl = backends.planner("hip")
+    log_n = 18
+    x = _rand(1 << log_n, 5)
+    want = cref.ntt(x, log_n, 1, False, 7)
+    dom = Radix2EvaluationDomain(1 << log_n, 7)
+
+    def once():
+        v = GpuVec.from_numpy(pl, x, GOLDILOCKS_FP)
+        plan = GpuFft(dom, GOLDILOCKS_FP, pl)
+        plan.encode(v)
+        plan.execute()
+        got = v.to_numpy()
+        plan.close()
+        v.free()
+        return got
+    assert np.array_equal(once(), want)
+    pl.sync()
+    before = free_bytes()
+    for _ in range(300):
+        got = once()
+    pl.sync()
+    assert np.array_equal(got, want)
+    assert before - free_bytes() < (8 << 20), f"device memory shrank by {before - free_bytes()} bytes over 300 handles"
