@@ -298,28 +298,43 @@ class OpeningBatch:
     `root` in one exchange and one download, and returns the assembled results there (None elsewhere).  The sizes are functions of the
     positions alone, so every rank computes every rank's byte counts without talking."""
 
+    EAGER_BYTES = 1 << 20                                       # one pooled block: the openings of a proof are a few hundred KiB
+
     def __init__(self, planner, comm, root=0):
         self.planner, self.comm, self.root, self.reqs = planner, comm, root, []
+        self.arena, self.used, self.eager = DeviceBytes(planner, self.EAGER_BYTES), 0, True
 
     def add(self, sizes, run, parse):
-        """sizes[q]: bytes rank q contributes; run(ptr): this rank's gathers into ptr .. ptr + sizes[rank]; parse(chunks): chunks[q] = rank q's bytes"""
-        self.reqs.append((list(sizes), run, parse))
+        """sizes[q]: bytes rank q contributes; run(ptr): this rank's gathers into ptr .. ptr + sizes[rank]; parse(chunks): chunks[q] = rank q's bytes.
+        The gathers are LAUNCHED HERE, behind the previous request's, while the host walks the next request's index lists (they all land
+        in one arena in request order); a batch that outgrows the arena is gathered again as a whole in `execute`."""
+        sizes = list(sizes)
+        mine = sizes[self.comm.rank]
+        if self.eager and self.used + mine <= self.EAGER_BYTES:
+            if mine:
+                run(self.arena.ptr + self.used)
+            self.used += mine
+        else:
+            self.eager = False
+        self.reqs.append((sizes, run, parse))
         return len(self.reqs) - 1
 
     def execute(self):
         pl, comm, G, r = self.planner, self.comm, self.comm.world, self.comm.rank
         totals = [sum(sz[q] for sz, _, _ in self.reqs) for q in range(G)]
-        arena = DeviceBytes(pl, max(8, totals[r]))
-        off = 0
-        for sz, run, _ in self.reqs:
-            if sz[r]:
-                run(arena.ptr + off)
-                off += sz[r]
+        arena = self.arena
+        if not self.eager:
+            arena = DeviceBytes(pl, max(8, totals[r]))
+            off = 0
+            for sz, run, _ in self.reqs:
+                if sz[r]:
+                    run(arena.ptr + off)
+                    off += sz[r]
         got = _collect(pl, comm, arena, totals, self.root)
         if r != self.root:
             return [None] * len(self.reqs)
-        raw = got.to_numpy()
         base = np.concatenate([[0], np.cumsum(totals)]).astype(np.int64)
+        raw = got.to_numpy(int(base[-1]))                         # what was gathered, not the arena's capacity
         cur = [int(b) for b in base[:-1]]
         out = []
         for sz, _, parse in self.reqs:

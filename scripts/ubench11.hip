@@ -280,6 +280,23 @@ __global__ void __launch_bounds__(512, 4) k_handoff(Ctl* ctl, uint64_t* buf, uin
     if (acc == 0x123456789abcull) sink[0] = acc;
 }
 
+// read the wide pattern (256 rows at stride 2^16 words, 64-word runs), write either ONE contiguous 128 KiB block per tile (WR = 0)
+// or the local pattern (256 runs at stride 2^8 words inside a 512 KiB block, WR = 1): what a plan with [j2][j3][k1] as its
+// intermediate layout would do in its first / last pass (only two of the six streams would then be wide)
+template <int WR>
+__global__ void __launch_bounds__(512, 4) k_mixed(Cols C) {
+    __shared__ uint64_t lds[8192];
+    const unsigned t = threadIdx.x, c = t & 63, r0 = t >> 6, b = blockIdx.x;
+    const uint64_t* __restrict__ src = C.src[blockIdx.y] + (size_t)b * 64;
+    uint64_t* __restrict__ dst = C.dst[blockIdx.y] + (WR == 0 ? (size_t)b * 16384 : (size_t)(b >> 2) * 65536 + (size_t)(b & 3) * 64);
+    uint64_t v[32];
+    #pragma unroll
+    for (int i = 0; i < 32; i++) v[i] = ld_nt(src, ((r0 + 8 * i) << 16) + c);
+    tile_work<32, 0>(v, lds);
+    #pragma unroll
+    for (int i = 0; i < 32; i++) st_nt(dst, WR == 0 ? (r0 + 8 * i) * 64 + c : ((r0 + 8 * i) << 8) + c, v[i]);
+}
+
 static uint64_t *IN[NCOL], *SCR[NCOL], *OUT[NCOL], *STAGE;
 static Ctl* CTL;
 static int g_launches = 10, g_reps = 7;
@@ -348,12 +365,20 @@ static void handoff() {
     snprintf(nm, sizeof nm, "handoff: store 64 KiB, team barrier, load a team mate's 64 KiB (%s loads), %d teams/XCD, 8 rounds", NTLD ? "nt" : "default", TEAMS);
     timeit(nm, [&] { reset_ctl(); hipLaunchKernelGGL((k_handoff<TEAMS, NTLD>), dim3(8 * TEAMS * 16), dim3(512), 0, 0, CTL, SCR[0], SCR[1], 8); });
 }
+template <int WR>
+static void mixed() {
+    Cols C; for (int c = 0; c < NCOL; c++) { C.src[c] = IN[c]; C.dst[c] = SCR[c]; }
+    char nm[200];
+    snprintf(nm, sizeof nm, "mixed: wide reads (stride 2^16 words), %s, nt, units 0", WR == 0 ? "one contiguous 128 KiB block written per tile" : "local writes (stride 2^8 words inside 512 KiB)");
+    timeit(nm, [&] { hipLaunchKernelGGL((k_mixed<WR>), dim3(1024, NCOL), dim3(512), 0, 0, C); });
+}
 struct Variant { const char* id; void (*fn)(); };
 static void ref16_0() { tile256<0>(16, "pass 1 / 3 of the shipped plan"); }
 static void ref16_8() { tile256<8>(16, "pass 1 / 3 of the shipped plan"); }
 static void ref8_0() { tile256<0>(8, "pass 2 of the shipped plan"); }
 static void ref12_0() { tile256<0>(12, "a pass-A tile without the team"); }
 static const Variant VARIANTS[] = {
+    {"mixed_contig", mixed<0>}, {"mixed_local", mixed<1>},
     {"ref16_0", ref16_0}, {"ref16_8", ref16_8}, {"ref8_0", ref8_0}, {"ref12_0", ref12_0},
     {"A64_t4_ip_0", teamA<64, 0, 0, 4, true>}, {"A64_t2_ip_0", teamA<64, 0, 0, 2, true>}, {"A64_t3_ip_0", teamA<64, 0, 0, 3, true>},
     {"A32_t4_ip_0", teamA<32, 0, 0, 4, true>}, {"A64_t4_slab_0", teamA<64, 0, 0, 4, false>}, {"A64_t2_slab_0", teamA<64, 0, 0, 2, false>},
