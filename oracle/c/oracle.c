@@ -145,12 +145,49 @@ static inline size_t bitrev(size_t i, unsigned log_n) {
  * bit_reverse_ce_trace, a reversal of the size-`prefix` prefix). */
 void oracle_bit_reverse(uint64_t* data, unsigned log_n, unsigned V) {
     size_t n = (size_t)1 << log_n;
-    #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; i++) {
-        size_t j = bitrev(i, log_n);
-        if (j > i) for (unsigned v = 0; v < V; v++) {
-            uint64_t t = data[i*V+v]; data[i*V+v] = data[j*V+v]; data[j*V+v] = t;
+    enum { T = 7 };                                           /* tiles of 128 x 128 elements */
+    if (log_n < 2 * T + 2) {
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; i++) {
+            size_t j = bitrev(i, log_n);
+            if (j > i) for (unsigned v = 0; v < V; v++) {
+                uint64_t t = data[i*V+v]; data[i*V+v] = data[j*V+v]; data[j*V+v] = t;
+            }
         }
+        return;
+    }
+    /* The same permutation tile by tile (round 5: the element-by-element swap above misses the cache twice per element and was 40 %
+     * of the 2^24-point transform's time): i = (hi, mid, lo) with 7-bit hi and lo; new[(hi, mid, lo)] = old[(rev lo, rev mid, rev hi)],
+     * so the tile `mid` is the transposed, row- and column-reversed tile `rev mid`: both are read with contiguous rows into buffers
+     * and written back with contiguous rows. */
+    const unsigned mb = log_n - 2 * T;
+    const size_t R = (size_t)1 << T, tile = R * R;
+    size_t rv[1 << T];
+    for (size_t i = 0; i < R; i++) rv[i] = bitrev(i, T);
+    #pragma omp parallel
+    {
+        uint64_t* A = (uint64_t*)malloc(tile * V * sizeof(uint64_t));
+        uint64_t* B = (uint64_t*)malloc(tile * V * sizeof(uint64_t));
+        #pragma omp for schedule(dynamic, 4)
+        for (size_t mid = 0; mid < ((size_t)1 << mb); mid++) {
+            size_t rm = bitrev(mid, mb);
+            if (rm < mid) continue;
+            for (size_t hi = 0; hi < R; hi++) {
+                memcpy(A + hi * R * V, data + (((hi << mb) | mid) << T) * V, R * V * sizeof(uint64_t));
+                if (rm != mid) memcpy(B + hi * R * V, data + (((hi << mb) | rm) << T) * V, R * V * sizeof(uint64_t));
+            }
+            const uint64_t* from_rm = rm != mid ? B : A;
+            for (size_t hi = 0; hi < R; hi++) {
+                uint64_t* o1 = data + (((hi << mb) | mid) << T) * V;       /* new tile mid  <- old tile rm  */
+                uint64_t* o2 = data + (((hi << mb) | rm) << T) * V;        /* new tile rm   <- old tile mid */
+                for (size_t lo = 0; lo < R; lo++) {
+                    const size_t src = (rv[lo] * R + rv[hi]) * V;
+                    for (unsigned v = 0; v < V; v++) o1[lo * V + v] = from_rm[src + v];
+                    if (rm != mid) for (unsigned v = 0; v < V; v++) o2[lo * V + v] = A[src + v];
+                }
+            }
+        }
+        free(A); free(B);
     }
 }
 
@@ -160,7 +197,7 @@ void oracle_bit_reverse(uint64_t* data, unsigned log_n, unsigned V) {
  *   forward: x_i *= offset^i ; DFT(root)
  *   inverse: DFT(root) ; x_i *= scale * offset^i   (root = gen^-1,
  *            offset = offset^-1, scale = n^-1 supplied by the caller)      */
-static void ntt_core(uint64_t* a, unsigned log_n, unsigned V, const uint64_t* tw /* n/2 powers of root */) {
+static void ntt_core_plain(uint64_t* a, unsigned log_n, unsigned V, const uint64_t* tw /* n/2 powers of root */) {
     size_t n = (size_t)1 << log_n;
     oracle_bit_reverse(a, log_n, V);
     for (unsigned s = 1; s <= log_n; s++) {
@@ -178,6 +215,69 @@ static void ntt_core(uint64_t* a, unsigned log_n, unsigned V, const uint64_t* tw
         }
     }
 }
+/* The same butterflies -- the same pairs, the same twiddle tw[(lo mod half) * (n >> s)], exact field arithmetic, hence the same words --
+ * taken in a cache-friendly order (round 5: the plain loop above sweeps the whole column once per stage, 24 sweeps of 128 MiB at
+ * 2^24 points, and made the CPU baseline of bench.py look slower than a parallel CPU FFT is): stages 1..12 block by block on
+ * contiguous 4096-point blocks, the later stages ten at a time on tiles of 1024 rows x 8 adjacent points gathered into a buffer
+ * that stays in the core's cache (the shape of ark-poly's parallel FFT: independent sub-FFTs per chunk, src/domain/radix2/fft.rs). */
+static void ntt_core(uint64_t* a, unsigned log_n, unsigned V, const uint64_t* tw) {
+    enum { B0 = 12, G = 10, W = 8 };
+    if (log_n <= B0) { ntt_core_plain(a, log_n, V, tw); return; }
+    size_t n = (size_t)1 << log_n;
+    oracle_bit_reverse(a, log_n, V);
+    #pragma omp parallel for schedule(static)
+    for (size_t b = 0; b < (n >> B0); b++) {
+        uint64_t* x = a + (b << B0) * V;
+        for (unsigned s = 1; s <= B0; s++) {
+            size_t m = (size_t)1 << s, half = m >> 1, tstride = n >> s;
+            for (size_t k = 0; k < ((size_t)1 << (B0 - 1)); k++) {
+                size_t blk = k / half, i = k % half, lo = blk * m + i, hi = lo + half;
+                uint64_t w = tw[i * tstride];
+                for (unsigned v = 0; v < V; v++) {
+                    uint64_t u = x[lo*V+v], t = gl_mul(x[hi*V+v], w);
+                    x[lo*V+v] = gl_add(u, t);
+                    x[hi*V+v] = gl_sub(u, t);
+                }
+            }
+        }
+    }
+    for (unsigned s0 = B0; s0 < log_n; ) {
+        unsigned s1 = s0 + G < log_n ? s0 + G : log_n;
+        size_t rows = (size_t)1 << (s1 - s0), lows = (size_t)1 << s0, tiles = (n >> s1) * (lows / W);
+        #pragma omp parallel
+        {
+            uint64_t* buf = (uint64_t*)malloc(rows * W * V * sizeof(uint64_t));
+            #pragma omp for schedule(static)
+            for (size_t t = 0; t < tiles; t++) {
+                size_t h = t / (lows / W), i0 = (t % (lows / W)) * W;
+                uint64_t* base = a + ((h << s1) + i0) * V;
+                for (size_t q = 0; q < rows; q++) memcpy(buf + q * W * V, base + (q << s0) * V, W * V * sizeof(uint64_t));
+                for (unsigned s = s0 + 1; s <= s1; s++) {
+                    size_t hq = (size_t)1 << (s - 1 - s0), tstride = n >> s;
+                    for (size_t q = 0; q < rows; q++) {
+                        if (q & hq) continue;
+                        size_t lowpart = ((q & (hq - 1)) << s0) + i0;          /* lo mod half, for j = 0 */
+                        for (size_t j = 0; j < W; j++) {
+                            uint64_t w = tw[(lowpart + j) * tstride];
+                            uint64_t* plo = buf + (q * W + j) * V;
+                            uint64_t* phi = buf + ((q + hq) * W + j) * V;
+                            for (unsigned v = 0; v < V; v++) {
+                                uint64_t u = plo[v], tt = gl_mul(phi[v], w);
+                                plo[v] = gl_add(u, tt);
+                                phi[v] = gl_sub(u, tt);
+                            }
+                        }
+                    }
+                }
+                for (size_t q = 0; q < rows; q++) memcpy(base + (q << s0) * V, buf + q * W * V, W * V * sizeof(uint64_t));
+            }
+            free(buf);
+        }
+        s0 = s1;
+    }
+}
+/* test hook: the plain stage-by-stage loop on its own (tests compare the blocked order with it at sizes the big-integer oracle cannot reach) */
+void oracle_ntt_stages_plain(uint64_t* a, unsigned log_n, unsigned V, const uint64_t* tw_unused, uint64_t root_mont);
 static uint64_t* make_twiddles(unsigned log_n, uint64_t root) {
     size_t half = ((size_t)1 << log_n) / 2;
     if (half == 0) half = 1;
@@ -204,6 +304,17 @@ static void distribute_powers(uint64_t* a, size_t n, unsigned V, uint64_t g, uin
             x = gl_mul(x, g);
         }
     }
+}
+void oracle_ntt_stages_plain(uint64_t* a, unsigned log_n, unsigned V, const uint64_t* tw_unused, uint64_t root_mont) {
+    (void)tw_unused;
+    uint64_t* tw = make_twiddles(log_n, root_mont);
+    ntt_core_plain(a, log_n, V, tw);
+    free(tw);
+}
+void oracle_ntt_stages_blocked(uint64_t* a, unsigned log_n, unsigned V, uint64_t root_mont) {
+    uint64_t* tw = make_twiddles(log_n, root_mont);
+    ntt_core(a, log_n, V, tw);
+    free(tw);
 }
 /* offset_canon: canonical (non-Montgomery) integer of the coset offset. */
 void oracle_ntt(uint64_t* a, unsigned log_n, unsigned V, int inverse, uint64_t offset_canon) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): the measurements DESIGN.md section 6 and bench.py's `roofline.traffic` cite.
+# Run on the GPU box (gpurun): the measurements DESIGN.md sections 4 and 6 and bench.py's `roofline.traffic` cite.
 #   scripts/collect_profiles.sh rNN
 #   1. bench.py (default command) under rocprofv3 --kernel-trace --stats      -> per-kernel average durations
 #   2. the same workload under --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no tracing domains)
@@ -11,7 +11,7 @@
 # gpurun's merge had left in place: hence the stamp (every input must be newer than it), the reduction before any delete,
 # and a non-zero exit when a counter file did not come back.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 OUT=$R/gpurun_out/profiles_raw

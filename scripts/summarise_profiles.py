@@ -23,7 +23,7 @@ if "--raw" in args:
     i = args.index("--raw"); RAW = args[i + 1]; del args[i:i + 2]
 if "--out" in args:
     i = args.index("--out"); PROF = args[i + 1]; del args[i:i + 2]
-tag = args[0] if args else "r04"
+tag = args[0] if args else "r05"
 os.makedirs(PROF, exist_ok=True)
 STAMP = os.path.join(RAW, "RUN_STAMP")
 if not os.path.exists(STAMP):

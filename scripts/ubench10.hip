@@ -1,5 +1,5 @@
 // Round-4 micro-benchmark: what would the strided pass of a TWO-pass 2^24-point transform cost in bare memory traffic?
-// Three radix-256 passes cannot go below ~143 us per column.  A two-pass split 2^24 = R x (2^24 / R) needs a strided
+// Three radix-256 passes cannot go below ~143 us per column (docs/DESIGN_HISTORY.md 8.1).  A two-pass split 2^24 = R x (2^24 / R) needs a strided
 // pass whose tile holds R points of W adjacent sub-transforms: R x W x 8 bytes of LDS, and only W x 8 contiguous bytes per row.
 //   R = 4096, W = 4   128 KiB, 32-byte runs      R = 2048, W = 8   128 KiB, 64-byte runs      R = 1024, W = 16  128 KiB, 128-byte runs
 //   R = 2048, W = 4    64 KiB (two workgroups per CU), 32-byte runs

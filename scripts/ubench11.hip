@@ -1,5 +1,5 @@
 // Round-5 micro-benchmark: can a 2^24-point natural-order transform be TWO fabric passes when the exchange that the granule rule
-// forbids in LDS goes through the XCD's 4 MiB L2 instead?  n = 4096 x 4096 words, i = i0 + 4096 i1:
+// forbids in LDS (docs/DESIGN_HISTORY.md 8.1-5; result: DESIGN.md 9.1) goes through the XCD's 4 MiB L2 instead?  n = 4096 x 4096 words, i = i0 + 4096 i1:
 //   pass A  super-tile = 4096 rows (i1, stride 32 KiB) x W words (W = 64: 2 MiB, 512-byte runs; W = 32: 1 MiB, 256-byte runs).
 //           A TEAM of 16 workgroups that sit on ONE XCD (found from HW_REG_XCC_ID, never assumed) does radix 4096 = 256 x 16:
 //           A1  member g loads rows g + 16 m (nt), radix-256 stand-in (two halves through 64 KiB of LDS, like ntt2_first_pass),
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(512, 4) k_handoff(Ctl* ctl, uint64_t* buf, uin
 
 // read the wide pattern (256 rows at stride 2^16 words, 64-word runs), write either ONE contiguous 128 KiB block per tile (WR = 0)
 // or the local pattern (256 runs at stride 2^8 words inside a 512 KiB block, WR = 1): what a plan with [j2][j3][k1] as its
-// intermediate layout would do in its first / last pass (only two of the six streams would then be wide)
+// intermediate layout would do in its first / last pass (no plan can use them without adding a wide stream elsewhere -- the digit order is forced)
 template <int WR>
 __global__ void __launch_bounds__(512, 4) k_mixed(Cols C) {
     __shared__ uint64_t lds[8192];

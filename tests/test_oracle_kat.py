@@ -262,3 +262,35 @@ def test_both_oracles_match_sympys_ntt():
     coset_in = [(v * pow(7, i, F.GL.p)) % F.GL.p for i, v in enumerate(x)]
     want = [int(v) for v in sympy_ntt(coset_in, F.GL.p)]
     assert from_mont(cref.ntt(to_mont(x), case["log_n"], 1, False, 7)) == want
+
+
+def test_cache_blocked_orders_of_the_c_oracle_equal_the_plain_loops():
+    """oracle/c (round 5): the transform takes its butterflies block by block and the bit reversal works tile by tile -- the same
+    pairs, twiddles and swaps in another order.  The plain stage-by-stage loop is kept as a test hook; both must give the same words
+    (sizes around the switch points: 2^12 / 2^13 for the stages, 2^15 / 2^16 for the tiled reversal; Fp and Fq3 element widths)."""
+    import ctypes
+    from oracle import cref
+    L = cref.lib()
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.oracle_gl_root_of_unity.restype = ctypes.c_uint64
+    L.oracle_gl_root_of_unity.argtypes = [ctypes.c_uint]
+    L.oracle_ntt_stages_plain.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint, u64p, ctypes.c_uint64]
+    L.oracle_ntt_stages_blocked.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64]
+    L.oracle_ntt_stages_plain.restype = L.oracle_ntt_stages_blocked.restype = None
+    for log_n in (12, 13, 14, 16, 18):
+        for V in (1, 3):
+            x = cref.random_elements((1 << log_n) * V, 40 + log_n + V)
+            a, b = x.copy(), x.copy()
+            root = L.oracle_gl_root_of_unity(log_n)
+            L.oracle_ntt_stages_plain(cref._p(a), log_n, V, None, root)
+            L.oracle_ntt_stages_blocked(cref._p(b), log_n, V, root)
+            assert np.array_equal(a, b), (log_n, V)
+    for log_n in (4, 15, 16, 17, 19):
+        n = 1 << log_n
+        idx = np.arange(n, dtype=np.uint64)
+        rev = np.zeros(n, dtype=np.uint64)
+        for bit in range(log_n):
+            rev |= ((idx >> np.uint64(bit)) & np.uint64(1)) << np.uint64(log_n - 1 - bit)
+        for V in (1, 3, 4):
+            x = cref.random_elements(n * V, 90 + log_n + V)
+            assert np.array_equal(cref.bit_reverse(x, log_n, V), x.reshape(n, V)[rev.astype(np.int64)].ravel()), (log_n, V)
