@@ -672,11 +672,28 @@ def _spawn_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
+    # rank 0's line is read on a thread while all ranks are watched: a rank that dies at start-up would otherwise leave rank 0
+    # waiting in its rendezvous (and this process in read()) until torch's own timeout
+    import threading
+    box = {}
+    reader = threading.Thread(target=lambda: box.__setitem__("out", procs[0].stdout.read().decode()), daemon=True)
+    reader.start()
+    deadline = time.time() + 1800
+    while reader.is_alive() and time.time() < deadline:
+        reader.join(timeout=0.5)
+        if any(pr.poll() not in (None, 0) for pr in procs):     # a failed rank: the others cannot finish a collective with it
+            time.sleep(2.0)                                        # (let a rank that is already printing finish)
+            break
+    if reader.is_alive():                                      # rank 0 never closed its line: a failed rank or the deadline
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    reader.join(timeout=5.0)
+    out0 = box.get("out", "")
     rcs = []
     for r, pr in enumerate(procs):
         try:
-            rcs.append(pr.wait(timeout=1800))
+            rcs.append(pr.wait(timeout=60))
         except subprocess.TimeoutExpired:
             pr.kill()
             rcs.append(-9)
@@ -782,7 +799,11 @@ def main():
             finally:
                 comm.close()
         if pr is not None:
-            if "prove_ms" in pr:
+            # every rank takes part in the reduction or none does: a rank whose prover raised must not leave the others in a collective
+            failed = reduce_max(0.0 if "prove_ms" in pr else 1.0)
+            if failed:
+                pr = pr if "error" in pr else {"error": "the prover failed on another rank", "n_gpus": world}
+            else:
                 pr["prove_ms"] = round(reduce_max(pr["prove_ms"]), 3)
             r["prove"] = pr
         for key in ("lde_ms", "exchange_ms", "commit_ms"):
