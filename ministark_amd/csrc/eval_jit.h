@@ -33,6 +33,7 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
     char b[256];
     for (unsigned r = 0; r < maxp; r++) { snprintf(b, sizeof b, is252 ? "    f252::E p%u;\n" : "    uint64_t p%u;\n", r); s += b; }
     for (unsigned r = 0; r < maxq; r++) { snprintf(b, sizeof b, "    gl::Fq3 q%u;\n", r); s += b; }
+    for (int r = 0; r < NACC; r++) { snprintf(b, sizeof b, is252 ? "    Acc19 acc%d;\n" : "    Acc6 acc%d;\n", r); s += b; }
     for (unsigned k = 0; k < ninstr; k++) {
         const Instr I = prog[k];
         const unsigned d = I.dst, x = I.a, y = I.b;
@@ -51,6 +52,10 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
             case OP_STORE_P: snprintf(b, sizeof b, "ev252_store(P, R, %uu, p%u);", y, x); break;
             case OP_XPOW_P: snprintf(b, sizeof b, "p%u = ev252_xpow(P, i, %uu, %uu);", d, x, y); break;
             case OP_TABLE_P: snprintf(b, sizeof b, "p%u = ev252_table(P, R, %uu);", d, x); break;
+            case OP_ACC_ZERO: snprintf(b, sizeof b, "acc_zero(acc%u);", d & (NACC - 1)); break;
+            case OP_ACC_MACC: snprintf(b, sizeof b, "acc_macc(acc%u, p%u, P.consts, %uu);", d & (NACC - 1), x, y); break;
+            case OP_ACC_MACP: snprintf(b, sizeof b, "acc_macp(acc%u, p%u, p%u);", d & (NACC - 1), x, y); break;
+            case OP_ACC_RED: snprintf(b, sizeof b, "p%u = acc_reduce(acc%u);", d, x & (NACC - 1)); break;
             default: break;
             }
         } else {
@@ -80,6 +85,10 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
             case OP_XPOW_P: snprintf(b, sizeof b, "p%u = ev_xpow(P, i, %uu, %uu);", d, x, y); break;
             case OP_TABLE_P: snprintf(b, sizeof b, "p%u = ev_table_p(P, R, %uu);", d, x); break;
             case OP_TABLE_Q: snprintf(b, sizeof b, "q%u = ev_table_q(P, R, %uu);", d, x); break;
+            case OP_ACC_ZERO: snprintf(b, sizeof b, "acc_zero(acc%u);", d & (NACC - 1)); break;
+            case OP_ACC_MACC: snprintf(b, sizeof b, "acc_macc(acc%u, p%u, P.consts, %uu);", d & (NACC - 1), x, y); break;
+            case OP_ACC_MACP: snprintf(b, sizeof b, "acc_macp(acc%u, p%u, p%u);", d & (NACC - 1), x, y); break;
+            case OP_ACC_RED: snprintf(b, sizeof b, "p%u = acc_reduce(acc%u);", d, x & (NACC - 1)); break;
             default: break;
             }
         }

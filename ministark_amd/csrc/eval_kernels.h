@@ -32,6 +32,11 @@ enum Op : uint32_t {
     OP_INV_P, OP_INV_Q, OP_POW_P, OP_POW_Q, OP_EMBED, OP_STORE_Q, OP_STORE_P,
     OP_XPOW_P,      // internal (eval_opt.h): dst = consts[a] * w_n^(b*i mod n)  ==  x^b with consts[a] = h^b
     OP_TABLE_P, OP_TABLE_Q,   // internal (eval_opt.h, split_inversions): dst = table a of `periodic` at this launch position
+    // internal (eval_regroup.h): sums of products accumulated UNREDUCED, one Montgomery reduction per sum.  dst of the first three = accumulator
+    OP_ACC_ZERO,              // acc[dst] = 0
+    OP_ACC_MACC,              // acc[dst] += P[a] * C, C a wave-uniform constant whose limbs / digits sit at consts[b ..) (host-prepared)
+    OP_ACC_MACP,              // acc[dst] += P[a] * P[b]
+    OP_ACC_RED,               // P[dst] = (acc[a]) * R^-1 mod p, canonical
     OP_COUNT
 };
 struct Instr { uint32_t op, dst, a, b; };
@@ -123,6 +128,69 @@ __device__ __forceinline__ void ev252_store(const EvalParams& P, size_t i, uint3
     msstage::Fp252T::store(slot ? (uint64_t*)P.periodic[slot - 1] : P.out, i, v);
 }
 
+// ---- unreduced sums of products (eval_regroup.h) ---------------------------------------------------------------------------
+// Goldilocks: the first factor is cut at 32 bits, the second into 22 / 22 / 20-bit limbs; the six partial products (54 bits) go to six
+// 64-bit columns of weights 2^0, 2^22, 2^44, 2^32, 2^54, 2^76 -- six multiply-adds per term and no carry anywhere (1 024 terms fit);
+// the columns are put together once (< 2^141) and reduced once: value * 2^-64 mod p, what the sum of the Montgomery products is.
+static constexpr int ACC_MAX_TERMS_GL = 512, ACC_MAX_TERMS_252 = 16, NACC = 2;
+struct Acc6 { uint64_t s[6]; };
+__device__ __forceinline__ void acc_zero(Acc6& A) {
+    #pragma unroll
+    for (int k = 0; k < 6; k++) A.s[k] = 0;
+}
+__device__ __forceinline__ void acc_mac_limbs(Acc6& A, uint64_t c, uint32_t y0, uint32_t y1, uint32_t y2) {
+    const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
+    A.s[0] += (uint64_t)c0 * y0; A.s[1] += (uint64_t)c0 * y1; A.s[2] += (uint64_t)c0 * y2;
+    A.s[3] += (uint64_t)c1 * y0; A.s[4] += (uint64_t)c1 * y1; A.s[5] += (uint64_t)c1 * y2;
+}
+__device__ __forceinline__ void acc_macc(Acc6& A, uint64_t v, const uint64_t* consts, uint32_t slot) {     // limbs: y0 | y1 << 32, y2
+    const uint64_t w0 = consts[slot], w1 = consts[slot + 1];
+    acc_mac_limbs(A, v, (uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1);
+}
+__device__ __forceinline__ void acc_macp(Acc6& A, uint64_t v, uint64_t b) {
+    acc_mac_limbs(A, v, (uint32_t)b & 0x3FFFFFu, (uint32_t)(b >> 22) & 0x3FFFFFu, (uint32_t)(b >> 44));
+}
+// (top 2^128 + hi 2^64 + lo) 2^-64 mod p, canonical: the Montgomery reduction of the low 128 bits (felt_u64.h.metal:165-177 as in
+// gl::mont_mul) with hi brought below p first, plus top 2^64 = top (2^32 - 1)
+__device__ __forceinline__ uint64_t acc_reduce_words(uint64_t lo, uint64_t hi, uint32_t top) {
+    const uint64_t xl = lo, xh = hi >= gl::P ? hi - gl::P : hi;
+    const uint64_t s = xl + (xl << 32);
+    const uint64_t ov = s < xl;
+    const uint64_t bb = s - (s >> 32) - ov;
+    const uint64_t r = xh - bb;
+    return gl::add((xh < bb) ? r + gl::P : r, (uint64_t)top * 0xFFFFFFFFull);
+}
+__device__ __forceinline__ uint64_t acc_reduce(const Acc6& A) {
+    typedef unsigned __int128 u128;
+    const uint64_t* S = A.s;
+    const u128 low = (u128)S[0] + ((u128)S[1] << 22) + ((u128)S[2] << 44) + ((u128)S[3] << 32) + ((u128)S[4] << 54);   // < 2^119
+    const u128 top = (u128)(S[5] & ((1ull << 52) - 1)) << 76;
+    const u128 sum = low + top;
+    const uint32_t over = (uint32_t)(S[5] >> 52) + (sum < top ? 1u : 0u);
+    return acc_reduce_words((uint64_t)sum, (uint64_t)(sum >> 64), over);
+}
+// The 252-bit field: the nineteen digit columns of f252::mul_t take up to sixteen products before its reduction runs (fp252.h)
+struct Acc19 { uint64_t c[19]; };
+__device__ __forceinline__ void acc_zero(Acc19& A) {
+    #pragma unroll
+    for (int k = 0; k < 19; k++) A.c[k] = 0;
+}
+__device__ __forceinline__ void acc_macc(Acc19& A, const f252::E& v, const uint64_t* consts, uint32_t slot) {   // digits: five words, two per word
+    uint32_t x[9], y[9];
+    f252::digits9(v, x);
+    #pragma unroll
+    for (int k = 0; k < 4; k++) { const uint64_t w = consts[slot + k]; y[2 * k] = (uint32_t)w; y[2 * k + 1] = (uint32_t)(w >> 32); }
+    y[8] = (uint32_t)consts[slot + 4];
+    f252::mac81(A.c, x, y);
+}
+__device__ __forceinline__ void acc_macp(Acc19& A, const f252::E& v, const f252::E& b) {
+    uint32_t x[9], y[9];
+    f252::digits9(v, x);
+    f252::digits9(b, y);
+    f252::mac81(A.c, x, y);
+}
+__device__ __forceinline__ f252::E acc_reduce(Acc19& A) { return f252::reduce_columns<true>(A.c); }
+
 template <int NP, int NQ>
 __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
     using F3 = msstage::Fq3T;
@@ -132,6 +200,7 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
     const size_t i = ev_point(P, R);
     uint64_t rp[NP];
     gl::Fq3 rq[NQ];
+    Acc6 acc[NACC];
     for (uint32_t pc = 0; pc < P.ninstr; pc++) {
         const Instr I = P.prog[pc];
         switch (I.op) {
@@ -160,6 +229,10 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
         case OP_XPOW_P: rp[I.dst] = ev_xpow(P, i, I.a, I.b); break;
         case OP_TABLE_P: rp[I.dst] = ev_table_p(P, R, I.a); break;
         case OP_TABLE_Q: rq[I.dst] = ev_table_q(P, R, I.a); break;
+        case OP_ACC_ZERO: acc_zero(acc[I.dst & (NACC - 1)]); break;
+        case OP_ACC_MACC: acc_macc(acc[I.dst & (NACC - 1)], rp[I.a], P.consts, I.b); break;
+        case OP_ACC_MACP: acc_macp(acc[I.dst & (NACC - 1)], rp[I.a], rp[I.b]); break;
+        case OP_ACC_RED: rp[I.dst] = acc_reduce(acc[I.a & (NACC - 1)]); break;
         default: break;
         }
     }
@@ -174,6 +247,7 @@ __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
     if (R >= P.n) return;
     const size_t i = ev_point(P, R);
     f252::E rp[NP];
+    Acc19 acc[NACC];
     for (uint32_t pc = 0; pc < P.ninstr; pc++) {
         const Instr I = P.prog[pc];
         switch (I.op) {
@@ -189,6 +263,10 @@ __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
         case OP_STORE_P: ev252_store(P, R, I.b, rp[I.a]); break;
         case OP_XPOW_P: rp[I.dst] = ev252_xpow(P, i, I.a, I.b); break;
         case OP_TABLE_P: rp[I.dst] = ev252_table(P, R, I.a); break;
+        case OP_ACC_ZERO: acc_zero(acc[I.dst & (NACC - 1)]); break;
+        case OP_ACC_MACC: acc_macc(acc[I.dst & (NACC - 1)], rp[I.a], P.consts, I.b); break;
+        case OP_ACC_MACP: acc_macp(acc[I.dst & (NACC - 1)], rp[I.a], rp[I.b]); break;
+        case OP_ACC_RED: rp[I.dst] = acc_reduce(acc[I.a & (NACC - 1)]); break;
         default: break;
         }
     }

@@ -70,31 +70,29 @@ MS_HD E sub(const E& a, const E& b) { return add(a, neg(b)); }      // felt_u256
 // mul_t<false> leaves out the final conditional subtraction (result < 2p) and accepts a LAZY first operand: any a < 2^256
 // with a canonical b keeps every column below 2^62 (a's top digit has 32 bits, so one term per column is < 2^60), and
 // (a b + m p) / R < a p / R + p < 2p because p / R < 1/31.9.  The NTT tiles (fp252_ntt_kernels.h) run on such values.
-template <bool CANON>
-MS_HD E mul_t(const E& a, const E& b) {
+// The product in pieces (round 5: the constraint evaluator accumulates SEVERAL products in the same columns before ONE reduction,
+// eval_kernels.h): nine 28-bit digits of an operand (the top one has 32 bits) ...
+MS_HD void digits9(const E& a, uint32_t* x) {
     constexpr uint32_t M = (1u << 28) - 1;
-    uint32_t x[9], y[9];
-    {
-        const uint64_t w0 = a.l[0], w1 = a.l[1], w2 = a.l[2], w3 = a.l[3];
-        x[0] = (uint32_t)w0 & M; x[1] = (uint32_t)(w0 >> 28) & M; x[2] = (uint32_t)((w0 >> 56) | (w1 << 8)) & M;
-        x[3] = (uint32_t)(w1 >> 20) & M; x[4] = (uint32_t)((w1 >> 48) | (w2 << 16)) & M; x[5] = (uint32_t)(w2 >> 12) & M;
-        x[6] = (uint32_t)((w2 >> 40) | (w3 << 24)) & M; x[7] = (uint32_t)(w3 >> 4) & M; x[8] = (uint32_t)(w3 >> 32);
-    }
-    {
-        const uint64_t w0 = b.l[0], w1 = b.l[1], w2 = b.l[2], w3 = b.l[3];
-        y[0] = (uint32_t)w0 & M; y[1] = (uint32_t)(w0 >> 28) & M; y[2] = (uint32_t)((w0 >> 56) | (w1 << 8)) & M;
-        y[3] = (uint32_t)(w1 >> 20) & M; y[4] = (uint32_t)((w1 >> 48) | (w2 << 16)) & M; y[5] = (uint32_t)(w2 >> 12) & M;
-        y[6] = (uint32_t)((w2 >> 40) | (w3 << 24)) & M; y[7] = (uint32_t)(w3 >> 4) & M; y[8] = (uint32_t)(w3 >> 32);
-    }
-    // columns c[k] = sum_{i+j=k} x_i y_j  (< 9 * 2^56: no overflow, no carries)
-    uint64_t c[19];
-    #pragma unroll
-    for (int k = 0; k < 19; k++) c[k] = 0;
+    const uint64_t w0 = a.l[0], w1 = a.l[1], w2 = a.l[2], w3 = a.l[3];
+    x[0] = (uint32_t)w0 & M; x[1] = (uint32_t)(w0 >> 28) & M; x[2] = (uint32_t)((w0 >> 56) | (w1 << 8)) & M;
+    x[3] = (uint32_t)(w1 >> 20) & M; x[4] = (uint32_t)((w1 >> 48) | (w2 << 16)) & M; x[5] = (uint32_t)(w2 >> 12) & M;
+    x[6] = (uint32_t)((w2 >> 40) | (w3 << 24)) & M; x[7] = (uint32_t)(w3 >> 4) & M; x[8] = (uint32_t)(w3 >> 32);
+}
+// ... columns c[k] += sum_{i+j=k} x_i y_j: one product adds less than 9 * 2^60 / 16 to a column (canonical operands: every digit
+// below 2^28 but the top ones, < 2^27.1), so SIXTEEN products fit a 64-bit column together with the reduction's own additions ...
+MS_HD void mac81(uint64_t* c, const uint32_t* x, const uint32_t* y) {
     #pragma unroll
     for (int i = 0; i < 9; i++) {
         #pragma unroll
         for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)x[i] * y[j];
     }
+}
+// ... and the Montgomery reduction of the columns: (sum of the products) * 2^-256 mod p.  With K canonical products in the columns
+// the value is below (K / 31.9 + 1) p: one conditional subtraction makes it canonical for K <= 30.
+template <bool CANON>
+MS_HD E reduce_columns(uint64_t* c) {
+    constexpr uint32_t M = (1u << 28) - 1;
     // eight reduction rounds of 28 bits: m = -c_k mod 2^28, c += m * p * 2^(28k), p = 1 + 17*2^192 + 2^251
     uint64_t carry = 0;
     #pragma unroll
@@ -126,6 +124,17 @@ MS_HD E mul_t(const E& a, const E& b) {
     r.l[3] = (uint64_t)d[16] | ((uint64_t)d[17] << 28) | ((uint64_t)d[18] << 56);
     if constexpr (!CANON) return r;
     return geq_p(r) ? sub_p(r) : r;
+}
+template <bool CANON>
+MS_HD E mul_t(const E& a, const E& b) {
+    uint32_t x[9], y[9];
+    digits9(a, x);
+    digits9(b, y);
+    uint64_t c[19];
+    #pragma unroll
+    for (int k = 0; k < 19; k++) c[k] = 0;
+    mac81(c, x, y);
+    return reduce_columns<CANON>(c);
 }
 MS_HD E mul(const E& a, const E& b) { return mul_t<true>(a, b); }
 

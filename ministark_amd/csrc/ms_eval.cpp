@@ -4,6 +4,7 @@
 #include "stage_kernels.h"
 #include "eval_kernels.h"
 #include "eval_opt.h"
+#include "eval_regroup.h"
 #ifndef MS_NO_JIT
 #include "eval_jit.h"
 #endif
@@ -108,6 +109,18 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     if (log_n >= 12) isplit = split_inversions(main_prog, main_n, nperiodic + short_tables, (unsigned)MAXPERIODIC - nperiodic - short_tables, PW);
     if (isplit.active) { main_prog = isplit.main.data(); main_n = (unsigned)isplit.main.size(); }
     const unsigned den_n = (unsigned)isplit.denom.size();
+    // ---- rewrite 4: the result as sums of products with one reduction per sum (eval_regroup.h; Fq = Fp programs; MS_EVAL_REGROUP=0: off)
+    Regrouped regrouped;
+    {
+        static const bool off = getenv("MS_EVAL_REGROUP") && !strcmp(getenv("MS_EVAL_REGROUP"), "0");
+        if (!off && maxq == 0 && out_field != MS_GOLDILOCKS_FQ3) {
+            static const bool force = getenv("MS_EVAL_REGROUP") && !strcmp(getenv("MS_EVAL_REGROUP"), "force");     // the fuzzers: whenever it CAN be applied
+            regrouped = is252 ? regroup_sums_of_products<Host252>(main_prog, main_n, consts, force) : regroup_sums_of_products<HostGL>(main_prog, main_n, consts, force);
+            if (getenv("MS_EVAL_DEBUG")) fprintf(stderr, "regroup: %s, estimated vector instructions per point %u -> %u\n", regrouped.active ? "applied" : "not applied", regrouped.old_cost, regrouped.new_cost);
+            if (regrouped.active && getenv("MS_EVAL_DEBUG")) for (auto& I : regrouped.prog) fprintf(stderr, "  regr: op %2u dst %u a %u b %u\n", I.op, I.dst, I.a, I.b);
+            if (regrouped.active) { main_prog = regrouped.prog.data(); main_n = (unsigned)regrouped.prog.size(); maxp = std::max(maxp, regrouped.maxp); }
+        }
+    }
     // ---- program(s) + constants -> device
     const size_t mbytes = (size_t)main_n * sizeof(Instr), pbytes = (size_t)pro_n * sizeof(Instr), dbytes = (size_t)den_n * sizeof(Instr), cbytes = consts.size() * 8;
     const size_t poff = (mbytes + 15) & ~(size_t)15, doff = (poff + pbytes + 15) & ~(size_t)15, coff = (doff + dbytes + 15) & ~(size_t)15, total = coff + cbytes + 64;
@@ -272,7 +285,23 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
             launch(Q, fn);
         }
         tp = (uint64_t*)inv_tables;
-        for (size_t t = 0; t < isplit.table_words.size(); t++) {
+        // 252-bit tables of a large domain are inverted TOGETHER (they are adjacent in memory): the middle level of the two-level scheme is
+        // one serial Fermat chain per lane at one or two waves per SIMD -- pure latency, paid once for all tables instead of once per table
+        bool all252 = !isplit.table_words.empty() && n >= ((size_t)1 << 16);
+        for (unsigned w : isplit.table_words) if (w != 4) all252 = false;
+        const size_t ntab_merged = all252 ? isplit.table_words.size() : 0;
+        if (ntab_merged) {
+            const size_t nn = n * ntab_merged;
+            ProfScope ps(ctx, "eval_batch_inverse", 16.0 * 4 * nn);
+            const unsigned blocks = (unsigned)(nn / (NT * 8));
+            const size_t m = (size_t)blocks * NT;
+            void* prod = nullptr;
+            MSCHK(pooled.alloc(m * 32, &prod));
+            hipLaunchKernelGGL((batch_inverse_up<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, nn, (uint64_t*)prod);
+            hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 16>), dim3((unsigned)((m + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
+            hipLaunchKernelGGL((batch_inverse_down<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, nn, (const uint64_t*)prod);
+        }
+        for (size_t t = ntab_merged; t < isplit.table_words.size(); t++) {
             const unsigned w = isplit.table_words[t];
             ProfScope ps(ctx, "eval_batch_inverse", 16.0 * w * n);
             // Fp / Fq3: the stage's kernel, in place (it keeps the K values in registers: one read and one write of the table)
@@ -315,7 +344,9 @@ extern "C" int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int ou
     }
     std::vector<char> code;
     std::string log;
-    if (!jit_compile(jit_source(prog, ninstr, is252, maxp, maxq), code, log)) return fail(MS_ERR_UNSUPPORTED, "hiprtc: %s", log.c_str());
+    const std::string src = jit_source(prog, ninstr, is252, maxp, maxq);
+    if (const char* dump = getenv("MS_EVAL_DUMP")) { if (FILE* f = fopen(dump, "a")) { fputs(src.c_str(), f); fputs("\n// ----\n", f); fclose(f); } }
+    if (!jit_compile(src, code, log)) return fail(MS_ERR_UNSUPPORTED, "hiprtc: %s", log.c_str());
     *code_bytes = code.size();
     return MS_OK;
 #else

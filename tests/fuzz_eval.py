@@ -19,7 +19,12 @@ from ministark_amd import expr as E  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-pl = Planner(0)
+EMU = os.environ.get("MS_FUZZ_BACKEND") == "emu"          # the simulator build (CPU): the rewriting passes and the interpreter, small domains
+if EMU:
+    from tests import backends  # noqa: E402
+    pl = backends.planner("emu")
+else:
+    pl = Planner(0)
 P = GL.p
 
 
@@ -60,7 +65,7 @@ def canon(arr, V):
 
 t0, count, jit = time.time(), 0, 0
 while time.time() - t0 < budget:
-    log_n = int(rng.choice([6, 9, 12, 12, 13, 16]))
+    log_n = int(rng.choice([6, 8, 9, 12] if EMU else [6, 9, 12, 12, 13, 16]))
     n = 1 << log_n
     fq_is_ext = bool(rng.integers(0, 2))
     nbase, next_, nch = int(rng.integers(1, 4)), (int(rng.integers(0, 3)) if fq_is_ext else 0), int(rng.integers(0, 3))
