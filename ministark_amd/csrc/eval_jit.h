@@ -34,6 +34,7 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
     for (unsigned r = 0; r < maxp; r++) { snprintf(b, sizeof b, is252 ? "    f252::E p%u;\n" : "    uint64_t p%u;\n", r); s += b; }
     for (unsigned r = 0; r < maxq; r++) { snprintf(b, sizeof b, "    gl::Fq3 q%u;\n", r); s += b; }
     for (int r = 0; r < NACC; r++) { snprintf(b, sizeof b, is252 ? "    Acc19 acc%d;\n" : "    Acc6 acc%d;\n", r); s += b; }
+    if (!is252) s += "    AccQ accq;\n";
     for (unsigned k = 0; k < ninstr; k++) {
         const Instr I = prog[k];
         const unsigned d = I.dst, x = I.a, y = I.b;
@@ -89,6 +90,14 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
             case OP_ACC_MACC: snprintf(b, sizeof b, "acc_macc(acc%u, p%u, P.consts, %uu);", d & (NACC - 1), x, y); break;
             case OP_ACC_MACP: snprintf(b, sizeof b, "acc_macp(acc%u, p%u, p%u);", d & (NACC - 1), x, y); break;
             case OP_ACC_RED: snprintf(b, sizeof b, "p%u = acc_reduce(acc%u);", d, x & (NACC - 1)); break;
+            case OP_ACCQ_ZERO: snprintf(b, sizeof b, "acc_zero(accq);"); break;
+            case OP_ACCQ_MACC: {
+                static const char* const fn[4] = {"accq_macc_p_cp(accq, p%u, P.consts, %uu);", "accq_macc_q_cp(accq, q%u, P.consts, %uu);",
+                                                  "accq_macc_p_cq(accq, p%u, P.consts, %uu);", "accq_macc_q_cq(accq, q%u, P.consts, %uu);"};
+                snprintf(b, sizeof b, fn[d & 3], x, y);
+            } break;
+            case OP_ACCQ_MACP: snprintf(b, sizeof b, (d & 1) ? "accq_macp_q_p(accq, q%u, p%u);" : "accq_macp_p_p(accq, p%u, p%u);", x, y); break;
+            case OP_ACCQ_RED: snprintf(b, sizeof b, "q%u = accq_reduce(accq);", d); break;
             default: break;
             }
         }

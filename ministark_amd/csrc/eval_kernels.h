@@ -37,6 +37,11 @@ enum Op : uint32_t {
     OP_ACC_MACC,              // acc[dst] += P[a] * C, C a wave-uniform constant whose limbs / digits sit at consts[b ..) (host-prepared)
     OP_ACC_MACP,              // acc[dst] += P[a] * P[b]
     OP_ACC_RED,               // P[dst] = (acc[a]) * R^-1 mod p, canonical
+    // the same over the cubic extension: ONE accumulator of three column sets (c0, c1, c2 of Fp[x] / (x^3 - 2)); dst of MACC / MACP = mode
+    OP_ACCQ_ZERO,
+    OP_ACCQ_MACC,             // mode bit 0: the register is Q[a] (else P[a]); bit 1: the constant at consts[b ..) is an Fq3 (limbs of C0, C1, C2, 2 C1, 2 C2) else Fp
+    OP_ACCQ_MACP,             // mode 0: c0 += P[a] * P[b];  mode 1: c_i += Q[a]_i * P[b]
+    OP_ACCQ_RED,              // Q[dst] = the three reduced components
     OP_COUNT
 };
 struct Instr { uint32_t op, dst, a, b; };
@@ -169,6 +174,30 @@ __device__ __forceinline__ uint64_t acc_reduce(const Acc6& A) {
     const uint32_t over = (uint32_t)(S[5] >> 52) + (sum < top ? 1u : 0u);
     return acc_reduce_words((uint64_t)sum, (uint64_t)(sum >> 64), over);
 }
+// Fq3 = Fp[x] / (x^3 - 2): (a0 + a1 x + a2 x^2)(b0 + b1 x + b2 x^2) = (a0 b0 + 2 a1 b2 + 2 a2 b1) + (a0 b1 + a1 b0 + 2 a2 b2) x + (a0 b2 + a1 b1 + a2 b0) x^2
+// (the reference's product, felt_u64.h.metal:205-231, before its Karatsuba regrouping).  Up to three partial products per column and term:
+// 256 terms fit.
+static constexpr int ACC_MAX_TERMS_Q = 256;
+struct AccQ { Acc6 c[3]; };
+__device__ __forceinline__ void acc_zero(AccQ& A) { acc_zero(A.c[0]); acc_zero(A.c[1]); acc_zero(A.c[2]); }
+__device__ __forceinline__ void accq_macc_p_cp(AccQ& A, uint64_t t, const uint64_t* consts, uint32_t s) { acc_macc(A.c[0], t, consts, s); }
+__device__ __forceinline__ void accq_macc_q_cp(AccQ& A, const gl::Fq3& t, const uint64_t* consts, uint32_t s) {
+    acc_macc(A.c[0], t.c0, consts, s); acc_macc(A.c[1], t.c1, consts, s); acc_macc(A.c[2], t.c2, consts, s);
+}
+__device__ __forceinline__ void accq_macc_p_cq(AccQ& A, uint64_t t, const uint64_t* consts, uint32_t s) {
+    acc_macc(A.c[0], t, consts, s); acc_macc(A.c[1], t, consts, s + 2); acc_macc(A.c[2], t, consts, s + 4);
+}
+__device__ __forceinline__ void accq_macc_q_cq(AccQ& A, const gl::Fq3& t, const uint64_t* consts, uint32_t s) {      // slots: C0 +0, C1 +2, C2 +4, 2 C1 +6, 2 C2 +8
+    acc_macc(A.c[0], t.c0, consts, s);     acc_macc(A.c[0], t.c1, consts, s + 8); acc_macc(A.c[0], t.c2, consts, s + 6);
+    acc_macc(A.c[1], t.c0, consts, s + 2); acc_macc(A.c[1], t.c1, consts, s);     acc_macc(A.c[1], t.c2, consts, s + 8);
+    acc_macc(A.c[2], t.c0, consts, s + 4); acc_macc(A.c[2], t.c1, consts, s + 2); acc_macc(A.c[2], t.c2, consts, s);
+}
+__device__ __forceinline__ void accq_macp_p_p(AccQ& A, uint64_t a, uint64_t b) { acc_macp(A.c[0], a, b); }
+__device__ __forceinline__ void accq_macp_q_p(AccQ& A, const gl::Fq3& a, uint64_t b) {
+    const uint32_t y0 = (uint32_t)b & 0x3FFFFFu, y1 = (uint32_t)(b >> 22) & 0x3FFFFFu, y2 = (uint32_t)(b >> 44);
+    acc_mac_limbs(A.c[0], a.c0, y0, y1, y2); acc_mac_limbs(A.c[1], a.c1, y0, y1, y2); acc_mac_limbs(A.c[2], a.c2, y0, y1, y2);
+}
+__device__ __forceinline__ gl::Fq3 accq_reduce(const AccQ& A) { return {acc_reduce(A.c[0]), acc_reduce(A.c[1]), acc_reduce(A.c[2])}; }
 // The 252-bit field: the nineteen digit columns of f252::mul_t take up to sixteen products before its reduction runs (fp252.h)
 struct Acc19 { uint64_t c[19]; };
 __device__ __forceinline__ void acc_zero(Acc19& A) {
@@ -201,6 +230,7 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
     uint64_t rp[NP];
     gl::Fq3 rq[NQ];
     Acc6 acc[NACC];
+    AccQ accq;
     for (uint32_t pc = 0; pc < P.ninstr; pc++) {
         const Instr I = P.prog[pc];
         switch (I.op) {
@@ -233,6 +263,15 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
         case OP_ACC_MACC: acc_macc(acc[I.dst & (NACC - 1)], rp[I.a], P.consts, I.b); break;
         case OP_ACC_MACP: acc_macp(acc[I.dst & (NACC - 1)], rp[I.a], rp[I.b]); break;
         case OP_ACC_RED: rp[I.dst] = acc_reduce(acc[I.a & (NACC - 1)]); break;
+        case OP_ACCQ_ZERO: acc_zero(accq); break;
+        case OP_ACCQ_MACC:
+            if ((I.dst & 3) == 0) accq_macc_p_cp(accq, rp[I.a], P.consts, I.b);
+            else if ((I.dst & 3) == 1) accq_macc_q_cp(accq, rq[I.a], P.consts, I.b);
+            else if ((I.dst & 3) == 2) accq_macc_p_cq(accq, rp[I.a], P.consts, I.b);
+            else accq_macc_q_cq(accq, rq[I.a], P.consts, I.b);
+            break;
+        case OP_ACCQ_MACP: if (I.dst & 1) accq_macp_q_p(accq, rq[I.a], rp[I.b]); else accq_macp_p_p(accq, rp[I.a], rp[I.b]); break;
+        case OP_ACCQ_RED: rq[I.dst] = accq_reduce(accq); break;
         default: break;
         }
     }

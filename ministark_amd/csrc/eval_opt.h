@@ -33,7 +33,7 @@ struct SplitProgram {
 static inline bool op_is_q_dst(uint32_t op) {
     switch (op) {
     case OP_CONST_Q: case OP_TRACE_Q: case OP_PERIODIC_Q: case OP_NEG_Q: case OP_ADD_QQ: case OP_ADD_QP:
-    case OP_MUL_QQ: case OP_MUL_QP: case OP_INV_Q: case OP_POW_Q: case OP_EMBED: case OP_TABLE_Q: return true;
+    case OP_MUL_QQ: case OP_MUL_QP: case OP_INV_Q: case OP_POW_Q: case OP_EMBED: case OP_TABLE_Q: case OP_ACCQ_RED: return true;
     default: return false;
     }
 }

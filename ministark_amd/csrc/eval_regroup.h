@@ -30,7 +30,7 @@ namespace mseval {
 struct Regrouped {
     bool active = false;
     std::vector<Instr> prog;
-    unsigned maxp = 0;
+    unsigned maxp = 0, maxq = 0;
     unsigned old_cost = 0, new_cost = 0;      // rough vector-instruction counts per point, before / after
 };
 
@@ -365,6 +365,372 @@ static inline Regrouped regroup_sums_of_products(const Instr* prog, unsigned nin
     }
     R.prog.swap(out);
     R.maxp = maxp;
+    R.active = true;
+    return R;
+}
+
+
+// ---- the same for Goldilocks programs with Fq3 values (Q-typed opcodes): the brainfuck-shaped AIRs (examples/brainfuck/air.rs:26-27) ----
+// A monomial is P-typed when all its factors are; inside a Q-typed sum it enters embedded, as ADD_QP / EMBED do.  Coefficients are
+// folded on the host in the field they live in; a Q group accumulates in AccQ (eval_kernels.h): 9 / 3 / 3 / 1 multiply-add sextets
+// per term for (Q value, Q constant) / (Q, P) / (P, Q) / (P, P), three reductions per sum -- against six Montgomery products and
+// fifteen modular additions for ONE extension-field product.
+namespace regroup_detail {
+struct UV { bool q; uint64_t p; gl::Fq3 v; };
+static inline gl::Fq3 uv_q(const UV& a) { return a.q ? a.v : gl::Fq3{a.p, 0, 0}; }
+static inline UV uv_mul(const UV& a, const UV& b) {
+    if (!a.q && !b.q) return UV{false, gl::mont_mul(a.p, b.p), {}};
+    if (a.q && b.q) return UV{true, 0, gl::mont_mul(a.v, b.v)};
+    return a.q ? UV{true, 0, gl::mont_mul_fp(a.v, b.p)} : UV{true, 0, gl::mont_mul_fp(b.v, a.p)};
+}
+static inline UV uv_add(const UV& a, const UV& b) {
+    if (!a.q && !b.q) return UV{false, gl::add(a.p, b.p), {}};
+    return UV{true, 0, gl::add(uv_q(a), uv_q(b))};
+}
+static inline UV uv_neg(const UV& a) { return a.q ? UV{true, 0, gl::neg(a.v)} : UV{false, gl::neg(a.p), {}}; }
+static inline bool uv_zero(const UV& a) { return a.q ? (a.v.c0 | a.v.c1 | a.v.c2) == 0 : a.p == 0; }
+static inline bool uv_is_one(const UV& a) { return a.q ? (a.v.c0 == gl::ONE_MONT && (a.v.c1 | a.v.c2) == 0) : a.p == gl::ONE_MONT; }
+}  // namespace regroup_detail
+
+static inline Regrouped regroup_sums_of_products_q(const Instr* prog, unsigned ninstr, std::vector<uint64_t>& consts, bool force = false) {
+    using namespace regroup_detail;
+    Regrouped R;
+    if ((ninstr < 8 && !force) || ninstr > 4096) return R;
+    // ---- DAG
+    std::vector<int> na(ninstr, -1), nb(ninstr, -1), defp(256, -1), defq(128, -1), uses(ninstr, 0);
+    std::vector<unsigned char> cls(ninstr, TR), isq(ninstr, 0);
+    int root = -1;
+    unsigned nstores = 0;
+    bool root_q = false;
+    for (unsigned k = 0; k < ninstr; k++) {
+        const Instr I = prog[k];
+        if (I.op >= OP_ACC_ZERO) return R;
+        unsigned opnd[2][2];
+        const int nop = (I.op == OP_XPOW_P) ? 0 : op_operands(I, opnd);
+        int d[2] = {-1, -1};
+        for (int o = 0; o < nop; o++) {
+            if (opnd[o][1] >= (opnd[o][0] ? 128u : 256u)) return R;
+            d[o] = opnd[o][0] ? defq[opnd[o][1]] : defp[opnd[o][1]];
+            if (d[o] < 0) return R;
+        }
+        if (op_is_store(I.op)) {
+            if (I.b != 0 || nop != 1) return R;
+            root = d[0]; root_q = I.op == OP_STORE_Q; nstores++;
+            continue;
+        }
+        isq[k] = op_is_q_dst(I.op) ? 1 : 0;
+        switch (I.op) {
+        case OP_CONST_P: case OP_CONST_Q: cls[k] = U; break;
+        case OP_X_P: case OP_XPOW_P: case OP_TABLE_P: case OP_TABLE_Q: case OP_PERIODIC_P: case OP_PERIODIC_Q: cls[k] = X; break;
+        case OP_TRACE_P: case OP_TRACE_Q: cls[k] = TR; break;
+        default: {
+            if (nop == 0) return R;
+            unsigned char c = U;
+            for (int o = 0; o < nop; o++) c = std::max(c, cls[d[o]]);
+            if ((I.op == OP_POW_P || I.op == OP_POW_Q) && I.b == 0) c = U;
+            cls[k] = c;
+        }
+        }
+        na[k] = d[0]; nb[k] = d[1];
+        if (na[k] >= 0) uses[na[k]]++;
+        if (nb[k] >= 0) uses[nb[k]]++;
+        if (I.dst >= (isq[k] ? 128u : 256u)) return R;
+        (isq[k] ? defq : defp)[I.dst] = (int)k;
+    }
+    if (nstores != 1 || root < 0 || cls[root] != TR) return R;
+    // ---- uniform values on the host
+    std::vector<char> u_done(ninstr, 0);
+    std::vector<UV> u_val(ninstr);
+    auto eval_u = [&](auto&& self, int k) -> UV {
+        if (u_done[k]) return u_val[k];
+        const Instr I = prog[k];
+        UV v{false, 0, {}};
+        switch (I.op) {
+        case OP_CONST_P: v = UV{false, consts[I.a], {}}; break;
+        case OP_CONST_Q: v = UV{true, 0, gl::Fq3{consts[I.a], consts[I.a + 1], consts[I.a + 2]}}; break;
+        case OP_NEG_P: case OP_NEG_Q: v = uv_neg(self(self, na[k])); break;
+        case OP_ADD_PP: case OP_ADD_QQ: case OP_ADD_QP: v = uv_add(self(self, na[k]), self(self, nb[k])); break;
+        case OP_MUL_PP: case OP_MUL_QQ: case OP_MUL_QP: v = uv_mul(self(self, na[k]), self(self, nb[k])); break;
+        case OP_INV_P: v = UV{false, gl::mont_inv(self(self, na[k]).p), {}}; break;
+        case OP_INV_Q: v = UV{true, 0, gl::mont_inv(uv_q(self(self, na[k])))}; break;
+        case OP_POW_P: v = UV{false, I.b == 0 ? gl::ONE_MONT : gl::mont_pow(self(self, na[k]).p, I.b), {}}; break;
+        case OP_POW_Q: v = UV{true, 0, I.b == 0 ? gl::Fq3{gl::ONE_MONT, 0, 0} : gl::mont_pow(uv_q(self(self, na[k])), I.b)}; break;
+        case OP_EMBED: v = UV{true, 0, uv_q(self(self, na[k]))}; break;
+        default: break;
+        }
+        if (isq[k] && !v.q) v = UV{true, 0, uv_q(v)};
+        u_done[k] = 1; u_val[k] = v;
+        return v;
+    };
+    // ---- expansion (same rules as the P-typed pass)
+    bool too_big = false;
+    auto atom = [&](int k) { Mono m; m.sign = 1; (cls[k] == U ? m.u : cls[k] == X ? m.x : m.t).push_back(k); return std::vector<Mono>{m}; };
+    auto expand = [&](auto&& self, int k, bool is_root) -> std::vector<Mono> {
+        if (too_big) return {};
+        if (cls[k] == U) return atom(k);
+        const Instr I = prog[k];
+        if (!(is_root || uses[k] <= 1)) return atom(k);
+        switch (I.op) {
+        case OP_ADD_PP: case OP_ADD_QQ: case OP_ADD_QP: {
+            std::vector<Mono> a = self(self, na[k], false), b = self(self, nb[k], false);
+            a.insert(a.end(), b.begin(), b.end());
+            if (a.size() > MAX_MONOS) too_big = true;
+            return a;
+        }
+        case OP_NEG_P: case OP_NEG_Q: {
+            std::vector<Mono> a = self(self, na[k], false);
+            for (auto& m : a) m.sign = -m.sign;
+            return a;
+        }
+        case OP_EMBED: return self(self, na[k], false);
+        case OP_MUL_PP: case OP_MUL_QQ: case OP_MUL_QP: {
+            std::vector<Mono> a = self(self, na[k], false), b = self(self, nb[k], false);
+            auto has_t = [](const std::vector<Mono>& v) { for (auto& m : v) if (!m.t.empty()) return true; return false; };
+            if (!(a.size() * b.size() <= MAX_CROSS && (a.size() == 1 || b.size() == 1 || !has_t(a) || !has_t(b)))) return atom(k);
+            std::vector<Mono> out;
+            for (auto& ma : a) for (auto& mb : b) {
+                Mono m;
+                m.sign = ma.sign * mb.sign;
+                m.u = ma.u; m.u.insert(m.u.end(), mb.u.begin(), mb.u.end());
+                m.x = ma.x; m.x.insert(m.x.end(), mb.x.begin(), mb.x.end());
+                m.t = ma.t; m.t.insert(m.t.end(), mb.t.begin(), mb.t.end());
+                out.push_back(std::move(m));
+            }
+            if (out.size() > MAX_MONOS) too_big = true;
+            return out;
+        }
+        default: return atom(k);
+        }
+    };
+    std::vector<Mono> monos = expand(expand, root, true);
+    if (too_big || (monos.size() < 2 && !force)) return R;
+    typedef std::vector<int> Key;
+    std::map<Key, std::map<Key, UV>> groups;
+    for (auto& m : monos) {
+        std::sort(m.x.begin(), m.x.end());
+        std::sort(m.t.begin(), m.t.end());
+        UV c{false, gl::ONE_MONT, {}};
+        for (int u : m.u) c = uv_mul(c, eval_u(eval_u, u));
+        if (m.sign < 0) c = uv_neg(c);
+        auto& g = groups[m.x];
+        auto it = g.find(m.t);
+        if (it == g.end()) g.emplace(m.t, c); else it->second = uv_add(it->second, c);
+    }
+    for (auto& g : groups)
+        for (auto it = g.second.begin(); it != g.second.end();) { if (uv_zero(it->second)) it = g.second.erase(it); else ++it; }
+    for (auto it = groups.begin(); it != groups.end();) { if (it->second.empty()) it = groups.erase(it); else ++it; }
+    if (groups.empty()) return R;
+    // ---- emission on typed virtual registers
+    std::vector<Instr> out;
+    std::vector<unsigned char> vq;                                           // type of every virtual register
+    std::vector<int> vreg_of(ninstr, -1);
+    auto new_v = [&](bool q) { vq.push_back(q ? 1 : 0); return (int)vq.size() - 1; };
+    unsigned cost = 0;
+    auto cost_of = [](const Instr& I) -> unsigned {
+        auto powc = [](uint32_t e, unsigned m) { return m * 2 * (32 - (unsigned)__builtin_clz(e | 1)); };
+        switch (I.op) {
+        case OP_MUL_PP: return 18; case OP_ADD_PP: case OP_NEG_P: case OP_ADD_QP: return 7;
+        case OP_MUL_QQ: return 215; case OP_MUL_QP: return 56; case OP_ADD_QQ: case OP_NEG_Q: return 21;
+        case OP_INV_P: return 1400; case OP_INV_Q: return 2200; case OP_POW_P: return powc(I.b, 18); case OP_POW_Q: return powc(I.b, 215);
+        case OP_X_P: case OP_XPOW_P: return 36;
+        case OP_ACC_MACC: return 6; case OP_ACC_MACP: return 11; case OP_ACC_RED: return 60; case OP_ACCQ_RED: return 180;
+        case OP_ACCQ_MACC: { static const unsigned c[4] = {6, 18, 18, 54}; return c[I.dst & 3]; }
+        case OP_ACCQ_MACP: return (I.dst & 1) ? 23 : 11;
+        default: return 0;
+        }
+    };
+    auto push = [&](const Instr& I) { out.push_back(I); cost += cost_of(I); };
+    auto emit_node = [&](auto&& self, int k) -> int {
+        if (vreg_of[k] >= 0) return vreg_of[k];
+        Instr I = prog[k];
+        if (na[k] >= 0) I.a = (uint32_t)self(self, na[k]);
+        if (nb[k] >= 0) I.b = (uint32_t)self(self, nb[k]);
+        const int v = new_v(isq[k]);
+        I.dst = (uint32_t)v;
+        push(I);
+        return vreg_of[k] = v;
+    };
+    int one_reg = -1;
+    auto get_one = [&]() {
+        if (one_reg < 0) { const uint32_t slot = (uint32_t)consts.size(); consts.push_back(gl::ONE_MONT); one_reg = new_v(false); push(Instr{OP_CONST_P, (uint32_t)one_reg, slot, 0}); }
+        return one_reg;
+    };
+    std::map<Key, int> prod_reg;
+    // product of atoms: the P atoms by Montgomery products, the Q atoms by extension products, then one mixed product; -1 = empty
+    auto product = [&](const Key& atoms) -> int {
+        if (atoms.empty()) return -1;
+        auto hit = prod_reg.find(atoms);
+        if (hit != prod_reg.end()) return hit->second;
+        int pp = -1, qq = -1;
+        for (int a : atoms) {
+            const int r = emit_node(emit_node, a);
+            if (vq[r]) { if (qq < 0) qq = r; else { const int v = new_v(true); push(Instr{OP_MUL_QQ, (uint32_t)v, (uint32_t)qq, (uint32_t)r}); qq = v; } }
+            else { if (pp < 0) pp = r; else { const int v = new_v(false); push(Instr{OP_MUL_PP, (uint32_t)v, (uint32_t)pp, (uint32_t)r}); pp = v; } }
+        }
+        int res = qq < 0 ? pp : qq;
+        if (qq >= 0 && pp >= 0) { res = new_v(true); push(Instr{OP_MUL_QP, (uint32_t)res, (uint32_t)qq, (uint32_t)pp}); }
+        prod_reg[atoms] = res;
+        return res;
+    };
+    auto limbs_p = [&](uint64_t c) { consts.push_back((c & 0x3FFFFFull) | (((c >> 22) & 0x3FFFFFull) << 32)); consts.push_back(c >> 44); };
+    auto const_slot = [&](const UV& c) -> uint32_t {                        // what OP_ACC(Q)_MACC reads
+        const uint32_t slot = (uint32_t)consts.size();
+        if (!c.q) limbs_p(c.p);
+        else { limbs_p(c.v.c0); limbs_p(c.v.c1); limbs_p(c.v.c2); limbs_p(gl::dbl(c.v.c1)); limbs_p(gl::dbl(c.v.c2)); }
+        return slot;
+    };
+    struct Outer { int d, x; };
+    std::vector<Outer> outer;
+    for (auto& g : groups) {
+        bool gq = false;
+        std::vector<std::pair<int, const UV*>> terms;                        // (T register or -1, coefficient)
+        for (auto& term : g.second) {
+            const int t = product(term.first);
+            terms.emplace_back(t, &term.second);
+            if (term.second.q || (t >= 0 && vq[t])) gq = true;
+        }
+        int d = -1;
+        if (terms.size() == 1 && terms[0].first >= 0 && uv_is_one(*terms[0].second)) d = terms[0].first;
+        else if (!gq && terms.size() <= 3) {                                // few P terms: products and additions
+            for (auto& tm : terms) {
+                const uint32_t slot = (uint32_t)consts.size();
+                consts.push_back(tm.second->p);
+                int v = new_v(false);
+                push(Instr{OP_CONST_P, (uint32_t)v, slot, 0});
+                if (tm.first >= 0) { const int w = new_v(false); push(Instr{OP_MUL_PP, (uint32_t)w, (uint32_t)tm.first, (uint32_t)v}); v = w; }
+                if (d < 0) d = v; else { const int w = new_v(false); push(Instr{OP_ADD_PP, (uint32_t)w, (uint32_t)d, (uint32_t)v}); d = w; }
+            }
+        } else {
+            std::vector<int> partial;
+            unsigned in_acc = 0;
+            const unsigned lim = gq ? ACC_MAX_TERMS_Q : ACC_MAX_TERMS_GL;
+            auto flush = [&]() {
+                const int v = new_v(gq);
+                push(gq ? Instr{OP_ACCQ_RED, (uint32_t)v, 0, 0} : Instr{OP_ACC_RED, (uint32_t)v, 0, 0});
+                partial.push_back(v); in_acc = 0;
+            };
+            for (auto& tm : terms) {
+                if (in_acc == 0) push(gq ? Instr{OP_ACCQ_ZERO, 0, 0, 0} : Instr{OP_ACC_ZERO, 0, 0, 0});
+                const int t = tm.first >= 0 ? tm.first : get_one();
+                const uint32_t slot = const_slot(*tm.second);
+                if (gq) push(Instr{OP_ACCQ_MACC, (uint32_t)((vq[t] ? 1 : 0) | (tm.second->q ? 2 : 0)), (uint32_t)t, slot});
+                else push(Instr{OP_ACC_MACC, 0, (uint32_t)t, slot});
+                if (++in_acc == lim) flush();
+            }
+            if (in_acc) flush();
+            d = partial[0];
+            for (size_t i = 1; i < partial.size(); i++) { const int w = new_v(gq); push(Instr{gq ? OP_ADD_QQ : OP_ADD_PP, (uint32_t)w, (uint32_t)d, (uint32_t)partial[i]}); d = w; }
+        }
+        outer.push_back(Outer{d, product(g.first)});
+    }
+    // ---- the outer sum  result = sum_g D_g * X_g
+    auto times = [&](int d, int x) -> int {                                 // one product as instructions
+        if (x < 0) return d;
+        if (!vq[d] && !vq[x]) { const int v = new_v(false); push(Instr{OP_MUL_PP, (uint32_t)v, (uint32_t)d, (uint32_t)x}); return v; }
+        const int v = new_v(true);
+        if (vq[d] && vq[x]) push(Instr{OP_MUL_QQ, (uint32_t)v, (uint32_t)d, (uint32_t)x});
+        else if (vq[d]) push(Instr{OP_MUL_QP, (uint32_t)v, (uint32_t)d, (uint32_t)x});
+        else push(Instr{OP_MUL_QP, (uint32_t)v, (uint32_t)x, (uint32_t)d});
+        return v;
+    };
+    int result = -1;
+    bool any_q = false;
+    for (auto& o : outer) if (vq[o.d] || (o.x >= 0 && vq[o.x])) any_q = true;
+    if (outer.size() <= 2 || (!any_q && outer.size() <= 4)) {
+        for (auto& o : outer) {
+            const int v = times(o.d, o.x);
+            if (result < 0) { result = v; continue; }
+            const int w = new_v(vq[result] || vq[v]);
+            if (vq[result] && vq[v]) push(Instr{OP_ADD_QQ, (uint32_t)w, (uint32_t)result, (uint32_t)v});
+            else if (vq[result]) push(Instr{OP_ADD_QP, (uint32_t)w, (uint32_t)result, (uint32_t)v});
+            else if (vq[v]) push(Instr{OP_ADD_QP, (uint32_t)w, (uint32_t)v, (uint32_t)result});
+            else push(Instr{OP_ADD_PP, (uint32_t)w, (uint32_t)result, (uint32_t)v});
+            result = w;
+        }
+    } else {
+        std::vector<int> partial;
+        unsigned in_acc = 0;
+        const unsigned lim = any_q ? ACC_MAX_TERMS_Q : ACC_MAX_TERMS_GL;
+        auto flush = [&]() {
+            const int v = new_v(any_q);
+            push(any_q ? Instr{OP_ACCQ_RED, (uint32_t)v, 0, 0} : Instr{OP_ACC_RED, (uint32_t)v, 0, 0});
+            partial.push_back(v); in_acc = 0;
+        };
+        UV one{false, gl::ONE_MONT, {}};
+        uint32_t one_slot = 0;
+        bool have_one_slot = false;
+        for (auto& o : outer) {
+            if (in_acc == 0) push(any_q ? Instr{OP_ACCQ_ZERO, 0, 0, 0} : Instr{OP_ACC_ZERO, 0, 0, 0});
+            int d = o.d, x = o.x;
+            if (!any_q) push(Instr{OP_ACC_MACP, 0, (uint32_t)d, (uint32_t)(x >= 0 ? x : get_one())});
+            else {
+                if (x >= 0 && vq[d] && vq[x]) { d = times(d, x); x = -1; }   // Q x Q (rare: an extension-valued table): reduced product, then added
+                if (x < 0) {
+                    if (!have_one_slot) { one_slot = const_slot(one); have_one_slot = true; }
+                    push(Instr{OP_ACCQ_MACC, (uint32_t)(vq[d] ? 1 : 0), (uint32_t)d, one_slot});
+                } else if (vq[d]) push(Instr{OP_ACCQ_MACP, 1, (uint32_t)d, (uint32_t)x});
+                else if (vq[x]) push(Instr{OP_ACCQ_MACP, 1, (uint32_t)x, (uint32_t)d});
+                else push(Instr{OP_ACCQ_MACP, 0, (uint32_t)d, (uint32_t)x});
+            }
+            if (++in_acc == lim) flush();
+        }
+        if (in_acc) flush();
+        result = partial[0];
+        for (size_t i = 1; i < partial.size(); i++) { const int w = new_v(any_q); push(Instr{any_q ? OP_ADD_QQ : OP_ADD_PP, (uint32_t)w, (uint32_t)result, (uint32_t)partial[i]}); result = w; }
+    }
+    if (root_q && !vq[result]) { const int w = new_v(true); push(Instr{OP_EMBED, (uint32_t)w, (uint32_t)result, 0}); result = w; }
+    if (!root_q && vq[result]) return R;                                    // cannot happen for a validated program
+    out.push_back(Instr{root_q ? (uint32_t)OP_STORE_Q : (uint32_t)OP_STORE_P, 0, (uint32_t)result, 0});
+    unsigned old_cost = 0;
+    for (unsigned k = 0; k < ninstr; k++) if (cls[k] != U) old_cost += cost_of(prog[k]);
+    R.old_cost = old_cost; R.new_cost = cost;
+    if (cost * 10 > old_cost * 9 && !force) return R;
+    // ---- virtual -> physical, one pool per register file
+    auto reads = [&](const Instr& I, uint32_t* r) -> int {
+        switch (I.op) {
+        case OP_ACC_MACC: case OP_ACCQ_MACC: r[0] = I.a; return 1;
+        case OP_ACC_MACP: case OP_ACCQ_MACP: r[0] = I.a; r[1] = I.b; return 2;
+        case OP_ACC_ZERO: case OP_ACCQ_ZERO: case OP_ACC_RED: case OP_ACCQ_RED: case OP_XPOW_P: return 0;
+        default: {
+            unsigned opnd[2][2];
+            const int n = op_operands(I, opnd);
+            for (int i = 0; i < n; i++) r[i] = opnd[i][1];
+            return n;
+        }
+        }
+    };
+    auto writes = [](const Instr& I) {
+        return !op_is_store(I.op) && I.op != OP_ACC_ZERO && I.op != OP_ACC_MACC && I.op != OP_ACC_MACP && I.op != OP_ACCQ_ZERO && I.op != OP_ACCQ_MACC && I.op != OP_ACCQ_MACP;
+    };
+    const int nv = (int)vq.size();
+    std::vector<int> last(nv, -1), phys(nv, -1);
+    for (size_t k = 0; k < out.size(); k++) { uint32_t r[2]; const int n = reads(out[k], r); for (int i = 0; i < n; i++) last[r[i]] = (int)k; }
+    std::vector<int> free_regs[2];
+    unsigned next[2] = {0, 0}, maxr[2] = {0, 0};
+    const unsigned cap[2] = {256, 128};
+    for (size_t k = 0; k < out.size(); k++) {
+        Instr& I = out[k];
+        uint32_t r[2];
+        const int n = reads(I, r);
+        const uint32_t v0 = n >= 1 ? r[0] : 0, v1 = n == 2 ? r[1] : 0;
+        if (n >= 1) I.a = (uint32_t)phys[v0];
+        if (n == 2) I.b = (uint32_t)phys[v1];
+        for (int i = 0; i < n; i++) { const uint32_t v = i == 0 ? v0 : v1; if (last[v] == (int)k && !(i == 1 && v1 == v0)) free_regs[vq[v]].push_back(phys[v]); }
+        if (writes(I)) {
+            const uint32_t v = I.dst;
+            const int f = vq[v];
+            int p;
+            if (!free_regs[f].empty()) { std::sort(free_regs[f].begin(), free_regs[f].end(), std::greater<int>()); p = free_regs[f].back(); free_regs[f].pop_back(); }
+            else p = (int)next[f]++;
+            if ((unsigned)p >= cap[f]) return R;
+            phys[v] = p;
+            I.dst = (uint32_t)p;
+            maxr[f] = std::max(maxr[f], (unsigned)p + 1);
+            if (last[v] < 0) free_regs[f].push_back(p);
+        }
+    }
+    R.prog.swap(out);
+    R.maxp = maxr[0]; R.maxq = maxr[1];
     R.active = true;
     return R;
 }

@@ -113,12 +113,14 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     Regrouped regrouped;
     {
         static const bool off = getenv("MS_EVAL_REGROUP") && !strcmp(getenv("MS_EVAL_REGROUP"), "0");
-        if (!off && maxq == 0 && out_field != MS_GOLDILOCKS_FQ3) {
+        if (!off) {
             static const bool force = getenv("MS_EVAL_REGROUP") && !strcmp(getenv("MS_EVAL_REGROUP"), "force");     // the fuzzers: whenever it CAN be applied
-            regrouped = is252 ? regroup_sums_of_products<Host252>(main_prog, main_n, consts, force) : regroup_sums_of_products<HostGL>(main_prog, main_n, consts, force);
+            if (is252) regrouped = regroup_sums_of_products<Host252>(main_prog, main_n, consts, force);
+            else if (maxq == 0 && out_field != MS_GOLDILOCKS_FQ3) regrouped = regroup_sums_of_products<HostGL>(main_prog, main_n, consts, force);
+            else regrouped = regroup_sums_of_products_q(main_prog, main_n, consts, force);
             if (getenv("MS_EVAL_DEBUG")) fprintf(stderr, "regroup: %s, estimated vector instructions per point %u -> %u\n", regrouped.active ? "applied" : "not applied", regrouped.old_cost, regrouped.new_cost);
             if (regrouped.active && getenv("MS_EVAL_DEBUG")) for (auto& I : regrouped.prog) fprintf(stderr, "  regr: op %2u dst %u a %u b %u\n", I.op, I.dst, I.a, I.b);
-            if (regrouped.active) { main_prog = regrouped.prog.data(); main_n = (unsigned)regrouped.prog.size(); maxp = std::max(maxp, regrouped.maxp); }
+            if (regrouped.active) { main_prog = regrouped.prog.data(); main_n = (unsigned)regrouped.prog.size(); maxp = std::max(maxp, regrouped.maxp); maxq = std::max(maxq, regrouped.maxq); }
         }
     }
     // ---- program(s) + constants -> device
@@ -301,7 +303,10 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
             hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 16>), dim3((unsigned)((m + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
             hipLaunchKernelGGL((batch_inverse_down<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, nn, (const uint64_t*)prod);
         }
-        for (size_t t = ntab_merged; t < isplit.table_words.size(); t++) {
+        // (Fp tables stay one launch each at 16 elements per inverse: merged at 32 per inverse the kernel holds 128 registers and was slower,
+        // 95 -> 106 us for the fib AIR's two tables at 2^23 points)
+        const size_t t_first = ntab_merged;
+        for (size_t t = t_first; t < isplit.table_words.size(); t++) {
             const unsigned w = isplit.table_words[t];
             ProfScope ps(ctx, "eval_batch_inverse", 16.0 * w * n);
             // Fp / Fq3: the stage's kernel, in place (it keeps the K values in registers: one read and one write of the table)
