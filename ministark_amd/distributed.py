@@ -609,6 +609,28 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
         out["nonce"] = grind_proof_of_work(pl, roots[-1] if roots else out["composition_root"], grinding_bits)
     lap("remainder + proof of work")
     positions = [int(p) for p in draws.positions]
+    if G == 1:
+        # one rank holds every row and every digest: the openings are the single-device ones (no owners to compute, nothing to collect) --
+        # the same gathers into one buffer and one download that pipeline.prove_phases issues
+        from .api import GatherBatch, Queries
+        from .pipeline import fri_layer_rows_launch
+        gb = GatherBatch(pl)
+        qs = Queries(Matrix(base_shard), None, Matrix(comp_shard), tree_b.local, None, tree_c.local, positions, gb)
+        pos, launched = sorted(set(positions)), []
+        for lay, tree, _, _size in layers:
+            pos = fold_positions(pos, folding)
+            local_tree = tree.local if isinstance(tree, ShardedTree) else tree
+            launched.append((pos, fri_layer_rows_launch(lay, folding, pos, gb), local_tree.prove_launch(pos, gb)))
+        lap("openings: index walks + requests")
+        gb.fetch()
+        lap("openings: gathers + exchange + download")
+        qs.fetch()
+        out["queries"] = {"base_trace_proof": qs.base_trace_proof, "composition_trace_proof": qs.composition_trace_proof,
+                          "base_trace_values": qs.base_trace_values, "composition_trace_values": qs.composition_trace_values,
+                          "extension_trace_proof": None, "extension_trace_values": None}
+        out["fri_openings"] = [{"positions": p_, "rows": rows(), "proof": proof()} for p_, rows, proof in launched]
+        lap("openings: assembly")
+        return out
     batch = OpeningBatch(pl, comm)                              # every opening of the proof: one exchange, one download
     kq = {"base_trace_proof": tree_b.request(batch, positions), "composition_trace_proof": tree_c.request(batch, positions),
           "base_trace_values": _rows_request(batch, base_shard, GOLDILOCKS_FP, positions, rows),

@@ -175,3 +175,44 @@ def test_sharded_commit_world1_nccl_hip(tmp_path):
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
     assert open(f).read().split("\n") == _expected() + ["eval_ok"]
+
+
+def test_whole_prover_with_one_rank_equals_the_single_device_prover_emu():
+    """N = 1 of the sharded prover (what `bench.py` times next to `prove`): nothing is exchanged, the shards alias the columns, the
+    openings take the single-device path -- and every output equals pipeline.prove_phases'."""
+    from tests import backends
+    from ministark_amd import GOLDILOCKS_FP, Matrix, pipeline
+    from ministark_amd.distributed import prove_sharded
+
+    class OneRank:                                           # the communicator surface prove_sharded uses, for a world of one
+        rank, world = 0, 1
+
+        def cols_to_rows(self, my_cols, total_cols, nrows, field=GOLDILOCKS_FP):
+            assert len(my_cols) == total_cols
+            return list(my_cols)
+
+        def p2p(self, ops):
+            assert not ops
+
+        def allgather_digests(self, ptr):
+            raise AssertionError("no all-gather with one rank")
+    pl = backends.planner("emu")
+    log_rows, ncols, blowup, folding, max_rem = 9, 8, 4, 8, 16
+    n_t = 1 << log_rows
+    cols = [cref.random_elements(n_t, 300 + c) for c in range(ncols)]
+    comp, ce, nch = pipeline.fib_constraints(n_t, ncols)
+    draws = pipeline.Draws(0xC5, ncols, nch, ce, 12, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, max_rem))
+    got = prove_sharded(pl, OneRank(), cols, ncols, log_rows, comp, draws, blowup, folding, max_rem, 6, ce_blowup=ce)
+    want = pipeline.prove_phases(pl, Matrix.from_numpy(pl, cols, GOLDILOCKS_FP), comp, draws, blowup, folding, max_rem, 6, ce_blowup=ce)
+    assert got["base_root"] == want["base_root"] and got["composition_root"] == want["composition_root"]
+    assert got["fri_roots"] == want["fri_roots"] and got["nonce"] == want["nonce"]
+    assert np.array_equal(got["remainder_coeffs"], want["remainder_coeffs"])
+    assert list(got["ood"][0]) == list(want["ood"][0]) and list(got["ood"][1]) == list(want["ood"][1])
+    wq = want["queries"]
+    for name in ("base_trace_proof", "composition_trace_proof"):
+        assert got["queries"][name] == getattr(wq, name)
+    for name in ("base_trace_values", "composition_trace_values"):
+        assert np.array_equal(got["queries"][name], getattr(wq, name))
+    assert len(got["fri_openings"]) == len(want["fri_openings"]) > 0
+    for a, b in zip(got["fri_openings"], want["fri_openings"]):
+        assert a["positions"] == b["positions"] and np.array_equal(a["rows"], b["rows"]) and a["proof"] == b["proof"]
