@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Random constraint expressions through compile_expr -> ms_eval_program (table hoisting, x^e lookups,
 interpreter on small domains, hiprtc-specialised kernels on 2^16 points) against the oracle's direct
-evaluation at sampled points:   python tests/fuzz_eval.py [seconds] [seed]"""
+evaluation at sampled points:   python tests/fuzz_eval.py [seconds] [seed]
+MS_FUZZ_BACKEND=emu: on the simulator build (small domains).  MS_FUZZ_FIELD=f252: programs over the 252-bit field (Fq = Fp; every output
+against the C oracle).  MS_EVAL_REGROUP=force: the sums-of-products pass applied wherever it can be."""
 import os
 import sys
 import time
@@ -26,6 +28,9 @@ if EMU:
 else:
     pl = Planner(0)
 P = GL.p
+F252 = os.environ.get("MS_FUZZ_FIELD") == "f252"
+if F252:
+    from ministark_amd import STARK252_FP  # noqa: E402
 
 
 def rand_expr(depth, nbase, next_, nch, log_n):
@@ -67,10 +72,28 @@ t0, count, jit = time.time(), 0, 0
 while time.time() - t0 < budget:
     log_n = int(rng.choice([6, 8, 9, 12] if EMU else [6, 9, 12, 12, 13, 16]))
     n = 1 << log_n
-    fq_is_ext = bool(rng.integers(0, 2))
+    fq_is_ext = bool(rng.integers(0, 2)) and not F252
     nbase, next_, nch = int(rng.integers(1, 4)), (int(rng.integers(0, 3)) if fq_is_ext else 0), int(rng.integers(0, 3))
     lde_step, offset = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 3, 7]))
     expr = rand_expr(int(rng.integers(2, 6)), nbase, next_, nch, log_n)
+    if F252:                                    # 4-word elements below 2^251 < p; the C oracle checks every output
+        def el(k, sd):
+            r = np.random.default_rng(sd)
+            a = r.integers(0, 1 << 63, size=4 * k, dtype=np.uint64)
+            a[3::4] >>= np.uint64(4)
+            return a
+        base = [el(n, seed * 1000 + count * 7 + c) for c in range(nbase)]
+        ch = el(max(nch, 1), count + 90).reshape(-1, 4)
+        prog = E.compile_expr(expr, nbase, False, STARK252_FP)
+        out = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, STARK252_FP) for c in base], []).to_numpy()
+        want_all = cref.eval_expr(expr, log_n, lde_step, offset, base, [], ch, ch[:1], False, field="f252")
+        if not np.array_equal(out, want_all):
+            bad = np.nonzero(out != want_all)[0]
+            print(f"MISMATCH (252-bit) case {count} (seed {seed}): log_n={log_n} lde_step={lde_step} offset={offset}: {bad.size} words differ, first at {bad[:4]}; {len(prog.instrs)} instructions")
+            sys.exit(1)
+        count += 1
+        jit += log_n >= 16
+        continue
     qw = 3 if fq_is_ext else 1
     base = [cref.random_elements(n, seed * 1000 + count * 7 + c) for c in range(nbase)]
     ext = [cref.random_elements(3 * n, seed * 1000 + count * 7 + 50 + c) for c in range(next_)]

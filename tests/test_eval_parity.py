@@ -298,3 +298,43 @@ def test_x_only_denominators_are_batch_inverted(kind):
     prog = E.compile_expr(comp, 8, False, STARK252_FP)
     got = E.eval(prog, pl, ch, ch[:1], 4, 3, n, [GpuVec.from_numpy(pl, c, STARK252_FP) for c in cols]).to_numpy()
     assert np.array_equal(got, cref.eval_expr(comp, log_n, 4, 3, cols, [], ch, ch[:1], False, field="f252"))
+
+
+@pytest.mark.parametrize("field", ["goldilocks", "f252", "mixed"])
+def test_sums_of_products_pass_on_the_reference_airs_emu(field):
+    """csrc/eval_regroup.h on the shapes it was written for -- the reference's fib AIR over Goldilocks and over the 252-bit field, the
+    17 Fp + 9 Fq3 composition -- on the simulator (the interpreter executes the accumulator opcodes): every output equals the C oracle's
+    (the switch MS_EVAL_REGROUP is read once per process: on / off / forced are compared by tests/test_fuzz_gpu.py in their own processes)."""
+    import numpy as np
+    from oracle import cref
+    from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3, STARK252_FP, GpuVec, pipeline
+    pl = backends.planner("emu")
+    log_n = 10
+    n = 1 << log_n
+    rng = np.random.default_rng(77)
+    P = (1 << 64) - (1 << 32) + 1
+    if field == "goldilocks":
+        step, off = 1, 7
+        comp, _, nch = pipeline.fib_constraints(n)
+        base = [rng.integers(0, P, size=n, dtype=np.uint64) for _ in range(8)]
+        ext, ch = [], rng.integers(1, P, size=(nch, 1), dtype=np.uint64)
+        prog, bf, ext_flag, kw = E.compile_expr(comp, 8, False, GOLDILOCKS_FP), GOLDILOCKS_FP, False, {}
+    elif field == "f252":
+        step, off = 4, 3
+        comp, _, nch = pipeline.fib_constraints(n // step, 8, STARK252_FP)
+        base = [rng.integers(0, 1 << 63, size=4 * n, dtype=np.uint64) for _ in range(8)]
+        for c in base:
+            c[3::4] >>= np.uint64(4)
+        ext, ch = [], rng.integers(0, 1 << 59, size=(nch, 4), dtype=np.uint64)
+        prog, bf, ext_flag, kw = E.compile_expr(comp, 8, False, STARK252_FP), STARK252_FP, False, {"field": "f252"}
+    else:
+        step, off = 2, 7
+        comp, nch = pipeline.mixed_air_constraints()
+        base = [rng.integers(0, P, size=n, dtype=np.uint64) for _ in range(17)]
+        ext = [rng.integers(0, P, size=3 * n, dtype=np.uint64) for _ in range(9)]
+        ch = rng.integers(1, P, size=(nch, 3), dtype=np.uint64)
+        prog, bf, ext_flag, kw = E.compile_expr(comp, 17, True, GOLDILOCKS_FP), GOLDILOCKS_FP, True, {}
+    want = cref.eval_expr(comp, log_n, step, off, base, ext, ch, ch[:1], ext_flag, **kw)
+    dbase = [GpuVec.from_numpy(pl, c, bf) for c in base]
+    dext = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FQ3) for c in ext]
+    assert np.array_equal(E.eval(prog, pl, ch, ch[:1], step, off, n, dbase, dext).to_numpy(), want)
