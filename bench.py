@@ -423,6 +423,40 @@ def bench_c2_sweep(pl):
     return out
 
 
+def bench_reference_harness(pl):
+    """The reference's own criterion harness (gpu/benches/fft.rs:18-74): sizes 2048 / 4096 / 32768 / 262144, ONE column, every iteration
+    builds the plan (`GpuFft::from(domain)`), encodes the column and executes (a device synchronisation) -- a LATENCY figure, over the
+    64-bit and the 252-bit field, subgroup and coset, forward and inverse.  The column is device-resident here (the reference's is in
+    Apple's unified memory: no copy either).  Microseconds per iteration, median of 30."""
+    from ministark_amd import GOLDILOCKS_FP, STARK252_FP, GpuFft, GpuIfft, GpuVec, Radix2EvaluationDomain
+    rng = np.random.default_rng(18)
+    out = {"workload": "gpu/benches/fft.rs: plan + encode + execute of one resident column per iteration (latency)", "unit": "us per iteration", "sizes": {}}
+    for n in (2048, 4096, 32768, 262144):
+        row = {}
+        for fname, field, words in (("fp64", GOLDILOCKS_FP, 1), ("fp252", STARK252_FP, 4)):
+            if words == 1:
+                col = GpuVec.from_numpy(pl, rng.integers(0, P_GOLDILOCKS, size=n, dtype=np.uint64), field)
+            else:
+                a = rng.integers(0, 1 << 63, size=4 * n, dtype=np.uint64)
+                a[3::4] >>= np.uint64(4)
+                col = GpuVec.from_numpy(pl, a, field)
+            gen = 7 if words == 1 else 3
+            for vname, cls, dom in (("GpuFft", GpuFft, Radix2EvaluationDomain(n, 1, field)), ("GpuFft (coset)", GpuFft, Radix2EvaluationDomain(n, gen, field)),
+                                    ("GpuIfft", GpuIfft, Radix2EvaluationDomain(n, 1, field)), ("GpuIfft (coset)", GpuIfft, Radix2EvaluationDomain(n, gen, field))):
+                ts = []
+                for it in range(34):
+                    t0 = time.perf_counter()
+                    plan = cls(dom, field, pl)
+                    plan.encode(col)
+                    plan.execute()
+                    ts.append(time.perf_counter() - t0)
+                    plan.close()
+                row[f"{fname} {vname}"] = round(sorted(ts[4:])[15] * 1e6, 1)
+            col.free()
+        out["sizes"][str(n)] = row
+    return out
+
+
 def bench_lde_commit(pl, with_cpu, pmc=None):
     """configs[2] (C3): 2^20 rows x 32 columns, blow-up 8, coset NTT + Merkle commit on one GPU."""
     import numpy as np
@@ -963,6 +997,7 @@ def main():
         for c in cols:
             c.free()
         out["c2_sweep"] = bench_c2_sweep(pl)
+        out["reference_criterion_harness"] = bench_reference_harness(pl)
         out["lde_commit"] = bench_lde_commit(pl, not args.no_cpu_baseline)
         out["lde_2_24"] = bench_lde_2_24(pl)
         out["constraint_eval"] = bench_constraint_eval(pl, not args.no_cpu_baseline)

@@ -54,7 +54,26 @@ void plans_release_ctx(ms_ctx* ctx) {
 static int plan_create_impl(ms_ctx* ctx, int field, unsigned log_n, int inverse, const void* h_offset, const void* h_group_gen, ms_ntt_plan** out) {
     unsigned V = 0;
     MSCHK(field_words(field, &V));
-    if (V == 4) return plan_build252(ctx, log_n, inverse != 0, h_offset, h_group_gen, out);
+    if (V == 4) {
+        // the 252-bit plans are cached per context like the Goldilocks ones (round 5: a handle used to build its own tables -- 2^18 powers
+        // of a 252-bit root on the host, 6-16 ms per `GpuFft::from(domain)` in the reference's criterion harness, gpu/benches/fft.rs)
+        if (log_n > 40) return fail(MS_ERR_INVALID, "log_n = %u too large", log_n);
+        if (h_group_gen) {
+            f252::E g; memcpy(g.l, h_group_gen, 32);
+            if (!f252::eq(g, f252::root_of_unity(log_n))) return fail(MS_ERR_UNSUPPORTED, "group_gen is not arkworks' get_root_of_unity(2^%u)", log_n);
+        }
+        f252::E h = f252::one();
+        if (h_offset) memcpy(h.l, h_offset, 32);
+        if (f252::is_zero(h) || f252::geq_p(h)) return fail(MS_ERR_INVALID, "coset offset must be a non-zero canonical element");
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ms_ntt_plan* base = nullptr;
+        MSCHK(plan252_cached(ctx, log_n, inverse != 0, h, &base));
+        ms_ntt_plan* handle = new ms_ntt_plan(*base);
+        handle->base = base; handle->refs = 0; handle->queue.clear(); handle->lde2.clear();
+        base->refs++;
+        *out = handle;
+        return MS_OK;
+    }
     if (log_n > 32) return fail(MS_ERR_INVALID, "log_n = %u exceeds the field's two-adicity (32)", log_n);
     if (h_group_gen) {
         uint64_t g_m;
