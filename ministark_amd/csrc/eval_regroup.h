@@ -37,7 +37,6 @@ struct Regrouped {
 // host arithmetic on the uniform values (Montgomery words, as the kernels compute)
 struct HostGL {
     typedef uint64_t T;
-    static constexpr unsigned W = 1;
     static T load(const uint64_t* p) { return p[0]; }
     static T zero() { return 0; }
     static T one() { return gl::ONE_MONT; }
@@ -60,7 +59,6 @@ struct HostGL {
 };
 struct Host252 {
     typedef f252::E T;
-    static constexpr unsigned W = 4;
     static T load(const uint64_t* p) { T r; memcpy(r.l, p, 32); return r; }
     static T zero() { return f252::zero(); }
     static T one() { return f252::one(); }
