@@ -34,7 +34,8 @@
 
 namespace msntt {
 
-static constexpr int MAXC = 128;       // columns per launch (grid.y): small columns need many per launch to fill 2048 workgroup slots
+static constexpr int MAXC = 256;       // columns per launch (grid.y): small columns need many per launch to fill the workgroup slots (round 5: 128 -> 256,
+                                       // 4 KiB of pointers in the kernel arguments: 2^15 x 256 columns 0.19 -> 0.245 of HBM, 2^14 x 256 0.11 -> 0.19)
 static constexpr int TILE = 4096;      // words per workgroup tile
 static constexpr int NT = 256;         // threads per workgroup
 static constexpr int LDS_PAD_CS = 144; // c-stride (words) of the mid-pass exchange layout (half tile + 16)

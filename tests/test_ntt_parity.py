@@ -548,11 +548,11 @@ def test_plan_outlives_its_context_safely(kind):
 
 # A batch larger than one launch holds (msntt::MAXC = 128 columns per launch): the groups must tile the batch exactly.
 def test_batch_wider_than_a_launch_emu():
-    _run("emu", GOLDILOCKS_FP, 12, False, 7, ncols=131)
+    _run("emu", GOLDILOCKS_FP, 12, False, 7, ncols=259)                      # a launch takes 256 columns (msntt::MAXC)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n,inverse,ncols", [(10, False, 260), (12, False, 131), (14, True, 129), (16, False, 130)])
+@pytest.mark.parametrize("log_n,inverse,ncols", [(10, False, 520), (12, False, 259), (14, True, 257), (16, False, 258)])
 def test_batch_wider_than_a_launch_hip(log_n, inverse, ncols):
     _run("hip", GOLDILOCKS_FP, log_n, inverse, 7, ncols=ncols)
 
