@@ -40,6 +40,8 @@ Extra objects on the JSON line:
                  default_prove on configs[4]'s shape (2^22 rows x 8 columns, ProofOptions::new(32, 4, 8, 8, 64)),
                  device-resident, fixed challenges in place of the channel (ministark_amd/pipeline.py); phases,
                  per-kernel time, and the oracle chain timed once at the same size.                   [N = 1 only]
+                 `one_rank_sharded_interleaved`: the same proof through distributed.prove_sharded over a one-rank
+                 communicator, the two provers taking turns on the same trace (what N = 1 of the multi-GPU path costs).
   sharded_lde_commit : configs[4]'s multi-GPU step for any N (also N = 1, where RCCL runs with one rank): a
                  2^22-row x 32-column trace, blow-up 4, columns sharded over the ranks -> LDE (no communication) ->
                  ms_cols_to_rows_alltoall -> row hashing + subtree -> ms_allgather_digests -> top levels.  The total
@@ -582,6 +584,34 @@ def bench_prove(pl, with_cpu, pmc=None):
                         "frac": round(alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
            "base_root": res["base_root"].hex(), "nonce": res["nonce"]}
     out["roofline"]["_res"] = ("prove", kernel_ms * 1e3, float(n_t) * ncols, None, "trace_cell")
+    try:
+        # the same proof through distributed.prove_sharded over a ONE-rank communicator, the two provers taking turns on the same trace
+        # (the sharded_lde_commit object is timed minutes earlier in the run, on other data): what N = 1 of the multi-GPU path costs
+        from ministark_amd.distributed import RcclComm, prove_sharded
+        with _stdout_to_stderr():
+            comm = RcclComm(pl, 0, 1, RcclComm.unique_id(pl.lib))
+            try:
+                a_ms, b_ms, same = [], [], True
+                for it in range(6):
+                    pl.sync()
+                    t0 = time.perf_counter()
+                    run()
+                    pl.sync()
+                    t1 = time.perf_counter()
+                    sh = prove_sharded(pl, comm, list(trace.columns), ncols, log_t, comp, draws, blowup, folding, 64, 8, ce_blowup=ce)
+                    pl.sync()
+                    t2 = time.perf_counter()
+                    same = same and sh["base_root"] == res["base_root"] and sh["nonce"] == res["nonce"]
+                    if it:
+                        a_ms.append((t1 - t0) * 1e3)
+                        b_ms.append((t2 - t1) * 1e3)
+            finally:
+                comm.close()
+        a, b = sorted(a_ms)[len(a_ms) // 2], sorted(b_ms)[len(b_ms) // 2]
+        out["one_rank_sharded_interleaved"] = {"prove_ms": round(a, 3), "prove_sharded_ms": round(b, 3), "ratio": round(b / a, 4), "same_root_and_nonce": bool(same),
+                                               "how": "5 timed rounds of pipeline.prove_phases then distributed.prove_sharded (world size 1) on the same trace, medians"}
+    except Exception as e:                                       # noqa: BLE001 -- for information; the figures above stand
+        out["one_rank_sharded_interleaved"] = {"error": f"{type(e).__name__}: {e}"}
     for c in trace.columns:
         c.free()
     out["native_host"] = _native_prove(log_t)
