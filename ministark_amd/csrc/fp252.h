@@ -137,6 +137,24 @@ MS_HD E mul_t(const E& a, const E& b) {
     return reduce_columns<CANON>(c);
 }
 MS_HD E mul(const E& a, const E& b) { return mul_t<true>(a, b); }
+// a * a * 2^-256 mod p for a CANONICAL a: the 81 digit products are 9 squares and 36 products taken twice -- 45 multiply-adds, the second
+// factor of the pairs doubled once (digits < 2^28, the top one < 2^27.1: the doubles fit 32 bits and a column holds what mul's holds).
+MS_HD E sqr(const E& a) {
+    uint32_t x[9], x2[9];
+    digits9(a, x);
+    #pragma unroll
+    for (int i = 0; i < 9; i++) x2[i] = x[i] << 1;
+    uint64_t c[19];
+    #pragma unroll
+    for (int k = 0; k < 19; k++) c[k] = 0;
+    #pragma unroll
+    for (int i = 0; i < 9; i++) {
+        c[2 * i] += (uint64_t)x[i] * x[i];
+        #pragma unroll
+        for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)x[i] * x2[j];
+    }
+    return reduce_columns<true>(c);
+}
 
 // ---- lazy forms for long butterfly chains: residues kept below 2^256 ~ 31.9 p, no conditional subtractions -------------
 MS_HD E add_lazy(const E& a, const E& b) {          // a + b, the caller guarantees a + b < 2^256
@@ -184,7 +202,7 @@ MS_HD E pow(E a, const uint64_t* e, int nlimbs) {
         uint64_t w = e[i];
         for (int b = 0; b < 64; b++) {
             if (w & 1) r = mul(r, a);
-            a = mul(a, a);
+            a = sqr(a);
             w >>= 1;
         }
     }
@@ -192,12 +210,26 @@ MS_HD E pow(E a, const uint64_t* e, int nlimbs) {
 }
 MS_HD E pow_u64(E a, uint64_t e) {
     E r = one();
-    while (e) { if (e & 1) r = mul(r, a); e >>= 1; if (e) a = mul(a, a); }
+    while (e) { if (e & 1) r = mul(r, a); e >>= 1; if (e) a = sqr(a); }
     return r;
 }
-MS_HD E inv(const E& a) {                 // a^(p-2); inv(0) = 0
-    const uint64_t e[4] = {P0 - 2, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, P3 - 1};   // p - 2 (borrow through the zero limbs)
-    return pow(a, e, 4);
+MS_HD E sqr_n(E a, int k) {               // a^(2^k)
+    #pragma unroll 1
+    for (int i = 0; i < k; i++) a = sqr(a);
+    return a;
+}
+// a^(p-2); inv(0) = 0.  p - 2 = 2^192 c - 1 with c = 2^59 + 17, and 2^192 c - 1 = c (2^192 - 1) + (c - 1): with b = a^c the inverse is
+// b^(2^192 - 1) a^(c-1) -- 250 squarings and 11 products (the run of 192 ones through 2^k - 1 for k = 2, 3, 6, 12, ..., 192) where
+// square-and-multiply over the bits of p - 2 takes 256 and 194.  The inverse is unique: the same words either way.
+MS_HD E inv(const E& a) {
+    const E a16 = sqr_n(a, 4);
+    const E am = mul(sqr_n(a16, 55), a16);                   // a^(2^59 + 16) = a^(c-1)
+    const E b = mul(am, a);                                  // a^c
+    E x = mul(sqr(b), b);                                    // b^(2^2 - 1)
+    x = mul(sqr(x), b);                                      // b^(2^3 - 1)
+    #pragma unroll 1
+    for (int k = 3; k < 192; k *= 2) x = mul(sqr_n(x, k), x);    // b^(2^2k - 1) = (b^(2^k - 1))^(2^k) b^(2^k - 1)
+    return mul(x, am);
 }
 MS_HD bool eq(const E& a, const E& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
 
