@@ -300,7 +300,11 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
             void* prod = nullptr;
             MSCHK(pooled.alloc(m * 32, &prod));
             hipLaunchKernelGGL((batch_inverse_up<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, nn, (uint64_t*)prod);
-            hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 16>), dim3((unsigned)((m + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
+            // the middle level: one Fermat inverse (55 000 instructions) per lane -- 32 products per lane while that still leaves a wave per SIMD
+            size_t min_lanes = 65536;                            // (MS_EVAL_INV_MIN_LANES: the tests reach the wide variant on a small domain)
+            if (const char* e = getenv("MS_EVAL_INV_MIN_LANES")) min_lanes = (size_t)std::max(1L, atol(e));
+            if (m >= 32 * min_lanes) hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 32>), dim3((unsigned)((m + NT * 32 - 1) / (NT * 32))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
+            else hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 16>), dim3((unsigned)((m + NT * 16 - 1) / (NT * 16))), dim3(NT), 0, ctx->stream, (uint64_t*)prod, m);
             hipLaunchKernelGGL((batch_inverse_down<msstage::Fp252T, 8>), dim3(blocks), dim3(NT), 0, ctx->stream, tp, nn, (const uint64_t*)prod);
         }
         // (Fp tables stay one launch each at 16 elements per inverse: merged at 32 per inverse the kernel holds 128 registers and was slower,
