@@ -52,7 +52,7 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
             case OP_POW_P: snprintf(b, sizeof b, "p%u = msstage::powu<F4>(p%u, %uu);", d, x, y); break;
             case OP_STORE_P: snprintf(b, sizeof b, "ev252_store(P, R, %uu, p%u);", y, x); break;
             case OP_XPOW_P: snprintf(b, sizeof b, "p%u = ev252_xpow(P, i, %uu, %uu);", d, x, y); break;
-            case OP_TABLE_P: snprintf(b, sizeof b, "p%u = ev252_table(P, R, %uu);", d, x); break;
+            case OP_TABLE_P: snprintf(b, sizeof b, "p%u = ev252_table(P, R, i, %uu, %uu);", d, x, y); break;
             case OP_ACC_ZERO: snprintf(b, sizeof b, "acc_zero(acc%u);", d & (NACC - 1)); break;
             case OP_ACC_MACC: snprintf(b, sizeof b, "acc_macc(acc%u, p%u, P.consts, %uu);", d & (NACC - 1), x, y); break;
             case OP_ACC_MACP: snprintf(b, sizeof b, "acc_macp(acc%u, p%u, p%u);", d & (NACC - 1), x, y); break;
@@ -84,7 +84,7 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
             case OP_STORE_Q: snprintf(b, sizeof b, "ev_store_q(P, R, %uu, q%u);", y, x); break;
             case OP_STORE_P: snprintf(b, sizeof b, "ev_store_p(P, R, %uu, p%u);", y, x); break;
             case OP_XPOW_P: snprintf(b, sizeof b, "p%u = ev_xpow(P, i, %uu, %uu);", d, x, y); break;
-            case OP_TABLE_P: snprintf(b, sizeof b, "p%u = ev_table_p(P, R, %uu);", d, x); break;
+            case OP_TABLE_P: snprintf(b, sizeof b, "p%u = ev_table_p(P, R, i, %uu, %uu);", d, x, y); break;
             case OP_TABLE_Q: snprintf(b, sizeof b, "q%u = ev_table_q(P, R, %uu);", d, x); break;
             case OP_ACC_ZERO: snprintf(b, sizeof b, "acc_zero(acc%u);", d & (NACC - 1)); break;
             case OP_ACC_MACC: snprintf(b, sizeof b, "acc_macc(acc%u, p%u, P.consts, %uu);", d & (NACC - 1), x, y); break;

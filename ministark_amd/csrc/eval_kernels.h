@@ -31,7 +31,7 @@ enum Op : uint32_t {
     OP_NEG_P, OP_NEG_Q, OP_ADD_PP, OP_ADD_QQ, OP_ADD_QP, OP_MUL_PP, OP_MUL_QQ, OP_MUL_QP,
     OP_INV_P, OP_INV_Q, OP_POW_P, OP_POW_Q, OP_EMBED, OP_STORE_Q, OP_STORE_P,
     OP_XPOW_P,      // internal (eval_opt.h): dst = consts[a] * w_n^(b*i mod n)  ==  x^b with consts[a] = h^b
-    OP_TABLE_P, OP_TABLE_Q,   // internal (eval_opt.h, split_inversions): dst = table a of `periodic` at this launch position
+    OP_TABLE_P, OP_TABLE_Q,   // internal (eval_opt.h, split_inversions): dst = table a of `periodic` at this launch position (P: b = row offset, eval_shift.h)
     // internal (eval_regroup.h): sums of products accumulated UNREDUCED, one Montgomery reduction per sum.  dst of the first three = accumulator
     OP_ACC_ZERO,              // acc[dst] = 0
     OP_ACC_MACC,              // acc[dst] += P[a] * C, C a wave-uniform constant whose limbs / digits sit at consts[b ..) (host-prepared)
@@ -100,7 +100,8 @@ __device__ __forceinline__ gl::Fq3 ev_periodic_q(const EvalParams& P, size_t i, 
     return {c[0], c[1], c[2]};
 }
 // full-length tables (one entry per launch position R, whatever the layout): the batch-inverted denominators
-__device__ __forceinline__ uint64_t ev_table_p(const EvalParams& P, size_t R, uint32_t id) { return P.periodic[id][R]; }
+// off != 0 (eval_shift.h): the entry of the point `off` trace rows further on, wherever the layout keeps it
+__device__ __forceinline__ uint64_t ev_table_p(const EvalParams& P, size_t R, size_t i, uint32_t id, uint32_t off) { return P.periodic[id][off ? ev_row(P, i, off) : R]; }
 __device__ __forceinline__ gl::Fq3 ev_table_q(const EvalParams& P, size_t R, uint32_t id) {
     const uint64_t* c = P.periodic[id] + 3 * R;
     return {c[0], c[1], c[2]};
@@ -128,7 +129,7 @@ __device__ __forceinline__ f252::E ev252_xpow(const EvalParams& P, size_t i, uin
 __device__ __forceinline__ f252::E ev252_const(const EvalParams& P, uint32_t a) { return f252::E{{P.consts[a], P.consts[a + 1], P.consts[a + 2], P.consts[a + 3]}}; }
 __device__ __forceinline__ f252::E ev252_trace(const EvalParams& P, size_t i, uint32_t col, uint32_t off) { return ev252_load(P.base_cols[col], ev_row(P, i, off)); }
 __device__ __forceinline__ f252::E ev252_periodic(const EvalParams& P, size_t i, uint32_t id) { return ev252_load(P.periodic[id], i % P.periodic_len[id]); }
-__device__ __forceinline__ f252::E ev252_table(const EvalParams& P, size_t R, uint32_t id) { return ev252_load(P.periodic[id], R); }
+__device__ __forceinline__ f252::E ev252_table(const EvalParams& P, size_t R, size_t i, uint32_t id, uint32_t off) { return ev252_load(P.periodic[id], off ? ev_row(P, i, off) : R); }
 __device__ __forceinline__ void ev252_store(const EvalParams& P, size_t i, uint32_t slot, const f252::E& v) {
     msstage::Fp252T::store(slot ? (uint64_t*)P.periodic[slot - 1] : P.out, i, v);
 }
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
         case OP_STORE_Q: ev_store_q(P, R, I.b, rq[I.a]); break;
         case OP_STORE_P: ev_store_p(P, R, I.b, rp[I.a]); break;
         case OP_XPOW_P: rp[I.dst] = ev_xpow(P, i, I.a, I.b); break;
-        case OP_TABLE_P: rp[I.dst] = ev_table_p(P, R, I.a); break;
+        case OP_TABLE_P: rp[I.dst] = ev_table_p(P, R, i, I.a, I.b); break;
         case OP_TABLE_Q: rq[I.dst] = ev_table_q(P, R, I.a); break;
         case OP_ACC_ZERO: acc_zero(acc[I.dst & (NACC - 1)]); break;
         case OP_ACC_MACC: acc_macc(acc[I.dst & (NACC - 1)], rp[I.a], P.consts, I.b); break;
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
         case OP_POW_P: rp[I.dst] = msstage::powu<F>(rp[I.a], I.b); break;
         case OP_STORE_P: ev252_store(P, R, I.b, rp[I.a]); break;
         case OP_XPOW_P: rp[I.dst] = ev252_xpow(P, i, I.a, I.b); break;
-        case OP_TABLE_P: rp[I.dst] = ev252_table(P, R, I.a); break;
+        case OP_TABLE_P: rp[I.dst] = ev252_table(P, R, i, I.a, I.b); break;
         case OP_ACC_ZERO: acc_zero(acc[I.dst & (NACC - 1)]); break;
         case OP_ACC_MACC: acc_macc(acc[I.dst & (NACC - 1)], rp[I.a], P.consts, I.b); break;
         case OP_ACC_MACP: acc_macp(acc[I.dst & (NACC - 1)], rp[I.a], rp[I.b]); break;

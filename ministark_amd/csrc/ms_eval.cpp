@@ -5,6 +5,7 @@
 #include "eval_kernels.h"
 #include "eval_opt.h"
 #include "eval_regroup.h"
+#include "eval_shift.h"
 #ifndef MS_NO_JIT
 #include "eval_jit.h"
 #endif
@@ -107,6 +108,14 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     const unsigned short_tables = (unsigned)split.table_words.size();
     InvSplit isplit;
     if (log_n >= 12) isplit = split_inversions(main_prog, main_n, nperiodic + short_tables, (unsigned)MAXPERIODIC - nperiodic - short_tables, PW);
+    // ---- rewrite 3b: denominators X - a whose roots differ by a power of the trace generator share one table (eval_shift.h; MS_EVAL_SHARE_TABLES=0: off)
+    if (isplit.active && !d_x_lde && isplit.table_words.size() >= 2) {
+        static const bool off = getenv("MS_EVAL_SHARE_TABLES") && !strcmp(getenv("MS_EVAL_SHARE_TABLES"), "0");
+        const bool dbg = getenv("MS_EVAL_DEBUG") != nullptr;
+        if (off) {}
+        else if (is252) share_shifted_tables<Host252>(isplit, nperiodic + short_tables, PW, consts, f252::pow_u64(f252::root_of_unity(log_n), lde_step), maxp, dbg);
+        else share_shifted_tables<HostGL>(isplit, nperiodic + short_tables, PW, consts, gl::to_mont(gl::pow(gl::root_of_unity(log_n), lde_step)), maxp, dbg);
+    }
     if (isplit.active) { main_prog = isplit.main.data(); main_n = (unsigned)isplit.main.size(); }
     const unsigned den_n = (unsigned)isplit.denom.size();
     // ---- rewrite 4: the result as sums of products with one reduction per sum (eval_regroup.h; Fq = Fp programs; MS_EVAL_REGROUP=0: off)

@@ -345,3 +345,54 @@ def test_sums_of_products_pass_on_the_reference_airs_emu(field):
     dbase = [GpuVec.from_numpy(pl, c, bf) for c in base]
     dext = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FQ3) for c in ext]
     assert np.array_equal(E.eval(prog, pl, ch, ch[:1], step, off, n, dbase, dext).to_numpy(), want)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("field", ["goldilocks", "f252"])
+def test_denominators_at_other_trace_rows_share_one_table(kind, field, capfd, monkeypatch):
+    """csrc/eval_shift.h: boundary denominators X - g^r for several rows r are rotations of ONE inverse table (1 / (x - g^r) = g^(r0 - r) times
+    the entry r0 - r trace rows further on).  Rows within reach of each other (16), one out of reach (its own table), a denominator that is not
+    X - a (left alone), the domain WITHOUT an offset (x_i = g^r for some i: the zero denominators, 0^-1 = 0, must agree), natural and
+    bit-reversed layouts, lde_step 1 / 4 -- the C oracle's per-point evaluation (eval_cpu::eval restated) is the reference."""
+    from ministark_amd import STARK252_FP
+    from ministark_amd.api import Radix2EvaluationDomain
+    pl = backends.planner(kind)
+    log_n = 12 if kind == "emu" else 16
+    n = 1 << log_n
+    f252 = field == "f252"
+    bf = STARK252_FP if f252 else FP
+    rng = np.random.default_rng(77)
+    if f252:
+        cols = [rng.integers(0, 1 << 63, size=4 * n, dtype=np.uint64) for _ in range(4)]
+        for c in cols:
+            c[3::4] >>= np.uint64(4)
+        ch = rng.integers(0, 1 << 59, size=(8, 4), dtype=np.uint64)
+        kw = {"field": "f252"}
+    else:
+        cols = [cref.random_elements(n, 300 + k) for k in range(4)]
+        ch = cref.random_elements(8, 301).reshape(-1, 1)
+        kw = {}
+    monkeypatch.setenv("MS_EVAL_DEBUG", "1")
+    for lde_step, offset in ((1, 7), (4, 3), (4, 1)):
+        dom = Radix2EvaluationDomain(n // lde_step, 1, bf)
+        g = dom.group_gen
+        x = E.X()
+        rows = [0, 1, -1, 5, -16, 40]                              # 40 is out of reach of every other row: a table of its own
+        expr = None
+        for j, r in enumerate(rows):
+            a = pow(g, r % (n // lde_step), dom.p)
+            t = (E.Trace(j % 4, 0) * E.Challenge(j) - E.Trace((j + 1) % 4, 1)) / (x - E.Constant(a))
+            expr = t if expr is None else expr + t
+        expr = expr + E.Trace(2, 0) / (x * x - E.Constant(9)) + E.Trace(3, 1) * E.Challenge(7) / (x - E.Constant(1))   # not X - a; X - 1 a second time
+        prog = E.compile_expr(expr, 4, False, bf)
+        want = cref.eval_expr(expr, log_n, lde_step, offset, cols, [], ch, ch[:1], False, **kw)
+        capfd.readouterr()
+        got = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, bf) for c in cols]).to_numpy()
+        err = capfd.readouterr().err
+        assert err.count("shared tables:") == 4, err[-2000:]          # rows 1, -1, 5, -16 ride on row 0's table (the second X - 1 IS the first: one node)
+        assert np.array_equal(got, want)
+        Vw = 4 if f252 else 1
+        perm = np.array([int(format(i, f"0{log_n}b")[::-1], 2) for i in range(n)])
+        brc = [np.ascontiguousarray(c.reshape(n, Vw)[perm].reshape(-1)) for c in cols]
+        got = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, bf) for c in brc], bit_reversed=True).to_numpy()
+        assert np.array_equal(got.reshape(n, Vw), want.reshape(n, Vw)[perm])
