@@ -235,11 +235,50 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         // Fp252 with a handful of points: one lane running the 252-bit Fermat inverse is ~0.6 ms of pure latency on
         // the device and microseconds on a host core -- the same fp252.h functions, so the same values
         bool on_host = false;
-        if (is252 && period <= 64 && !d_x_lde) {
+        if (period <= 64 && !d_x_lde) {
             on_host = true;
-            for (auto& I : split.prologue) if (I.op == OP_PERIODIC_P) on_host = false;       // caller tables live on the device
+            for (auto& I : split.prologue) if (I.op == OP_PERIODIC_P || I.op == OP_PERIODIC_Q || I.op == OP_TRACE_P || I.op == OP_TRACE_Q || I.op == OP_XPOW_P || I.op >= OP_TABLE_P) on_host = false;   // caller tables live on the device
         }
-        if (on_host) {
+        if (on_host && !is252) {
+            // Goldilocks (round 5): the same few points on the host too -- the launch was 16 us of latency in front of every evaluation
+            // (the interpreter's register arrays, one wave); gl.h's host functions are the kernels' own formulas, so the same words
+            std::vector<uint64_t> host_tabs(words, 0);
+            const uint64_t w = gl::root_of_unity(log_n);
+            uint64_t xi = h;                                                                  // x_i = h * w^i, canonical
+            std::vector<uint64_t> rp(256);
+            std::vector<gl::Fq3> rq(128);
+            for (size_t i = 0; i < period; i++) {
+                for (auto& I : split.prologue) {
+                    switch (I.op) {
+                    case OP_X_P: rp[I.dst] = gl::to_mont(xi); break;
+                    case OP_CONST_P: rp[I.dst] = consts[I.a]; break;
+                    case OP_CONST_Q: rq[I.dst] = gl::Fq3{consts[I.a], consts[I.a + 1], consts[I.a + 2]}; break;
+                    case OP_NEG_P: rp[I.dst] = gl::neg(rp[I.a]); break;
+                    case OP_NEG_Q: rq[I.dst] = gl::neg(rq[I.a]); break;
+                    case OP_ADD_PP: rp[I.dst] = gl::add(rp[I.a], rp[I.b]); break;
+                    case OP_ADD_QQ: rq[I.dst] = gl::add(rq[I.a], rq[I.b]); break;
+                    case OP_ADD_QP: rq[I.dst] = gl::Fq3{gl::add(rq[I.a].c0, rp[I.b]), rq[I.a].c1, rq[I.a].c2}; break;
+                    case OP_MUL_PP: rp[I.dst] = gl::mont_mul(rp[I.a], rp[I.b]); break;
+                    case OP_MUL_QQ: rq[I.dst] = gl::mont_mul(rq[I.a], rq[I.b]); break;
+                    case OP_MUL_QP: rq[I.dst] = gl::mont_mul_fp(rq[I.a], rp[I.b]); break;
+                    case OP_INV_P: rp[I.dst] = gl::mont_inv(rp[I.a]); break;
+                    case OP_INV_Q: rq[I.dst] = gl::mont_inv(rq[I.a]); break;
+                    case OP_POW_P: rp[I.dst] = gl::mont_pow(rp[I.a], (uint64_t)I.b); break;
+                    case OP_POW_Q: rq[I.dst] = gl::mont_pow(rq[I.a], (uint64_t)I.b); break;
+                    case OP_EMBED: rq[I.dst] = gl::Fq3{rp[I.a], 0, 0}; break;
+                    case OP_STORE_P: case OP_STORE_Q: {
+                        size_t off = 0;
+                        for (unsigned t = 0; t + nperiodic + 1 < I.b; t++) off += split.table_words[t] * period;
+                        if (I.op == OP_STORE_P) host_tabs[off + i] = rp[I.a];
+                        else { host_tabs[off + 3 * i] = rq[I.a].c0; host_tabs[off + 3 * i + 1] = rq[I.a].c1; host_tabs[off + 3 * i + 2] = rq[I.a].c2; }
+                    } break;
+                    default: break;
+                    }
+                }
+                xi = gl::mul(xi, w);
+            }
+            MSCHK(stage_upload(ctx, tables, host_tabs.data(), words * 8));                    // stream-ordered, out of the pinned ring
+        } else if (on_host) {
             std::vector<uint64_t> host_tabs(words, 0);
             const f252::E w = f252::root_of_unity(log_n);
             f252::E xi = h252;                                                                // x_i = h * w^i
@@ -264,8 +303,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
                 }
                 xi = f252::mul(xi, w);
             }
-            HIPCHK(hipMemcpyAsync(tables, host_tabs.data(), words * 8, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));           // host_tabs is pageable and about to go out of scope
+            MSCHK(stage_upload(ctx, tables, host_tabs.data(), words * 8));                    // stream-ordered, out of the pinned ring
         } else {
             EvalParams Q = E;
             Q.prog = (const Instr*)((char*)ctx->prog_buf + poff); Q.ninstr = pro_n;
