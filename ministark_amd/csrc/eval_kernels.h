@@ -381,4 +381,33 @@ __global__ void __launch_bounds__(NT) batch_inverse_down(uint64_t* t, size_t n, 
     }
 }
 
+// ---- the denominators X + c of a Goldilocks program: table AND inversion in one pass (round 5) ---------------------------------------
+// t[R] = (x_R + c)^-1 at every launch position R, 0^-1 = 0: what the denominators' program followed by k_batch_inverse leaves, without the
+// table of x_R + c going to memory and back.  A lane owns the positions tid + j stride, stride = n / K; their points are point(tid) plus
+// j stride (natural order) or plus rev(j) (bit-reversed storage: the top bits of a position are the low bits of its point), so x_j is x_0
+// times one of K wave-uniform factors the host supplies (XcParams::m; exact products of canonical values: the words ev_x would give).
+struct XcParams { uint64_t m[16]; uint64_t c; };
+template <int K>
+__global__ void __launch_bounds__(NT) batch_inverse_x_plus_c(EvalParams P, uint64_t* t, XcParams X) {
+    static_assert(K <= 16, "XcParams holds 16 factors");
+    using F = msstage::FpT;
+    const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;      // stride * K == P.n
+    const uint64_t x0 = ev_x(P, ev_point(P, tid));
+    uint64_t val[K], pre[K];
+    uint64_t acc = F::one();
+    #pragma unroll
+    for (int j = 0; j < K; j++) {
+        pre[j] = acc;
+        val[j] = gl::add(j ? gld::mmul(x0, X.m[j]) : x0, X.c);
+        if (val[j] != 0) acc = gld::mmul(acc, val[j]);
+    }
+    uint64_t inv = F::inv(acc);
+    #pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        const size_t i = tid + (size_t)j * stride;
+        if (val[j] == 0) t[i] = 0;
+        else { t[i] = gld::mmul(inv, pre[j]); inv = gld::mmul(inv, val[j]); }
+    }
+}
+
 }  // namespace mseval

@@ -25,17 +25,14 @@ namespace mseval {
 
 static constexpr int SHIFT_MAX_ROWS = 16;      // |k| searched
 
-// S: what split_inversions returned (active).  first_table: periodic slot of table 0.  g: the trace generator w_n^lde_step (Montgomery).
-// maxp: P registers in use (one more is taken).  Returns the number of tables removed.
+// The tables of S whose denominator is X + (a value built from constants alone): has_c[t], c[t] (Montgomery), and the instruction that stores it.
 template <class F>
-static inline unsigned share_shifted_tables(InvSplit& S, unsigned first_table, unsigned elem_words_p, std::vector<uint64_t>& consts,
-                                            const typename F::T& g, unsigned& maxp, bool debug) {
+static inline void tables_x_plus_c(const InvSplit& S, unsigned first_table, unsigned elem_words_p, const std::vector<uint64_t>& consts,
+                                   std::vector<char>& has_c, std::vector<typename F::T>& c, std::vector<int>& store_of) {
     typedef typename F::T FT;
-    if (!S.active || S.table_words.size() < 2 || maxp >= 256) return 0;
     const unsigned nd = (unsigned)S.denom.size(), ntab = (unsigned)S.table_words.size();
-    // ---- the denominators' program as a DAG; root a_t of every table that is X + (uniform)
-    std::vector<int> na(nd, -1), nb(nd, -1), defp(256, -1);
-    std::vector<int> store_of(ntab, -1), node_of(ntab, -1);
+    std::vector<int> na(nd, -1), nb(nd, -1), defp(256, -1), node_of(ntab, -1);
+    has_c.assign(ntab, 0); c.assign(ntab, F::zero()); store_of.assign(ntab, -1);
     for (unsigned k = 0; k < nd; k++) {
         const Instr I = S.denom[k];
         unsigned opnd[2][2];
@@ -61,16 +58,30 @@ static inline unsigned share_shifted_tables(InvSplit& S, unsigned first_table, u
         default: return false;
         }
     };
-    std::vector<char> has_root(ntab, 0);
-    std::vector<FT> root(ntab);
     for (unsigned t = 0; t < ntab; t++) {
         if (S.table_words[t] != elem_words_p || store_of[t] < 0 || node_of[t] < 0) continue;
         const int k = node_of[t];
         if (S.denom[k].op != OP_ADD_PP || na[k] < 0 || nb[k] < 0) continue;
-        FT c;
-        if (S.denom[na[k]].op == OP_X_P && uniform(uniform, nb[k], c)) { root[t] = F::neg(c); has_root[t] = !F::is_zero(root[t]); }
-        else if (S.denom[nb[k]].op == OP_X_P && uniform(uniform, na[k], c)) { root[t] = F::neg(c); has_root[t] = !F::is_zero(root[t]); }
+        FT v;
+        if (S.denom[na[k]].op == OP_X_P && uniform(uniform, nb[k], v)) { c[t] = v; has_c[t] = 1; }
+        else if (S.denom[nb[k]].op == OP_X_P && uniform(uniform, na[k], v)) { c[t] = v; has_c[t] = 1; }
     }
+}
+
+// S: what split_inversions returned (active).  first_table: periodic slot of table 0.  g: the trace generator w_n^lde_step (Montgomery).
+// maxp: P registers in use (one more is taken).  Returns the number of tables removed.
+template <class F>
+static inline unsigned share_shifted_tables(InvSplit& S, unsigned first_table, unsigned elem_words_p, std::vector<uint64_t>& consts,
+                                            const typename F::T& g, unsigned& maxp, bool debug) {
+    typedef typename F::T FT;
+    if (!S.active || S.table_words.size() < 2 || maxp >= 256) return 0;
+    const unsigned nd = (unsigned)S.denom.size(), ntab = (unsigned)S.table_words.size();
+    // ---- root a_t = -c of every table whose denominator is X + c
+    std::vector<char> has_root;
+    std::vector<FT> root;
+    std::vector<int> store_of;
+    tables_x_plus_c<F>(S, first_table, elem_words_p, consts, has_root, root, store_of);
+    for (unsigned t = 0; t < ntab; t++) { root[t] = F::neg(root[t]); if (F::is_zero(root[t])) has_root[t] = 0; }
     // ---- g^k, k = -SHIFT_MAX_ROWS .. SHIFT_MAX_ROWS
     std::vector<FT> gp(2 * SHIFT_MAX_ROWS + 1);
     gp[SHIFT_MAX_ROWS] = F::one();

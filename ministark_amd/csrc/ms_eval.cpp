@@ -1,5 +1,6 @@
 // Fused constraint evaluation: program validation, rewriting (eval_opt.h), specialisation (eval_jit.h), launches
 // (src/eval_gpu.rs, parity with src/eval_cpu.rs:33-150).
+#include <algorithm>
 #include "ms_internal.h"
 #include "stage_kernels.h"
 #include "eval_kernels.h"
@@ -115,6 +116,31 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         if (off) {}
         else if (is252) share_shifted_tables<Host252>(isplit, nperiodic + short_tables, PW, consts, f252::pow_u64(f252::root_of_unity(log_n), lde_step), maxp, dbg);
         else share_shifted_tables<HostGL>(isplit, nperiodic + short_tables, PW, consts, gl::to_mont(gl::pow(gl::root_of_unity(log_n), lde_step)), maxp, dbg);
+    }
+    // ---- Goldilocks tables whose denominator is X + c are generated inside the inversion kernel (eval_kernels.h batch_inverse_x_plus_c):
+    // their stores leave the denominators' program, which disappears when nothing else is left in it
+    std::vector<char> fused;
+    std::vector<uint64_t> fused_c;
+    if (isplit.active && !is252 && !d_x_lde && log_n >= 12) {
+        static const bool off = getenv("MS_EVAL_FUSE_DENOMINATORS") && !strcmp(getenv("MS_EVAL_FUSE_DENOMINATORS"), "0");
+        std::vector<int> store_of;
+        if (!off) tables_x_plus_c<HostGL>(isplit, nperiodic + short_tables, PW, consts, fused, fused_c, store_of);
+        bool any = false;
+        for (char f : fused) any = any || f;
+        if (any) {
+            std::vector<Instr> denom;
+            bool stores_left = false;
+            for (size_t k = 0; k < isplit.denom.size(); k++) {
+                bool drop = false;
+                for (size_t t = 0; t < fused.size(); t++) if (fused[t] && store_of[t] == (int)k) drop = true;
+                if (drop) continue;
+                if (op_is_store(isplit.denom[k].op)) stores_left = true;
+                denom.push_back(isplit.denom[k]);
+            }
+            if (!stores_left) denom.clear();
+            isplit.denom.swap(denom);
+            if (getenv("MS_EVAL_DEBUG")) fprintf(stderr, "fused denominators: %zu of %zu tables are X + c%s\n", (size_t)std::count(fused.begin(), fused.end(), 1), fused.size(), stores_left ? "" : " (no denominators' program left)");
+        } else fused.clear();
     }
     if (isplit.active) { main_prog = isplit.main.data(); main_n = (unsigned)isplit.main.size(); }
     const unsigned den_n = (unsigned)isplit.denom.size();
@@ -317,7 +343,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     E.bitrev = (flags & MS_EVAL_BIT_REVERSED) ? 1 : 0;
     // ---- the x-only denominators of every point (in the launch's own layout), inverted in place
     void* inv_tables = nullptr;
-    if (den_n) {
+    if (isplit.active && !isplit.table_words.empty()) {
         size_t words = 0;
         for (unsigned w : isplit.table_words) words += (size_t)w * n;
         MSCHK(pooled.alloc(words * 8, &inv_tables));
@@ -328,7 +354,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         }
         EvalParams Q = E;
         Q.prog = (const Instr*)((char*)ctx->prog_buf + doff); Q.ninstr = den_n;
-        {
+        if (den_n) {
             hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(isplit.denom.data(), den_n) : nullptr;
             ProfScope ps(ctx, "eval_denominators", 0.0);
             launch(Q, fn);
@@ -361,7 +387,18 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
             const unsigned w = isplit.table_words[t];
             ProfScope ps(ctx, "eval_batch_inverse", 16.0 * w * n);
             // Fp / Fq3: the stage's kernel, in place (it keeps the K values in registers: one read and one write of the table)
-            if (w == 1) hipLaunchKernelGGL((msstage::k_batch_inverse<msstage::FpT, 16>), dim3((unsigned)((n + msstage::NT * 16 - 1) / (msstage::NT * 16))), dim3(msstage::NT), 0, ctx->stream, tp, (const uint64_t*)tp, n);
+            if (w == 1 && t < fused.size() && fused[t]) {      // X + c: generated in the kernel (n is a multiple of 16 NT: log_n >= 12)
+                XcParams X;
+                memset(&X, 0, sizeof X);
+                X.c = fused_c[t];
+                const uint64_t wn = gl::root_of_unity(log_n);
+                for (unsigned j = 0; j < 16; j++) {
+                    const uint64_t e = E.bitrev ? (uint64_t)(((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3)) : (uint64_t)j * (n / 16);
+                    X.m[j] = gl::to_mont(gl::pow(wn, e));
+                }
+                hipLaunchKernelGGL((batch_inverse_x_plus_c<16>), dim3((unsigned)(n / ((size_t)NT * 16))), dim3(NT), 0, ctx->stream, E, tp, X);
+            }
+            else if (w == 1) hipLaunchKernelGGL((msstage::k_batch_inverse<msstage::FpT, 16>), dim3((unsigned)((n + msstage::NT * 16 - 1) / (msstage::NT * 16))), dim3(msstage::NT), 0, ctx->stream, tp, (const uint64_t*)tp, n);
             else if (w == 3) hipLaunchKernelGGL((msstage::k_batch_inverse<msstage::Fq3T, 8>), dim3((unsigned)((n + msstage::NT * 8 - 1) / (msstage::NT * 8))), dim3(msstage::NT), 0, ctx->stream, tp, (const uint64_t*)tp, n);
             else if (n < ((size_t)1 << 16)) hipLaunchKernelGGL((batch_inverse<msstage::Fp252T, 8>), dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT), 0, ctx->stream, tp, n);
             else {                                             // two levels: one 252-bit Fermat inverse per 128 elements
