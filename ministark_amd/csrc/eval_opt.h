@@ -259,14 +259,16 @@ static inline InvSplit split_inversions(const Instr* prog, unsigned ninstr, unsi
     std::vector<Instr> main;
     for (unsigned k = 0; k < ninstr; k++) {
         const Instr I = prog[k];
-        if (in_den[k]) S.denom.push_back(I);
         if (hoisted[k]) {
+            // the store of the denominator comes BEFORE the inversion itself, which stays in the denominators' program when a later
+            // denominator is built on this inverse (a / (b / (x - c))) and may write the register it reads (dst == a)
             const bool q = I.op == OP_INV_Q;
             S.denom.push_back(Instr{q ? (uint32_t)OP_STORE_Q : (uint32_t)OP_STORE_P, 0, I.a, first_table + tab + 1});
             main.push_back(Instr{q ? (uint32_t)OP_TABLE_Q : (uint32_t)OP_TABLE_P, I.dst, first_table + tab, 0});
             S.table_words.push_back(q ? 3u : elem_words_p);
             tab++;
         } else main.push_back(I);
+        if (in_den[k]) S.denom.push_back(I);
     }
     // dead-code elimination of the per-point program (the denominators' own sub-trees, x when nothing else needs it)
     std::vector<char> lp(256, 0), lq(128, 0), keep(main.size(), 0);

@@ -261,7 +261,8 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         // Fp252 with a handful of points: one lane running the 252-bit Fermat inverse is ~0.6 ms of pure latency on
         // the device and microseconds on a host core -- the same fp252.h functions, so the same values
         bool on_host = false;
-        if (period <= 64 && !d_x_lde) {
+        static const bool host_off = getenv("MS_EVAL_HOST_TABLES") && !strcmp(getenv("MS_EVAL_HOST_TABLES"), "0");
+        if (period <= 64 && !d_x_lde && !host_off) {
             on_host = true;
             for (auto& I : split.prologue) if (I.op == OP_PERIODIC_P || I.op == OP_PERIODIC_Q || I.op == OP_TRACE_P || I.op == OP_TRACE_Q || I.op == OP_XPOW_P || I.op >= OP_TABLE_P) on_host = false;   // caller tables live on the device
         }

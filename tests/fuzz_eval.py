@@ -3,7 +3,8 @@
 interpreter on small domains, hiprtc-specialised kernels on 2^16 points) against the oracle's direct
 evaluation at sampled points:   python tests/fuzz_eval.py [seconds] [seed]
 MS_FUZZ_BACKEND=emu: on the simulator build (small domains).  MS_FUZZ_FIELD=f252: programs over the 252-bit field (Fq = Fp; every output
-against the C oracle).  MS_EVAL_REGROUP=force: the sums-of-products pass applied wherever it can be."""
+against the C oracle).  MS_EVAL_REGROUP=force: the sums-of-products pass applied wherever it can be.  Divisors are random expressions or, about
+as often, boundary-style X - g^r for a few trace rows r (the shared inverse tables of csrc/eval_shift.h)."""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ from oracle import cref  # noqa: E402  (the checker)
 from oracle.pyref import evalexpr  # noqa: E402
 from oracle.pyref.fields import GL  # noqa: E402
 from ministark_amd import GOLDILOCKS_FP as FP, GOLDILOCKS_FQ3 as FQ3, GpuVec, Planner  # noqa: E402
+from ministark_amd.api import Radix2EvaluationDomain  # noqa: E402
 from ministark_amd import expr as E  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -31,6 +33,9 @@ P = GL.p
 F252 = os.environ.get("MS_FUZZ_FIELD") == "f252"
 if F252:
     from ministark_amd import STARK252_FP  # noqa: E402
+
+
+BOUNDARY = []                                  # g^r for a few trace rows r of the case at hand
 
 
 def rand_expr(depth, nbase, next_, nch, log_n):
@@ -60,6 +65,8 @@ def rand_expr(depth, nbase, next_, nch, log_n):
         return a - b
     if r < 0.92:
         return a * b
+    if BOUNDARY and rng.random() < 0.45:       # a boundary-style divisor X - g^r (csrc/eval_shift.h: rotations of one inverse table)
+        return a / (E.X() - E.Constant(BOUNDARY[int(rng.integers(0, len(BOUNDARY)))]))
     return a / b                               # 0^-1 = 0 on both sides
 
 
@@ -75,6 +82,8 @@ while time.time() - t0 < budget:
     fq_is_ext = bool(rng.integers(0, 2)) and not F252
     nbase, next_, nch = int(rng.integers(1, 4)), (int(rng.integers(0, 3)) if fq_is_ext else 0), int(rng.integers(0, 3))
     lde_step, offset = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 3, 7]))
+    dom = Radix2EvaluationDomain(max(n // lde_step, 1), 1, STARK252_FP if F252 else FP)
+    BOUNDARY[:] = [pow(dom.group_gen, int(r) % max(n // lde_step, 1), dom.p) for r in rng.integers(-20, 21, size=4)]
     expr = rand_expr(int(rng.integers(2, 6)), nbase, next_, nch, log_n)
     if F252:                                    # 4-word elements below 2^251 < p; the C oracle checks every output
         def el(k, sd):

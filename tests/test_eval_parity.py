@@ -396,3 +396,23 @@ def test_denominators_at_other_trace_rows_share_one_table(kind, field, capfd, mo
         brc = [np.ascontiguousarray(c.reshape(n, Vw)[perm].reshape(-1)) for c in cols]
         got = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, bf) for c in brc], bit_reversed=True).to_numpy()
         assert np.array_equal(got.reshape(n, Vw), want.reshape(n, Vw)[perm])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_denominator_built_on_another_inverse(kind):
+    """a / (b / (x - c)) next to d / (x - c): the inverse of x - c is a hoisted table AND an operand of the second denominator.  The
+    denominators' program used to run the inversion (in place: dst == a) before it stored x - c, and the table held (x - c)^-1 before the batch
+    inversion -- found by the constraint fuzzer once it drew boundary-style divisors (round 5)."""
+    x = E.X()
+    a = E.Constant(628335062820441145)
+    expr = ((x ** 2) / (E.Constant(2242740954004980262) / (x - a) / (-E.Challenge(1)))) ** 0 \
+        + (E.Trace(1, 2) - (x / (x - a)) * ((x ** 64) * E.Constant(4605101940728796340)) + E.Trace(0, -2) * (E.Constant(2298312417385081279) + x))
+    expr = expr + E.Trace(2, 1) / (E.Constant(3) / (x - a) + x)
+    pl = backends.planner(kind)
+    log_n = 12 if kind == "emu" else 16
+    n = 1 << log_n
+    base = [cref.random_elements(n, 10 + c) for c in range(3)]
+    ch = cref.random_elements(2, 5).reshape(-1, 1)
+    prog = E.compile_expr(expr, 3, False)
+    out = E.eval(prog, pl, ch, ch[:1], 2, 7, n, [GpuVec.from_numpy(pl, c, FP) for c in base], []).to_numpy()
+    assert np.array_equal(out, cref.eval_expr(expr, log_n, 2, 7, base, [], ch, ch[:1], False))
