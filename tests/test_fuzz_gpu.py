@@ -37,9 +37,11 @@ def test_fuzz_eval_hip(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"MS_EVAL_REGROUP": "force"}, {"MS_EVAL_REGROUP": "force", "MS_FUZZ_FIELD": "f252"}, {"MS_EVAL_REGROUP": "0"}],
-                         ids=["regroup-forced", "regroup-forced-252", "regroup-off"])
+@pytest.mark.parametrize("env", [{"MS_EVAL_REGROUP": "force"}, {"MS_EVAL_REGROUP": "force", "MS_FUZZ_FIELD": "f252"}, {"MS_EVAL_REGROUP": "0"},
+                                 {"MS_EVAL_SHARE_TABLES": "0", "MS_EVAL_FUSE_DENOMINATORS": "0", "MS_EVAL_HOST_TABLES": "0"}],
+                         ids=["regroup-forced", "regroup-forced-252", "regroup-off", "tables-plain"])
 def test_fuzz_eval_rewriting_pass_hip(env):
     """the sums-of-products pass (csrc/eval_regroup.h) applied to EVERY random program it can be applied to -- Goldilocks with and without
-    Fq3 values, and the 252-bit field -- and switched off: the same outputs as the C oracle either way"""
+    Fq3 values, and the 252-bit field -- and switched off; "tables-plain": every inverse table computed, stored and inverted on its own on the device
+    (csrc/eval_shift.h and the fused / host-side tables off).  The same outputs as the C oracle every way"""
     _run("fuzz_eval.py", 23, env)
