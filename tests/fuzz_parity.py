@@ -3,7 +3,8 @@
     python tests/fuzz_parity.py [seconds] [seed]
 Random sizes (2^0 .. 2^21: every plan family incl. the (256, R, 256) ones), fields, directions, coset offsets, blow-ups, folding factors, shifts and column
 counts; values are a mix of uniform elements and edge values (0, 1, p-1, 2^32-1, 2^32, p-2^32 ...).
-Complements tests/ (fixed shapes): any mismatch prints the failing case and exits non-zero."""
+Complements tests/ (fixed shapes): any mismatch prints the failing case and exits non-zero.  MS_FUZZ_BACKEND=emu: the same on the simulator build
+(CPU; transforms to 2^18, LDEs to 2^14 rows)."""
 import sys
 import time
 
@@ -19,7 +20,13 @@ P = cref.GL_P
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-pl = Planner(0)
+EMU = __import__("os").environ.get("MS_FUZZ_BACKEND") == "emu"      # the simulator build (CPU): the same kernels, smaller upper sizes
+if EMU:
+    from tests import backends  # noqa: E402
+    pl = backends.planner("emu")
+else:
+    pl = Planner(0)
+TOP_NTT, TOP_LDE = (19, 15) if EMU else (22, 18)
 EDGE = np.array([gl_to_mont(v % P) for v in (0, 1, 2, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - (1 << 32), (1 << 63), 7)], dtype=np.uint64)
 RAW_EDGE = np.array([0, 1, P - 1, P - 2, 0xFFFFFFFF, 1 << 32, 0xFFFFFFFF00000000], dtype=np.uint64)   # canonical Montgomery words
 
@@ -40,7 +47,7 @@ def offset():
 
 
 def case_ntt():
-    log_n, V, inv, off = int(rng.integers(0, 22)), int(rng.choice([1, 3])), bool(rng.integers(0, 2)), offset()
+    log_n, V, inv, off = int(rng.integers(0, TOP_NTT)), int(rng.choice([1, 3])), bool(rng.integers(0, 2)), offset()
     field = FQ3 if V == 3 else FP
     x = values((1 << log_n) * V)
     v = GpuVec.from_numpy(pl, x, field)
@@ -50,7 +57,7 @@ def case_ntt():
 
 
 def case_lde():
-    log_n, log_b, V, off, br = int(rng.integers(0, 18)), int(rng.integers(0, 6)), int(rng.choice([1, 3])), offset(), bool(rng.integers(0, 2))
+    log_n, log_b, V, off, br = int(rng.integers(0, TOP_LDE)), int(rng.integers(0, 6)), int(rng.choice([1, 3])), offset(), bool(rng.integers(0, 2))
     field = FQ3 if V == 3 else FP
     cols = [values((1 << log_n) * V) for _ in range(int(rng.integers(1, 4)))]
     out = Matrix.from_numpy(pl, cols, field).lde(1 << log_b, off, br).to_numpy()
