@@ -184,7 +184,8 @@ int ms_sha256_rows_row_major(ms_ctx* ctx, int field, size_t nrows, unsigned ncol
  *   The program is validated on the host (MS_ERR_INVALID on any out-of-range operand; `b` of a STORE
  *   must be 0).  Before launch the library rewrites it (csrc/eval_opt.h): sub-expressions of short
  *   period in i (zerofier inverses, x^N) are evaluated once into tables, long x^e chains become
- *   twiddle-table lookups, divisions by values of x alone are batch-inverted into tables, and the result is regrouped into
+ *   twiddle-table lookups, divisions by values of x alone are batch-inverted into tables (ONE table for all the divisors X - a whose
+ *   roots differ by a power of the trace generator: they are rotations of each other, csrc/eval_shift.h), and the result is regrouped into
  *   sums of products that are accumulated unreduced with one reduction per sum (csrc/eval_regroup.h; MS_EVAL_REGROUP=0
  *   switches that step off); on domains of >= 2^16 points the result is compiled (hiprtc, cached per
  *   context) into a specialised straight-line kernel (csrc/eval_jit.h; MS_EVAL_JIT=0 keeps the
