@@ -416,3 +416,32 @@ def test_denominator_built_on_another_inverse(kind):
     prog = E.compile_expr(expr, 3, False)
     out = E.eval(prog, pl, ch, ch[:1], 2, 7, n, [GpuVec.from_numpy(pl, c, FP) for c in base], []).to_numpy()
     assert np.array_equal(out, cref.eval_expr(expr, log_n, 2, 7, base, [], ch, ch[:1], False))
+
+
+def test_shared_tables_in_a_program_with_extension_columns_emu(capfd, monkeypatch):
+    """the same rotation of one inverse table inside a Q-typed program (Fq3 columns and challenges: the table and its scaling constant stay in
+    the base field, the product with the numerator is an Fq3 x Fp one) -- against the C oracle, natural and bit-reversed layouts"""
+    from ministark_amd.api import Radix2EvaluationDomain
+    pl = backends.planner("emu")
+    log_n, lde_step, offset = 12, 2, 7
+    n = 1 << log_n
+    g = Radix2EvaluationDomain(n // lde_step, 1, FP).group_gen
+    x = E.X()
+    expr = None
+    for j, r in enumerate([0, 1, -1, 3]):
+        a = pow(g, r % (n // lde_step), P)
+        t = (E.Trace(2 + j % 2, 0) * E.Challenge(j % 2) - E.Trace(j % 2, 1)) / (x - E.Constant(a))
+        expr = t if expr is None else expr + t * E.Trace(3, 1)
+    base = [cref.random_elements(n, 400 + k) for k in range(2)]
+    ext = [cref.random_elements(3 * n, 410 + k) for k in range(2)]
+    ch = cref.random_elements(6, 420).reshape(-1, 3)
+    prog = E.compile_expr(expr, 2, True)
+    want = cref.eval_expr(expr, log_n, lde_step, offset, base, ext, ch, ch[:1], True)
+    monkeypatch.setenv("MS_EVAL_DEBUG", "1")
+    capfd.readouterr()
+    got = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, FP) for c in base], [GpuVec.from_numpy(pl, c, FQ3) for c in ext]).to_numpy()
+    assert capfd.readouterr().err.count("shared tables:") == 3
+    assert np.array_equal(got, want)
+    got = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, cref.bit_reverse(c.copy(), log_n, 1), FP) for c in base],
+                 [GpuVec.from_numpy(pl, cref.bit_reverse(c.copy(), log_n, 3), FQ3) for c in ext], bit_reversed=True).to_numpy()
+    assert np.array_equal(got, cref.bit_reverse(want.copy(), log_n, 3))
