@@ -170,9 +170,101 @@ def _claim_stdout():
         os.dup2(2, 1)
 
 
+LINE_LIMIT = 4096          # the driver recovers the line from a bounded tail of stdout: the printed line stays below this, always
+
+
+def _g(o, *path):
+    """o[path[0]][path[1]]... or None."""
+    for k in path:
+        if not isinstance(o, dict) or k not in o:
+            return None
+        o = o[k]
+    return o
+
+
+def compact_line(d):
+    """The ONE line printed on stdout, built from the full record `d` (which goes to bench_detail.json): the contract's keys, the
+    dominant kernel's `roofline`, `cpu_baseline`, and one scalar per secondary object.  Pure: tests/test_bench_line.py builds it from
+    a recorded detail file and checks the size and the keys."""
+    r = d.get("roofline") or {}
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                  "vs_baseline", "dtype", "data")}
+    cfg = d.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("workload", "columns_per_gpu", "log_n", "parallelism") if k in cfg}
+    if r:
+        line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_transform",
+                                                  "us_per_transform_events", "valu_insts_per_element", "frac_of_valu_issue_peak")}
+        line["roofline"]["kernel"] = r.get("kernel")
+        if r.get("traffic") and r.get("algorithmic_bytes_per_transform"):
+            line["roofline"]["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes_per_transform"], 2)
+    if isinstance(d.get("cpu_baseline"), dict):
+        line["cpu_baseline"] = {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "ms_per_transform", "sample")}
+    sec = {
+        "field_ops_per_s": d.get("field_ops_per_s"),
+        "us_per_transform": d.get("us_per_transform"),
+        "single_column_us": _g(d, "variants", "single_column_repeated_us_per_transform"),
+        "inverse_coset_us": _g(d, "variants", "inverse_coset_us_per_transform"),
+        "lde_commit_frac": _g(d, "lde_commit", "roofline", "frac"),
+        "lde_commit_traffic_x": _g(d, "lde_commit", "roofline", "traffic_over_algorithmic"),
+        "lde_commit_wall_ms": _g(d, "lde_commit", "wall_ms"),
+        "lde_2_24_frac": _g(d, "lde_2_24", "roofline", "frac"),
+        "lde_2_24_traffic_x": _g(d, "lde_2_24", "roofline", "traffic_over_algorithmic"),
+        "lde_fq3_4x2_20_b8_ms": _g(d, "lde_fq3", "kernel_ms"),
+        "c4_i_frac": _g(d, "constraint_eval", "fib_air_fp", "roofline", "frac"),
+        "c4_ii_frac": _g(d, "constraint_eval", "mixed_17fp_9fq3", "roofline", "frac"),
+        "c4_iii_frac": _g(d, "constraint_eval", "fib_air_fp252", "roofline", "frac"),
+        "c4_iii_traffic_x": _g(d, "constraint_eval", "fib_air_fp252", "roofline", "traffic_over_algorithmic"),
+        "prove_ms": _g(d, "prove", "prove_ms"),
+        "prove_kernel_ms": _g(d, "prove", "kernel_ms"),
+        "prove_native_ms": _g(d, "prove", "native_host", "prove_ms"),
+        "prove_cpu_baseline_ms": _g(d, "prove", "cpu_baseline", "value"),
+        "cold_prove_ms": _g(d, "cold_start", "cold_prove_ms"),
+        "cold_prove_cached_ms": _g(d, "cold_start", "cold_prove_cached_ms"),
+        "jit_compile_ms": _g(d, "cold_start", "jit_compile_ms"),
+        "jit_cached_load_ms": _g(d, "cold_start", "jit_cached_load_ms"),
+        "sharded_lde_ms": _g(d, "sharded_lde_commit", "lde_ms"),
+        "sharded_exchange_ms": _g(d, "sharded_lde_commit", "exchange_ms"),
+        "sharded_commit_ms": _g(d, "sharded_lde_commit", "commit_ms"),
+        "sharded_prove_ms": _g(d, "sharded_lde_commit", "prove", "prove_ms"),
+        "sharded_root": (_g(d, "sharded_lde_commit", "root") or "")[:16] or None,
+        "sharded_error": _g(d, "sharded_lde_commit", "error"),
+        "multi_gpu": d.get("multi_gpu_note"),
+        "detail": d.get("detail_file"),
+    }
+    line.update({k: v for k, v in sec.items() if v is not None})
+    if isinstance(d.get("sharded_lde_commit"), dict) and d.get("mode") == "lde-commit":     # that mode's own object, without its prose
+        slim = lambda o: {k: (slim(v) if isinstance(v, dict) else v) for k, v in o.items() if k not in ("workload", "phases_ms_this_rank")}
+        line["sharded_lde_commit"] = slim(d["sharded_lde_commit"])
+    # the bound is a promise: shed the optional scalars, last first, until the line fits
+    optional = [k for k in sec if k in line]
+    while len(json.dumps(line)) >= LINE_LIMIT - 1 and optional:
+        line.pop(optional.pop())
+    return line
+
+
+def _write_detail(obj):
+    """The full record (every object, per-kernel counters, sweeps) next to bench.py and, on a gpurun box, under gpurun_out/ so that it
+    comes back; profiles/rNN_bench_detail.json is a copy of it.  -> the path written (relative), or None."""
+    wrote = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if d != ROOT and not os.path.isdir(d):
+                continue
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                json.dump(obj, f, indent=1)
+            wrote = wrote or os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT)
+        except OSError:
+            pass
+    return wrote
+
+
 def _emit(obj):
+    """Rank 0, once: the full record to bench_detail.json, its summary (< LINE_LIMIT bytes) as the one JSON line on stdout."""
+    obj["detail_file"] = _write_detail(obj)
+    line = json.dumps(compact_line(obj))
+    assert len(line) < LINE_LIMIT, len(line)
     out = _LINE_OUT if _LINE_OUT is not None else sys.stdout
-    out.write(json.dumps(obj) + "\n")
+    out.write(line + "\n")
     out.flush()
 
 
@@ -191,9 +283,9 @@ def _measure_traffic(log_n):
     per = {}
     work = tempfile.mkdtemp(prefix="ms_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(work, counter)
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable,
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")):
+            out = os.path.join(work, counters[0])
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cols", "2", "--log-n", str(log_n), "--no-cpu-baseline", "--no-extras", "--settle", "0.3"]
             env = dict(os.environ, MS_BENCH_NO_PMC="1", TMPDIR="/tmp")
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -211,22 +303,29 @@ def _measure_traffic(log_n):
                 name = row["Kernel_Name"]
                 # the three launches of the forward coset transform (the variants of the child run are off with --no-extras ... they are not:
                 # subgroup / inverse plans run too and are told apart by their template arguments, as in scripts/summarise_profiles.py)
-                if "msntt2" not in name or row["Counter_Name"] != counter:
+                counter = row["Counter_Name"]
+                if "msntt2" not in name or counter not in counters:
                     continue
                 if not any(t in name for t in ("ntt2_first_pass<true, false, true, 16", "ntt2_mid_pass<true, false, false, 0", "ntt2_mid_pass<true, false, true, 0",
                                                "ntt2_first_pass<false, false, true, 16", "ntt2_mid_pass<false, false, false, 0", "ntt2_mid_pass<false, false, true, 0")):
                     continue
                 cols = max(1.0, float(row["Grid_Size"]) / (((1 << log_n) // 16384) * 512))
                 per.setdefault(name, {}).setdefault(counter, []).append(float(row["Counter_Value"]) / cols)
-        total, kernels = 0.0, {}
+        total, insts, kernels = 0.0, 0.0, {}
+        mean = lambda v: sum(v) / len(v)
         for name, c in per.items():
             if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
                 return None
-            fb = 2 * 1024 * sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
-            wb = 1024 * sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
-            kernels[name.split("(")[0].replace("void ", "")] = {"fetch_bytes_per_column": round(fb), "write_bytes_per_column": round(wb)}
+            fb = 2 * 1024 * mean(c["FETCH_SIZE"])
+            wb = 1024 * mean(c["WRITE_SIZE"])
+            k = kernels[name.split("(")[0].replace("void ", "")] = {"fetch_bytes_per_column": round(fb), "write_bytes_per_column": round(wb)}
+            if "SQ_INSTS_VALU" in c:                             # wave instructions of one column's launch -> per element (64 lanes)
+                k["valu_insts_per_element"] = round(mean(c["SQ_INSTS_VALU"]) * 64.0 / (1 << log_n), 1)
+                insts += mean(c["SQ_INSTS_VALU"])
+                if c.get("SQ_BUSY_CYCLES") and mean(c["SQ_BUSY_CYCLES"]):
+                    k["valu_busy"] = round((mean(c["SQ_ACTIVE_INST_VALU"]) * 4.0 / 1024) / (mean(c["SQ_BUSY_CYCLES"]) / 32.0), 3)
             total += fb + wb
-        return (total, kernels) if len(per) == 3 else None
+        return (total, kernels, insts or None) if len(per) == 3 else None
     except Exception:                                            # noqa: BLE001 -- an extra: the line falls back to the tracked summary
         return None
     finally:
@@ -773,6 +872,12 @@ def _spawn_ranks(n):
     return 0
 
 
+def _latest_traffic_json():
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ntt_traffic.json")))
+    return hits[-1] if hits else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -782,7 +887,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed transforms before the warm-up steps (clock ramp)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_ntt_traffic.json"), help="JSON file with PMC-derived HBM bytes per transform")
+    ap.add_argument("--traffic-json", default=_latest_traffic_json(), help="JSON file with PMC-derived HBM bytes per transform (default: the newest profiles/rNN_ntt_traffic.json)")
     ap.add_argument("--mode", choices=["ntt", "lde-commit"], default="ntt", help="lde-commit: only the column-sharded LDE + commitment (any N)")
     ap.add_argument("--no-extras", action="store_true", help="skip the lde_commit / prove / sharded objects")
     ap.add_argument("--pmc-child", action="store_true", help="internal: every object's workload between marker launches, under rocprofv3 --pmc")
@@ -884,7 +989,7 @@ def main():
                               "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["total_ms"],
                               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                               "config": {"workload": r["workload"], "parallelism": f"columns x{world}, rows x{world} after the exchange"},
-                              "sharded_lde_commit": r})
+                              "mode": "lde-commit", "sharded_lde_commit": r})
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -983,6 +1088,7 @@ def main():
         "us_per_transform": round(elapsed / args.steps / args.cols * 1e6, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_kernels": traffic_kernels,
+                     "kernel": "ntt2_first_pass + 2 x ntt2_mid_pass: the three radix-256 passes of one forward coset transform",
                      "algorithmic_bytes_per_transform": alg_bytes_col,
                      "us_per_transform_events": round(us_per_transform, 2), "kernels": kernels},
     }
@@ -1051,8 +1157,11 @@ def main():
         pl.sync()
         measured = _measure_traffic(log_n)
         if measured is not None:
-            traffic, traffic_kernels = measured
-            traffic_source = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child runs of 2 columns x 2 steps), per launch and column"
+            traffic, traffic_kernels, wave_insts = measured
+            traffic_source = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (three child runs of 2 columns x 2 steps), per launch and column"
+            if wave_insts and us_per_transform:
+                out["roofline"]["valu_insts_per_element"] = round(wave_insts * 64.0 / n, 1)
+                out["roofline"]["frac_of_valu_issue_peak"] = round(wave_insts / (us_per_transform * 1e-6) / VALU_ISSUE_PEAK, 4)
         _attach_all({k: out[k] for k in ("lde_commit", "lde_2_24", "constraint_eval", "prove") if isinstance(out.get(k), dict)}, _measure_objects())
     if traffic is None and args.traffic_json and os.path.exists(args.traffic_json):
         traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_transform")

@@ -226,6 +226,25 @@ int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, con
  * MS_ERR_UNSUPPORTED with the compiler log in ms_last_error(). */
 int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int out_field, size_t* code_bytes);
 
+/* Where the specialised kernels came from and what they cost.  The reference ships its shaders
+ * precompiled (gpu/src/plan.rs:30 include_bytes!("metal/shaders.metallib")) and pays nothing at run
+ * time; here a program's first evaluation in a PROCESS either loads its gfx950 code object from the
+ * on-disk cache ($MS_JIT_CACHE, default ~/.cache/ministark_hip; MS_JIT_CACHE=0 switches it off; entries
+ * are keyed by SHA-256 of source + options + compiler version + the library's device headers, carry a
+ * digest, and a damaged entry is dropped and recompiled) or compiles it with hiprtc and stores it.
+ * compile_failures > 0 means some program runs on the interpreter (same words, several times slower;
+ * a warning is printed once per process).  ctx NULL: the totals of the process (ms_eval_jit_check
+ * counts there). */
+typedef struct ms_jit_stats {
+    uint64_t kernels_compiled;   /* hiprtc runs that produced a kernel                         */
+    uint64_t kernels_from_disk;  /* kernels loaded from the cache without compiling            */
+    uint64_t compile_failures;   /* programs left to the interpreter                           */
+    uint64_t damaged_entries;    /* cache files rejected (digest / size / loader) and replaced */
+    double compile_ms;           /* wall time inside hiprtc                                    */
+    double load_ms;              /* reading cache entries + hipModuleLoadData                  */
+} ms_jit_stats;
+int ms_eval_jit_stats(ms_ctx* ctx, ms_jit_stats* out);
+
 /* ---- extension columns and queries.
  * ms_scan_affine     the sequential host loops that build running-product / running-evaluation
  *                    extension columns (examples/brainfuck/trace.rs:108-289):

@@ -206,17 +206,33 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
         hipFunction_t fn = nullptr;
         std::vector<char> code;
         std::string log;
-        if (jit_compile(src, code, log)) {
+        JitStats st;
+        // a cached entry the loader refuses (it passed its digest: a foreign or stale code object) is compiled afresh once
+        for (int attempt = 0; attempt < 2 && !fn; attempt++) {
+            const uint64_t disk_before = st.from_disk;
+            if (!jit_obtain(src, code, log, st, attempt == 1)) break;
+            const double t0 = jit_now_ms();
             hipModule_t mod = nullptr;
             if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, "ms_eval_jit") == hipSuccess) ctx->jit_modules.push_back(mod);
-            else { fn = nullptr; (void)hipGetLastError(); }
-            if (fn && getenv("MS_EVAL_DEBUG")) {
-                int regs = 0, spill = 0;
-                (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn);
-                (void)hipFuncGetAttribute(&spill, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn);
-                fprintf(stderr, "[ministark_hip] specialised constraint kernel: %u instructions, %d vector registers, %d bytes of scratch per lane\n", cnt, regs, spill);
-            }
-        } else if (getenv("MS_EVAL_DEBUG")) fprintf(stderr, "[ministark_hip] constraint kernel compilation failed, using the interpreter:\n%s\n", log.c_str());
+            else { fn = nullptr; (void)hipGetLastError(); if (mod) (void)hipModuleUnload(mod); }
+            st.load_ms += jit_now_ms() - t0;
+            if (!fn && st.from_disk == disk_before) break;       // a freshly compiled object that does not load: no second try
+            if (!fn) { st.damaged_entries++; st.from_disk--; }
+        }
+        if (!fn) {
+            if (!st.failures) st.failures++;
+            jit_warn_failure(log.empty() ? std::string("(the code object was produced but hipModuleLoadData / hipModuleGetFunction refused it)") : log);
+        } else if (getenv("MS_EVAL_DEBUG")) {
+            int regs = 0, spill = 0;
+            (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn);
+            (void)hipFuncGetAttribute(&spill, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn);
+            fprintf(stderr, "[ministark_hip] specialised constraint kernel: %u instructions, %d vector registers, %d bytes of scratch per lane (%s)\n", cnt, regs, spill,
+                    st.from_disk ? "from the disk cache" : "compiled");
+        }
+        for (JitStats* t : {&ctx->jit_stats, &jit_process_stats()}) {
+            t->compiled += st.compiled; t->from_disk += st.from_disk; t->failures += st.failures; t->damaged_entries += st.damaged_entries;
+            t->compile_ms += st.compile_ms; t->load_ms += st.load_ms;
+        }
         ctx->jit_cache[key] = fn;
         return fn;
 #else
@@ -440,11 +456,30 @@ extern "C" int ms_eval_jit_check(const uint32_t* h_prog, unsigned ninstr, int ou
     std::string log;
     const std::string src = jit_source(prog, ninstr, is252, maxp, maxq);
     if (const char* dump = getenv("MS_EVAL_DUMP")) { if (FILE* f = fopen(dump, "a")) { fputs(src.c_str(), f); fputs("\n// ----\n", f); fclose(f); } }
-    if (!jit_compile(src, code, log)) return fail(MS_ERR_UNSUPPORTED, "hiprtc: %s", log.c_str());
+    // through the on-disk cache like an evaluation (jit_cache.h): the first call for a program compiles and stores, later processes load
+    static std::mutex mu;                                     // the process totals have no context lock of their own
+    std::lock_guard<std::mutex> lk(mu);
+    JitStats st;
+    const bool ok = jit_obtain(src, code, log, st);
+    JitStats& T = jit_process_stats();
+    T.compiled += st.compiled; T.from_disk += st.from_disk; T.failures += st.failures; T.damaged_entries += st.damaged_entries; T.compile_ms += st.compile_ms; T.load_ms += st.load_ms;
+    if (!ok) return fail(MS_ERR_UNSUPPORTED, "hiprtc: %s", log.c_str());
     *code_bytes = code.size();
     return MS_OK;
 #else
     (void)h_prog; (void)ninstr; (void)out_field; (void)code_bytes;
     return fail(MS_ERR_UNSUPPORTED, "built without hiprtc");
 #endif
+}
+
+JitStats& jit_process_stats() { static JitStats s; return s; }
+
+extern "C" int ms_eval_jit_stats(ms_ctx* ctx, ms_jit_stats* out) {
+    if (!out) return fail(MS_ERR_INVALID, "ms_eval_jit_stats: null argument");
+    JitStats st;
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); st = ctx->jit_stats; }
+    else st = jit_process_stats();
+    out->kernels_compiled = st.compiled; out->kernels_from_disk = st.from_disk; out->compile_failures = st.failures;
+    out->damaged_entries = st.damaged_entries; out->compile_ms = st.compile_ms; out->load_ms = st.load_ms;
+    return MS_OK;
 }

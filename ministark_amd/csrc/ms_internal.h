@@ -35,6 +35,10 @@ int field_words(int field, unsigned* V);
     } while (0)
 
 
+// what the specialised constraint kernels cost and where they came from (eval_jit.h, jit_cache.h; ms_eval_jit_stats)
+struct JitStats { uint64_t compiled = 0, from_disk = 0, failures = 0, damaged_entries = 0; double compile_ms = 0, load_ms = 0; };
+JitStats& jit_process_stats();              // the process-wide totals (ms_eval_jit_check has no context)
+
 struct ms_ntt_plan;
 struct PlanKey { unsigned V, log_n; bool inverse; uint64_t h; };
 struct ms_ctx {
@@ -72,6 +76,7 @@ struct ms_ctx {
     // nullptr = compilation failed once, use the interpreter
     std::map<std::string, hipFunction_t> jit_cache;   // keyed by the full source text, not a hash of it
     std::vector<hipModule_t> jit_modules;
+    JitStats jit_stats;
     // optional per-launch timing (ms_profile_*): hipEvent pairs around every kernel launch
     bool profiling = false;
     struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes; };
