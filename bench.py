@@ -821,6 +821,121 @@ def bench_constraint_eval(pl, with_cpu, pmc=None):
     return None if pmc is not None else out
 
 
+def _cold_child_main():
+    """--cold-child: what a process that proves ONCE pays (the reference's usage: examples/fib/main.rs:227-243).  Fresh process, nothing
+    created yet: context -> (trace upload, not counted) -> first proof (plans, twiddle uploads, kernel code loading, the constraint
+    kernels: hiprtc or the on-disk cache) -> second proof (warm).  Then the three configs[3] programs on 2^16 points each, for their
+    compilation / cache-load cost alone.  Prints one JSON object on stdout."""
+    t_proc = time.perf_counter()
+    from ministark_amd import GOLDILOCKS_FP, GOLDILOCKS_FQ3, STARK252_FP, GpuVec, Matrix, Planner, expr as E, pipeline
+    t_imp = time.perf_counter()
+    pl = Planner(int(os.environ.get("LOCAL_RANK", "0")))
+    pl.sync()
+    t_ctx = time.perf_counter()
+    log_t, blowup, folding, ncols = 22, 4, 8, 8
+    n_t = 1 << log_t
+    rng = np.random.default_rng(5)
+    host = [rng.integers(0, P_GOLDILOCKS, size=n_t, dtype=np.uint64) for _ in range(ncols)]
+    comp, ce, nch = pipeline.fib_constraints(n_t, ncols)
+    draws = pipeline.Draws(0xC5, ncols, nch, ce, 32, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64))
+    t_up0 = time.perf_counter()
+    trace = Matrix.from_numpy(pl, host, GOLDILOCKS_FP)
+    pl.sync()
+    t_up1 = time.perf_counter()
+    times, roots = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, ce_blowup=ce)
+        pl.sync()
+        times.append((time.perf_counter() - t0) * 1e3)
+        roots.append(res["base_root"].hex())
+        if len(times) == 1:
+            first_phases, first_jit = dict(res["phases_ms"]), pl.jit_stats()
+    out = {"import_ms": round((t_imp - t_proc) * 1e3, 1), "context_ms": round((t_ctx - t_imp) * 1e3, 1), "trace_upload_ms": round((t_up1 - t_up0) * 1e3, 1),
+           "first_prove_ms": round(times[0], 2), "second_prove_ms": round(times[1], 2), "third_prove_ms": round(times[2], 2),
+           "cold_prove_ms": round((t_ctx - t_imp) * 1e3 + times[0], 2), "first_prove_phases_ms": first_phases, "first_prove_jit": first_jit,
+           "same_root": len(set(roots)) == 1, "base_root": roots[0]}
+    for c in trace.columns:
+        c.free()
+    # the three constraint programs of configs[3] on a small domain: their first evaluation in this process, by itself
+    n = 1 << 16
+    P = P_GOLDILOCKS
+    jit = {}
+    cases = []
+    comp, _, nch = pipeline.fib_constraints(n)
+    cases.append(("fib_air_fp", comp, 1, 7, GOLDILOCKS_FP, False, [rng.integers(0, P, size=n, dtype=np.uint64) for _ in range(8)], [],
+                  rng.integers(1, P, size=(nch, 1), dtype=np.uint64)))
+    comp, nch = pipeline.mixed_air_constraints()
+    cases.append(("mixed_17fp_9fq3", comp, 2, 7, GOLDILOCKS_FP, True, [rng.integers(0, P, size=n, dtype=np.uint64) for _ in range(17)],
+                  [rng.integers(0, P, size=3 * n, dtype=np.uint64) for _ in range(9)], rng.integers(1, P, size=(nch, 3), dtype=np.uint64)))
+    comp, _, nch = pipeline.fib_constraints(n >> 2, 8, STARK252_FP)
+    f252 = []
+    for _ in range(8):
+        c = rng.integers(0, 1 << 63, size=4 * n, dtype=np.uint64)
+        c[3::4] >>= np.uint64(4)
+        f252.append(c)
+    cases.append(("fib_air_fp252", comp, 4, 3, STARK252_FP, False, f252, [], rng.integers(0, 1 << 59, size=(nch, 4), dtype=np.uint64)))
+    for key, comp, lde_step, offset, field, fq_ext, base, ext, ch in cases:
+        prog = E.compile_expr(comp, len(base), fq_ext, field)
+        dbase = [GpuVec.from_numpy(pl, c, field) for c in base]
+        dext = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FQ3) for c in ext]
+        pl.sync()
+        b = pl.jit_stats()
+        t0 = time.perf_counter()
+        E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, dbase, dext)
+        pl.sync()
+        first = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, dbase, dext)
+        pl.sync()
+        a = pl.jit_stats()
+        jit[key] = {"first_eval_ms": round(first, 2), "second_eval_ms": round((time.perf_counter() - t0) * 1e3, 2),
+                    "compile_ms": round(a["compile_ms"] - b["compile_ms"], 2), "load_ms": round(a["load_ms"] - b["load_ms"], 2),
+                    "kernels_compiled": a["kernels_compiled"] - b["kernels_compiled"], "kernels_from_disk": a["kernels_from_disk"] - b["kernels_from_disk"],
+                    "compile_failures": a["compile_failures"] - b["compile_failures"]}
+    if not (jit["fib_air_fp"]["kernels_compiled"] or jit["fib_air_fp"]["kernels_from_disk"]):
+        # the same AIR as the proof above: its kernel is already in this context's table -- what it cost is the first proof's record
+        jit["fib_air_fp"].update({k: (round(first_jit[k], 2) if isinstance(first_jit[k], float) else first_jit[k]) for k in ("compile_ms", "load_ms", "kernels_compiled", "kernels_from_disk")},
+                                 note="compiled / loaded during the first proof (same program)")
+    out["constraint_programs"] = jit
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+
+
+def bench_cold_start():
+    """Two fresh processes (--cold-child), the first with an EMPTY on-disk kernel cache, the second with the cache the first one filled:
+    the cost of a first-ever proof on a machine, and of the first proof of every later process.  Bar: the reference pays zero run-time
+    compilation (gpu/src/plan.rs:30)."""
+    import shutil
+    import subprocess
+    import tempfile
+    work = tempfile.mkdtemp(prefix="ms_jit_cold_", dir="/tmp")
+    try:
+        runs = []
+        for _ in range(2):
+            # the compiler's own cache (comgr, ~/.cache/comgr) is switched off in BOTH processes: the first must really compile,
+            # the second must owe what it saves to the library's cache alone
+            env = dict(os.environ, MS_JIT_CACHE=os.path.join(work, "cache"), AMD_COMGR_CACHE="0")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-child"], env=env, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": (r.stdout + r.stderr)[-600:]}
+            runs.append(json.loads(lines[-1]))
+        empty, cached = runs
+        entries = [f for f in os.listdir(os.path.join(work, "cache")) if f.endswith(".co")]
+        return {"workload": "a fresh process: context + first proof of configs[4]'s shape (2^22 rows x 8 columns, fib AIR); then the configs[3] programs on 2^16 points",
+                "cold_prove_ms": empty["cold_prove_ms"], "cold_prove_cached_ms": cached["cold_prove_ms"], "warm_prove_ms": min(cached["second_prove_ms"], cached["third_prove_ms"]),
+                "jit_compile_ms": {k: v["compile_ms"] for k, v in empty["constraint_programs"].items()},
+                "jit_cached_load_ms": {k: v["load_ms"] for k, v in cached["constraint_programs"].items()},
+                "same_root_both_processes": empty["base_root"] == cached["base_root"] and empty["same_root"] and cached["same_root"],
+                "cache_entries": len(entries), "cache_bytes": sum(os.path.getsize(os.path.join(work, "cache", f)) for f in entries),
+                "empty_cache_process": empty, "cached_process": cached}
+    except Exception as e:                                       # noqa: BLE001 -- an extra
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def _spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) as children of this process with the
     environment torch.distributed.run would give them, pass rank 0's stdout (the JSON line) through, fail if any rank fails."""
@@ -891,10 +1006,14 @@ def main():
     ap.add_argument("--mode", choices=["ntt", "lde-commit"], default="ntt", help="lde-commit: only the column-sharded LDE + commitment (any N)")
     ap.add_argument("--no-extras", action="store_true", help="skip the lde_commit / prove / sharded objects")
     ap.add_argument("--pmc-child", action="store_true", help="internal: every object's workload between marker launches, under rocprofv3 --pmc")
+    ap.add_argument("--cold-child", action="store_true", help="internal: a fresh process's first proof (bench_cold_start)")
     ap.add_argument("--log-rows", type=int, default=22, help="--mode lde-commit: rows of the trace (configs[4]: 2^22)")
     ap.add_argument("--total-cols", type=int, default=32, help="--mode lde-commit: columns of the trace, sharded over the ranks")
     args = ap.parse_args()
 
+    if args.cold_child:
+        _cold_child_main()
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(_spawn_ranks(args.gpus))
     _claim_stdout()
@@ -1138,6 +1257,7 @@ def main():
         out["lde_2_24"] = bench_lde_2_24(pl)
         out["constraint_eval"] = bench_constraint_eval(pl, not args.no_cpu_baseline)
         out["prove"] = bench_prove(pl, not args.no_cpu_baseline)
+        out["cold_start"] = bench_cold_start()
     if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
         from oracle import cref
         x = host_cols[0].copy()

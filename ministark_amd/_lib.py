@@ -20,6 +20,15 @@ class MsError(RuntimeError):
         self.code = code
 
 
+class JitStats(ctypes.Structure):
+    """`ms_jit_stats` of include/ministark_hip.h."""
+    _fields_ = [("kernels_compiled", ctypes.c_uint64), ("kernels_from_disk", ctypes.c_uint64), ("compile_failures", ctypes.c_uint64),
+                ("damaged_entries", ctypes.c_uint64), ("compile_ms", ctypes.c_double), ("load_ms", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class Lib:
     """Typed view of the C ABI in include/ministark_hip.h."""
 
@@ -66,6 +75,7 @@ class Lib:
             "ms_eval_program": (i, [vp, vp, u, vp, u, u, u, vp, vp, c_void_pp, u, c_void_pp, u, c_void_pp, vp, u, i, vp]),
             "ms_eval_program_ex": (i, [vp, vp, u, vp, u, u, u, vp, vp, c_void_pp, u, c_void_pp, u, c_void_pp, vp, u, i, vp, u]),
             "ms_eval_jit_check": (i, [vp, u, i, vp]),
+            "ms_eval_jit_stats": (i, [vp, ctypes.POINTER(JitStats)]),
             "ms_scan_affine": (i, [vp, i, sz, vp, vp, vp, i, vp]),
             "ms_gather_rows": (i, [vp, i, sz, c_void_pp, u, vp, sz, vp]),
             "ms_gather_digests": (i, [vp, sz, vp, vp, sz, vp]),
@@ -104,6 +114,13 @@ class Lib:
         fn.restype = res
         fn.argtypes = args
         return fn
+
+    def jit_stats(self, handle=None):
+        """Specialised constraint kernels of a context (None: of the whole process): compiled / loaded from the disk cache / left to the
+        interpreter, and the milliseconds each cost (ms_eval_jit_stats)."""
+        st = JitStats()
+        self.check(self.L.ms_eval_jit_stats(handle, ctypes.byref(st)))
+        return st.as_dict()
 
     def check(self, rc):
         if rc != 0:

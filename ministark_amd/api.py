@@ -84,6 +84,11 @@ class Planner:
                          "bytes_per_call": float(b)}
         return out
 
+    def jit_stats(self):
+        """-> dict: this context's specialised constraint kernels -- compiled, loaded from the on-disk cache, failed (interpreter) -- and
+        what that cost in milliseconds.  A non-zero `compile_failures` is a performance bug worth reporting, never a wrong result."""
+        return self.lib.jit_stats(self.handle)
+
     def close(self):
         if self.handle:
             for plan in list(self._plans):               # plans refer to the context: release them first

@@ -55,6 +55,8 @@ public:
     Planner& operator=(const Planner&) = delete;
     ms_ctx* ctx() const { return ctx_; }
     void sync() const { check(ms_sync(ctx_)); }        // command_buffer.wait_until_completed()
+    // specialised constraint kernels of this context: compiled / loaded from the on-disk cache / left to the interpreter (include/ministark_hip.h)
+    ms_jit_stats jit_stats() const { ms_jit_stats st{}; check(ms_eval_jit_stats(ctx_, &st)); return st; }
 private:
     ms_ctx* ctx_ = nullptr;
 };

@@ -23,6 +23,13 @@ impl Planner {
     pub fn ctx(&self) -> *mut sys::ms_ctx { self.ctx }
     /// `command_buffer.commit(); command_buffer.wait_until_completed()`
     pub fn sync(&self) { sys::check(unsafe { sys::ms_sync(self.ctx) }) }
+    /// Specialised constraint kernels of this context: compiled / loaded from the on-disk cache / left to the interpreter.  The Metal arm has
+    /// nothing to report (its shaders are a build artefact, gpu/src/plan.rs:30); here `compile_failures > 0` is worth a log line.
+    pub fn jit_stats(&self) -> sys::ms_jit_stats {
+        let mut st = sys::ms_jit_stats::default();
+        sys::check(unsafe { sys::ms_eval_jit_stats(self.ctx, &mut st) });
+        st
+    }
 }
 impl Default for Planner {
     /// `Planner::default()` (gpu/src/plan.rs:464-468: the system default device): GPU `$MINISTARK_HIP_DEVICE`, else 0.
