@@ -111,12 +111,19 @@ template <bool STREAM, bool UNI>
 __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
     const uint64_t* __restrict__ src = P.src[blockIdx.z];
-    const unsigned j = blockIdx.y;
+    // Which (tile, coset) this workgroup takes.  A tile of coefficients is read by all beta cosets; in plain grid order (tile fastest) the
+    // beta readers of a tile are a whole coset apart and, for 2^22-row columns (32 MiB = all eight L2s), the tile has left the cache by
+    // then: 2.8 x the input fetched at beta = 4 (round 5, FETCH_SIZE).  Workgroups are dealt to the XCDs round-robin (linear id % 8;
+    // observed, as for first_pass_tile -- only speed depends on it), so the beta cosets of a tile take CONSECUTIVE slots of one XCD:
+    // the first one misses, the others find the lines in that XCD's L2 (or merge with the miss in flight).
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+    const unsigned j = slot & ((1u << P.log_b) - 1);
+    const unsigned bx = ((slot >> P.log_b) << 3) | (lin & 7);
     const size_t n = (size_t)1 << P.log_n, L = n >> 8;
     uint64_t* __restrict__ dst = P.dst[blockIdx.z] + (size_t)j * n;
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t i0 = (size_t)blockIdx.x * TW + lane;
+    const size_t i0 = (size_t)bx * TW + lane;
     const uint64_t* gpl_j = P.gpl + (size_t)j * 256 * 4;
 
     const size_t step = 16 * L;
@@ -129,7 +136,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     }
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        net1<1, UNI>(x[h], P, w + 8 * h, gpl_j, glimb::Q3{}, (blockIdx.x * 16 + w + 8 * h) * 16);
+        net1<1, UNI>(x[h], P, w + 8 * h, gpl_j, glimb::Q3{}, (bx * 16 + w + 8 * h) * 16);
         #pragma unroll
         for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
         __builtin_amdgcn_sched_barrier(0);
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
         glimb::dft<16, false>(v);
         uint64_t* q = dst + (size_t)ap * L + i0;
         if constexpr (UNI) {
-            const unsigned slot0 = ((j * (unsigned)(L >> 6)) + blockIdx.x) * 16;
+            const unsigned slot0 = ((j * (unsigned)(L >> 6)) + bx) * 16;
             #pragma unroll
             for (int g = 0; g < 4; g++) {                     // four factors at a time (more of them in flight spill scalar registers)
                 glimb::W4 wc[4];
@@ -201,7 +208,12 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     constexpr int T1 = T > 16 ? T / 16 : 1, LOGT1 = T1 == 4 ? 2 : T1 == 2 ? 1 : 0;     // T >= 32: radix T = 16 x T1
     constexpr int ITEMP = 16 * T1 + 1;                       // T >= 32: pitch (words) of a (k, row) item in the third exchange
     constexpr int X3WORDS = 8192 + 8192 / 16;               // third exchange: the 8192 words of a round, one pad word per 16
-    constexpr int XWORDS = X3WORDS > 128 * X2P ? X3WORDS : 128 * X2P;
+    constexpr int XCHW = X3WORDS > 128 * X2P ? X3WORDS : 128 * X2P;
+    // The second half of the first network's outputs (x[h][8..15], 32 registers) waits in registers through all of round 0; NSP of those
+    // words per lane wait in the tail of the LDS buffer instead (80 KiB per workgroup: still two per CU) -- with them in registers the
+    // compiler kept 5 .. 19 registers in scratch memory, and scratch stores reach HBM.
+    constexpr int NSP = 3, XWORDS = XCHW + NSP * NT;
+    static_assert(XWORDS * 8 <= 80 * 1024, "two workgroups per CU");
     __shared__ uint64_t xch[XWORDS];
     const unsigned j = blockIdx.z;
     const size_t n = (size_t)1 << P.log_n;
@@ -236,6 +248,10 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
         net1<UNI ? 2 : 0>(x[h], P, w + 8 * h, nullptr, qh);
         #pragma unroll
         for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][q];
+        if (h == 1) {
+            #pragma unroll
+            for (int k = 0; k < NSP; k++) xch[XCHW + k * NT + threadIdx.x] = x[1][16 - NSP + k];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     #pragma unroll
@@ -245,7 +261,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             #pragma unroll
             for (int h = 0; h < 2; h++)
                 #pragma unroll
-                for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = x[h][8 + q];
+                for (int q = 0; q < 8; q++) xch[((w + 8 * h) * 8 + q) * TW + lane] = (h == 1 && q >= 8 - NSP) ? xch[XCHW + (q - (8 - NSP)) * NT + threadIdx.x] : x[h][8 + q];
         }
         __syncthreads();
         const unsigned ap = w + 8 * r;                        // a' = low digit of k
@@ -337,9 +353,14 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
         } else {
         // ---- T = 16 T1 (T1 = 2, 4): t = t1 + T1 t0, output s = s0 + 16 s1.  Radix 16 over t0 with t1 WAVE-UNIFORM (one (k, row, t1)
         // item per lane: 128 k x RSEL rows x T1 = 512), times w_T^(t1 s0) from scalar registers, third exchange, radix T1 over t1.
+        // (the lane index of each block below goes through pin(): otherwise the compiler computes the index arithmetic of BOTH rounds once,
+        // ahead of round 0, and keeps ~40 addresses alive through it -- 16 / 19 registers in scratch at T = 64 / 32, and scratch stores reach
+        // HBM: a quarter more bytes written than the output itself (round 6, WRITE_SIZE).  Not done for T <= 16: there the shared index
+        // arithmetic is 250 instructions per round, 6 % of the kernel, against two spilled registers)
         {
-            const unsigned t1 = w & (T1 - 1);
-            const unsigned q = (w >> LOGT1) * 64 + lane, kk = q & 127, rsel = q >> 7;
+            const unsigned ln = (unsigned)pin((uint64_t)lane);
+            const unsigned t1 = msntt2::spin(w & (T1 - 1));   // (and the 16 factors of c3 are loaded again in round 1 rather than parked in vector lanes)
+            const unsigned q = (w >> LOGT1) * 64 + ln, kk = q & 127, rsel = q >> 7;
             glimb::L4 v[16];
             #pragma unroll
             for (int t0 = 0; t0 < 16; t0++) v[t0] = glimb::from_u64(xch[kk * X2P + rsel * T + t1 + T1 * t0]);
@@ -359,8 +380,15 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
         __syncthreads();
         // radix T1 and the stores: wave = a' (as after the first exchange), lane = (position s0r = rev4(s0) of the run, bq); a lane takes the
         // chunks rev4(b') = bq + 4 i of its wave's 16 T-word chunks: T1 consecutive words each (bit-reversed order of s1), 16-byte stores
+        // T1 = 4: a lane's four words are 32 consecutive bytes but a store instruction carries 16 per lane -- written straight out, each of
+        // the two instructions covers HALF of every 32-byte sector, and the streaming stores are not merged on the way to HBM: 2.04 x the
+        // output written (round 5, WRITE_SIZE).  So the lanes of a pair (2 p, 2 p + 1) take the groups p and 8 + p of the 16-group chunk and
+        // swap halves through one DPP move per register: every lane then holds words 2 l, 2 l + 1 and 32 + 2 l, 33 + 2 l of the chunk, and
+        // each store instruction writes 256 contiguous bytes per 16 lanes.
         {
-            const unsigned s0r = lane & 15, bq = lane >> 4, s0 = __brev(s0r) >> 28;
+            const unsigned ln = (unsigned)pin((uint64_t)lane);
+            const unsigned s0r = ln & 15, bq = ln >> 4;
+            const unsigned grp = T1 == 4 ? ((s0r & 1) << 3) | (s0r >> 1) : s0r, s0 = __brev(grp) >> 28;      // position of this lane's group in the chunk
             #pragma unroll
             for (int i = 0; i < 4 * RSEL; i++) {
                 const unsigned brev = bq + 4 * (i & 3), rsel = i >> 2, bp = __brev(brev) >> 28, kk = w * 16 + bp;
@@ -370,12 +398,15 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
                 for (int tt = 0; tt < T1; tt++) u[tt] = glimb::from_u64(e3[tt]);
                 glimb::dft<T1, false>(u);
                 const unsigned k1 = row0 + rsel;
-                uint64_t* const o = dst + (size_t)(__brev(k1) >> 24) * L + (size_t)((r + 2 * (__brev(w) >> 29)) * 16 + brev) * T + s0r * T1;
+                uint64_t* const chunk = dst + (size_t)(__brev(k1) >> 24) * L + (size_t)((r + 2 * (__brev(w) >> 29)) * 16 + brev) * T;
                 if constexpr (T1 == 4) {
-                    NTT2_ST((msntt2::Pair*)o, (msntt2::Pair{glimb::to_canon(u[0]), glimb::to_canon(u[2])}), 2);
-                    NTT2_ST((msntt2::Pair*)(o + 2), (msntt2::Pair{glimb::to_canon(u[1]), glimb::to_canon(u[3])}), 2);
+                    const uint64_t w0 = glimb::to_canon(u[0]), w1 = glimb::to_canon(u[2]), w2 = glimb::to_canon(u[1]), w3 = glimb::to_canon(u[3]);   // memory order
+                    const uint64_t n0 = msntt2::lane_xor1(w0), n1 = msntt2::lane_xor1(w1), n2 = msntt2::lane_xor1(w2), n3 = msntt2::lane_xor1(w3);
+                    const bool odd = s0r & 1;
+                    NTT2_ST((msntt2::Pair*)(chunk + 2 * s0r), (msntt2::Pair{odd ? n2 : w0, odd ? n3 : w1}), 2);
+                    NTT2_ST((msntt2::Pair*)(chunk + 32 + 2 * s0r), (msntt2::Pair{odd ? w2 : n0, odd ? w3 : n1}), 2);
                 } else {
-                    NTT2_ST((msntt2::Pair*)o, (msntt2::Pair{glimb::to_canon(u[0]), glimb::to_canon(u[1])}), 2);
+                    NTT2_ST((msntt2::Pair*)(chunk + s0r * T1), (msntt2::Pair{glimb::to_canon(u[0]), glimb::to_canon(u[1])}), 2);
                 }
             }
         }
