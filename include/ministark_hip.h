@@ -42,7 +42,8 @@ enum {
     MS_ERR_INVALID = -1,     /* bad argument (size not a power of two, null pointer, ...) */
     MS_ERR_UNSUPPORTED = -2, /* field / size / option outside what the backend implements */
     MS_ERR_HIP = -3,         /* a HIP runtime call failed */
-    MS_ERR_NOMEM = -4
+    MS_ERR_NOMEM = -4,
+    MS_ERR_INTERNAL = -5     /* a self-check of the library failed (MS_EVAL_SELFCHECK): a bug, please report */
 };
 
 typedef struct ms_ctx ms_ctx;
@@ -215,6 +216,11 @@ int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const 
  * consecutive positions differ in the high bits of the point index, so rotated rows are again consecutive positions
  * and the loads stay coalesced.  d_out = the natural-order result, bit-reversed. */
 #define MS_EVAL_BIT_REVERSED 1u
+/* MS_EVAL_PLAIN (diagnostics): evaluate the program exactly as given on the interpreter -- none of the rewriting passes (tables of
+ * short-period / x-only sub-expressions, shared inverse tables, sums of products), no specialised kernel.  Same output words, several
+ * times slower.  With MS_EVAL_SELFCHECK=1 in the environment every evaluation is followed by this one and compared word by word
+ * (MS_ERR_INTERNAL on a difference). */
+#define MS_EVAL_PLAIN 2u
 int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
                        unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
                        const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,

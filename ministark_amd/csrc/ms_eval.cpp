@@ -22,13 +22,50 @@ extern "C" int ms_eval_program(ms_ctx* ctx, const uint32_t* h_prog, unsigned nin
     return ms_eval_program_ex(ctx, h_prog, ninstr, h_consts, nconst_words, log_n, lde_step, h_domain_offset, d_x_lde, d_base_cols, nbase,
                               d_ext_cols, next, d_periodic, periodic_len, nperiodic, out_field, d_out, 0u);
 }
+static int eval_locked(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                       unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                       const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                       const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                       int out_field, void* d_out, unsigned flags);
+
 extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
                                   unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
                                   const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
                                   const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
                                   int out_field, void* d_out, unsigned flags) {
+    if (!ctx) return fail(MS_ERR_INVALID, "ms_eval_program: null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MSCHK(eval_locked(ctx, h_prog, ninstr, h_consts, nconst_words, log_n, lde_step, h_domain_offset, d_x_lde, d_base_cols, nbase, d_ext_cols, next,
+                      d_periodic, periodic_len, nperiodic, out_field, d_out, flags));
+    // MS_EVAL_SELFCHECK=1 (tests, bug hunts): the five rewriting passes and the specialised kernels must not change a single output word --
+    // the ORIGINAL program runs once more on the plain interpreter and every word is compared (blocks; two downloads of the result)
+    static const bool selfcheck = getenv("MS_EVAL_SELFCHECK") && strcmp(getenv("MS_EVAL_SELFCHECK"), "0");
+    if (selfcheck && !(flags & MS_EVAL_PLAIN)) {
+        const size_t bytes = ((size_t)1 << log_n) * ms_field_bytes(out_field);
+        LockedPoolGuard pooled(ctx);
+        void* plain = nullptr;
+        MSCHK(pooled.alloc(bytes, &plain));
+        MSCHK(eval_locked(ctx, h_prog, ninstr, h_consts, nconst_words, log_n, lde_step, h_domain_offset, d_x_lde, d_base_cols, nbase, d_ext_cols, next,
+                          d_periodic, periodic_len, nperiodic, out_field, plain, flags | MS_EVAL_PLAIN));
+        std::vector<uint64_t> a(bytes / 8), b(bytes / 8);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(a.data(), d_out, bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b.data(), plain, bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < a.size(); i++)
+            if (a[i] != b[i]) return fail(MS_ERR_INTERNAL, "constraint evaluation self-check: word %zu of %zu differs between the rewritten program (%016llx) and the "
+                                          "original on the interpreter (%016llx) -- a bug in a rewriting pass or a specialised kernel", i, a.size(), (unsigned long long)a[i], (unsigned long long)b[i]);
+    }
+    return MS_OK;
+}
+
+static int eval_locked(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, const void* h_consts, unsigned nconst_words,
+                       unsigned log_n, unsigned lde_step, const void* h_domain_offset, const void* d_x_lde,
+                       const void* const* d_base_cols, unsigned nbase, const void* const* d_ext_cols, unsigned next,
+                       const void* const* d_periodic, const unsigned* periodic_len, unsigned nperiodic,
+                       int out_field, void* d_out, unsigned flags) {
     using namespace mseval;
-    if (flags & ~(unsigned)MS_EVAL_BIT_REVERSED) return fail(MS_ERR_INVALID, "ms_eval_program_ex: unknown flags 0x%x", flags);
+    if (flags & ~(unsigned)(MS_EVAL_BIT_REVERSED | MS_EVAL_PLAIN)) return fail(MS_ERR_INVALID, "ms_eval_program_ex: unknown flags 0x%x", flags);
+    const bool plain = (flags & MS_EVAL_PLAIN) != 0;           // the program as given: no rewriting pass, no specialised kernel
     if (!ctx || !h_prog || !d_out || (nconst_words && !h_consts)) return fail(MS_ERR_INVALID, "ms_eval_program: null argument");
     if (nbase > (unsigned)MAXCOLS || next > (unsigned)MAXCOLS) return fail(MS_ERR_UNSUPPORTED, "at most %d base and %d extension columns", MAXCOLS, MAXCOLS);
     if (nperiodic > 16u) return fail(MS_ERR_UNSUPPORTED, "at most 16 periodic columns");      // the other slots hold hoisted tables
@@ -77,11 +114,10 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     if (h_domain_offset && !is252) { uint64_t h_m; memcpy(&h_m, h_domain_offset, 8); h = gl::from_mont(h_m); }
     f252::E h252 = f252::one();
     if (h_domain_offset && is252) memcpy(h252.l, h_domain_offset, 32);
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     // ---- rewrite: short-period sub-expressions -> tables, long x^e chains -> twiddle lookups (eval_opt.h)
     SplitProgram split;
-    {
+    if (!plain) {
         split = split_periodic(prog, ninstr, log_n, d_x_lde == nullptr, periodic_len, nperiodic, (unsigned)MAXPERIODIC - nperiodic, PW);
         size_t words = 0;
         for (unsigned w : split.table_words) words += (size_t)w << split.log_period;
@@ -108,7 +144,9 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     // ---- rewrite 3: divisions by x-only denominators -> full-length tables, inverted in batches (eval_opt.h split_inversions)
     const unsigned short_tables = (unsigned)split.table_words.size();
     InvSplit isplit;
-    if (log_n >= 12) isplit = split_inversions(main_prog, main_n, nperiodic + short_tables, (unsigned)MAXPERIODIC - nperiodic - short_tables, PW);
+    // (MS_EVAL_SPLIT_MIN_LOG_N: the exhaustive structural test runs the table passes on 64-point domains)
+    static const unsigned split_min_log_n = getenv("MS_EVAL_SPLIT_MIN_LOG_N") ? (unsigned)atoi(getenv("MS_EVAL_SPLIT_MIN_LOG_N")) : 12u;
+    if (log_n >= split_min_log_n && !plain) isplit = split_inversions(main_prog, main_n, nperiodic + short_tables, (unsigned)MAXPERIODIC - nperiodic - short_tables, PW);
     // ---- rewrite 3b: denominators X - a whose roots differ by a power of the trace generator share one table (eval_shift.h; MS_EVAL_SHARE_TABLES=0: off)
     if (isplit.active && !d_x_lde && isplit.table_words.size() >= 2) {
         static const bool off = getenv("MS_EVAL_SHARE_TABLES") && !strcmp(getenv("MS_EVAL_SHARE_TABLES"), "0");
@@ -148,7 +186,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     Regrouped regrouped;
     {
         static const bool off = getenv("MS_EVAL_REGROUP") && !strcmp(getenv("MS_EVAL_REGROUP"), "0");
-        if (!off) {
+        if (!off && !plain) {
             static const bool force = getenv("MS_EVAL_REGROUP") && !strcmp(getenv("MS_EVAL_REGROUP"), "force");     // the fuzzers: whenever it CAN be applied
             if (is252) regrouped = regroup_sums_of_products<Host252>(main_prog, main_n, consts, force);
             else if (maxq == 0 && out_field != MS_GOLDILOCKS_FQ3) regrouped = regroup_sums_of_products<HostGL>(main_prog, main_n, consts, force);
@@ -197,7 +235,7 @@ extern "C" int ms_eval_program_ex(ms_ctx* ctx, const uint32_t* h_prog, unsigned 
     auto specialised = [&](const Instr* pr, unsigned cnt) -> hipFunction_t {
 #ifndef MS_NO_JIT
         static const bool off = getenv("MS_EVAL_JIT") && !strcmp(getenv("MS_EVAL_JIT"), "0");
-        if (off) return nullptr;
+        if (off || plain) return nullptr;
         const std::string src = jit_source(pr, cnt, is252, maxp, maxq);
         if (const char* dump = getenv("MS_EVAL_DUMP")) { if (FILE* f = fopen(dump, "a")) { fputs(src.c_str(), f); fputs("\n// ----\n", f); fclose(f); } }
         const std::string& key = src;
