@@ -9,6 +9,11 @@
  *   - All field data is the reference's in-memory format, untouched at the
  *     boundary: Montgomery residues, little-endian u64 limbs
  *     (Fp = 1 limb, R = 2^64; Fq3 = 3 consecutive Fp; Fp252 = 4 limbs, R = 2^256).
+ *     Every element handed in -- columns, constants, challenges, offsets -- must be
+ *     CANONICAL (< p), as every value of the reference's field types is (ark-ff keeps
+ *     residues reduced): the kernels' unreduced accumulators are sized for canonical
+ *     operands, a word in [p, 2^64) or a 252-bit value in [p, 2^256) gives a wrong
+ *     (not a rejected) result.  Every element handed back is canonical.
  *   - `void* d_*` are DEVICE pointers (hipMalloc / ms_alloc / a torch tensor's
  *     data_ptr); `const void* h_*` are small HOST constants (one field element).
  *   - Every function returns 0 on success, a negative MS_ERR_* otherwise, and

@@ -45,6 +45,7 @@ struct PassParams {
     unsigned log_r0, log_r1;    // last pass: sizes of the earlier digits (log_r1 = 0 with two passes)
     int scale_in, scale_out, bitrev_out;
 };
+static_assert(sizeof(PassParams) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 
 __device__ __forceinline__ f252::E ldg2(const uint64_t* p, size_t i) {
     const U2* q = (const U2*)p + 2 * i;

@@ -47,6 +47,7 @@ struct Params {
     const uint64_t* c3;        // pass B, T >= 32: [t1][s0] w_T^(t1 s0), t1 < T / 16, s0 < 16, 4 plain copies (between radix 16 and radix T / 16)
     unsigned log_n, log_b, lo_bits;   // n = 2^log_n points per coset, beta = 2^log_b cosets
 };
+static_assert(sizeof(Params) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 
 __device__ __forceinline__ uint64_t twn_pow(const Params& P, uint64_t e) {      // w_n^e = w_N^(beta e), e < n
     e <<= P.log_b;
@@ -107,7 +108,11 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
 // ---- pass A ----------------------------------------------------------------------------------------------------------
 // grid = (L / 64, beta, columns): coefficients src[col][i1 L + i0] -> dst[col][j n + k1 L + i0].  The cosets of a column are
 // adjacent in dispatch order, so its coefficients (read beta times) come from L2 / the Infinity Cache after the first read.
-template <bool STREAM, bool UNI>
+// V = 3 (Fq3 columns, three interleaved words per element): the grid's y extent is 3 beta -- one workgroup per (tile, coset, word plane c);
+// it reads the words 3 i + c of the coefficients (24-byte stride: each line is read by the three planes' workgroups back to back on
+// one XCD, as the cosets are) and writes plane c of the PLANAR scratch column (dst + c N): the same arithmetic, tables and twiddles as
+// for an Fp column, since all three words of an element share its index i.
+template <bool STREAM, bool UNI, int V = 1>
 __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
     const uint64_t* __restrict__ src = P.src[blockIdx.z];
@@ -117,10 +122,17 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     // observed, as for first_pass_tile -- only speed depends on it), so the beta cosets of a tile take CONSECUTIVE slots of one XCD:
     // the first one misses, the others find the lines in that XCD's L2 (or merge with the miss in flight).
     const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
-    const unsigned j = slot & ((1u << P.log_b) - 1);
-    const unsigned bx = ((slot >> P.log_b) << 3) | (lin & 7);
+    unsigned j, bx, plane = 0;
+    if constexpr (V == 1) {
+        j = slot & ((1u << P.log_b) - 1);
+        bx = ((slot >> P.log_b) << 3) | (lin & 7);
+    } else {
+        const unsigned per = (unsigned)V << P.log_b, q = slot / per, jc = slot - q * per;     // wave-uniform: scalar unit
+        j = jc / V; plane = jc - j * V;
+        bx = (q << 3) | (lin & 7);
+    }
     const size_t n = (size_t)1 << P.log_n, L = n >> 8;
-    uint64_t* __restrict__ dst = P.dst[blockIdx.z] + (size_t)j * n;
+    uint64_t* __restrict__ dst = P.dst[blockIdx.z] + (size_t)plane * (n << P.log_b) + (size_t)j * n;
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t i0 = (size_t)bx * TW + lane;
@@ -130,9 +142,9 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     uint64_t x[2][16];
     #pragma unroll
     for (int h = 0; h < 2; h++) {                            // both halves requested before the first network
-        const uint64_t* p = src + i0 + (size_t)(w + 8 * h) * L;
+        const uint64_t* p = src + (i0 + (size_t)(w + 8 * h) * L) * V + plane;
         #pragma unroll
-        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step; }
+        for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step * V; }
     }
     #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -200,14 +212,20 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
 static constexpr int X2P = 65;                               // pitch of the second exchange (words): conflict-free both ways
 // NATURAL (one coset): the output X[k1 + 256 k0] goes to its natural position -- the forward transform of a 2^18-point column in two
 // passes (T = 4; ms_ntt.cpp routes GpuFft there): a workgroup's 64 / T consecutive rows k1 give runs of 64 / T words per k0.
-template <bool STREAM, int T, bool UNI, bool NATURAL = false>
+// V = 3 (Fq3 columns; T <= 16): the source is the PLANAR scratch of lde2_strided_pass<.., 3>, the destination the interleaved column.  The
+// lane groups that are rows for an Fp column (rs = lane >> log T, 64 / T of them) become (row, word plane): rs = 4 row + plane, plane 3
+// idle -- 16 / T rows x 3 planes per workgroup, three quarters of the lanes at work -- so that the three words of every element a
+// workgroup produces meet in its LDS and leave as whole runs of 48 T consecutive words: no partial line is ever stored.
+template <bool STREAM, int T, bool UNI, bool NATURAL = false, int V = 1>
 __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     static_assert(!NATURAL || T <= 4, "natural-order stores: runs of 64 / T words, T = 2 or 4");
+    static_assert(V == 1 || (V == 3 && T <= 16 && !NATURAL), "Fq3 columns: rows of at most 4096 elements, bit-reversed order");
     constexpr int LOGT = T == 64 ? 6 : T == 32 ? 5 : T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
     constexpr int RSEL = 64 / T;                             // rows per workgroup
     constexpr int T1 = T > 16 ? T / 16 : 1, LOGT1 = T1 == 4 ? 2 : T1 == 2 ? 1 : 0;     // T >= 32: radix T = 16 x T1
     constexpr int ITEMP = 16 * T1 + 1;                       // T >= 32: pitch (words) of a (k, row) item in the third exchange
-    constexpr int X3WORDS = 8192 + 8192 / 16;               // third exchange: the 8192 words of a round, one pad word per 16
+    constexpr int X3WORDS = 8192 + 8192 / 16;               // third exchange: the 8192 words of a round, one pad word per 16 (V = 3: + 11 per plane,
+                                                             // inside the slots of the idle fourth plane)
     constexpr int XCHW = X3WORDS > 128 * X2P ? X3WORDS : 128 * X2P;
     // The second half of the first network's outputs (x[h][8..15], 32 registers) waits in registers through all of round 0; NSP of those
     // words per lane wait in the tail of the LDS buffer instead (80 KiB per workgroup: still two per CU) -- with them in registers the
@@ -221,10 +239,14 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned rs = lane >> LOGT, t = lane & (T - 1);
-    const unsigned row0 = blockIdx.x * RSEL;
-    const uint64_t* __restrict__ src = P.src[blockIdx.y] + (size_t)j * n + (size_t)(row0 + rs) * L + t;
+    constexpr int RW = V == 3 ? RSEL / 4 : RSEL;             // rows of the transform per workgroup
+    // the row (within the workgroup) and the word plane of lane group g; the idle fourth plane reads plane 0 again and stores nothing
+    auto row_of = [](unsigned g) { return V == 3 ? g >> 2 : g; };
+    const unsigned row0 = blockIdx.x * RW, my_row = row0 + row_of(rs);
+    const unsigned my_plane = V == 3 ? ((rs & 3) == 3 ? 0 : (rs & 3)) : 0;
+    const uint64_t* __restrict__ src = P.src[blockIdx.y] + (size_t)my_plane * (n << P.log_b) + (size_t)j * n + (size_t)my_row * L + t;
     const unsigned jr = P.log_b ? __brev(j) >> (32 - P.log_b) : 0;     // block of coset j in the bit-reversed order
-    uint64_t* __restrict__ dst = P.dst[blockIdx.y] + (size_t)jr * n;
+    uint64_t* __restrict__ dst = P.dst[blockIdx.y] + (size_t)jr * n * V;
 
     // UNI: the part of pass A's factor that is per lane there, (G_j w_n^k1)^(i0 & 63), is one value per lane and half here
     // (k1 = this lane's row; i0 & 63 = ((b & (64 / T - 1)) T + t, b = w + 8 h): the 128-bit product replaces the conversion
@@ -233,7 +255,7 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
         static_assert(!UNI || T >= 4, "i0 & 63 must not reach the register digit a");
         #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const unsigned tl = ((w + 8 * h) & (64 / T - 1)) * T + t, k1 = row0 + rs;
+            const unsigned tl = ((w + 8 * h) & (64 / T - 1)) * T + t, k1 = my_row;
             qm[h] = gld::mmul(twn_pow(P, (uint64_t)k1 * tl), P.aux[(size_t)j * L + tl]);
         }
     }
@@ -337,10 +359,12 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
                 #pragma unroll
                 for (int bit = 0; bit < LOGT; bit++) rt |= ((tt >> bit) & 1u) << (LOGT - 1 - bit);
                 const unsigned ad = chunk * T + rt;
-                xch[ad + (ad >> 4)] = out[u][tt];
+                if (V == 3 && (rsel & 3) == 3) continue;      // the idle plane: its slots take the overhang of plane 2's bank offset
+                xch[ad + (ad >> 4) + (V == 3 ? 11 * (rsel & 3) : 0)] = out[u][tt];      // (V = 3: the planes of an element on different banks)
             }
         }
         __syncthreads();
+        if constexpr (V == 1) {
         // stores: row rev8(k1); inside the row, run (r + 2 x) of 16 T words = chunks c = 0..15 of T words
         #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -348,6 +372,41 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
             const unsigned tt = idx & (T - 1), c = (idx >> LOGT) & 15, xq = (idx >> (LOGT + 4)) & 7, rsel = idx >> (LOGT + 7);
             const unsigned k1 = row0 + rsel;
             NTT2_ST(dst + ((size_t)(__brev(k1) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + c * T + tt), (uint64_t)xch[idx + (idx >> 4)], 2);
+        }
+        } else {
+        // Fq3 stores: the run (row, x) of 16 T elements = 48 T consecutive words, the three planes of an element side by side.  A wave takes
+        // four segments of 64 elements = 192 words (three store instructions of 64 consecutive words each): which element of the segment
+        // and which plane a lane carries in instruction m is the same for every segment ((64 m + lane) / 3 and the remainder), so an
+        // address is a wave-uniform base plus one of three per-lane constants -- no division in the loop.
+        {
+            unsigned eo[3], lds_off[3];
+            #pragma unroll
+            for (int m = 0; m < 3; m++) {
+                const unsigned wd = 64 * m + lane, el = wd / 3, plane = wd - 3 * el;          // element of the segment (< 64), word of the element
+                eo[m] = el;
+                const unsigned lo = plane * (128 * T) + (16 * T >= 64 ? el : 0);               // T = 2: the element's share is added per segment
+                lds_off[m] = lo + (lo >> 4) + 11 * plane;
+            }
+            #pragma unroll
+            for (int sgi = 0; sgi < 4; sgi++) {
+                const unsigned sg = w * 4 + sgi;                                               // elements 64 sg .. 64 sg + 63 of the round: wave-uniform
+                #pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    if constexpr (16 * T >= 64) {
+                        const unsigned el0 = 64 * sg, e0 = el0 & (16 * T - 1), xq = (el0 >> (LOGT + 4)) & 7, rw = el0 >> (LOGT + 7);   // scalar unit
+                        const unsigned ad0 = ((rw * 4) * 8 + xq) * 16 * T + e0;                                                           // a multiple of 64
+                        const size_t g0 = ((size_t)(__brev(row0 + rw) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + e0) * 3;
+                        NTT2_ST(dst + g0 + 64 * m + lane, (uint64_t)xch[ad0 + (ad0 >> 4) + lds_off[m]], 2);
+                    } else {                                                                   // T = 2: a segment spans two runs of 32 elements
+                        const unsigned el = 64 * sg + eo[m], e = el & (16 * T - 1), xq = (el >> (LOGT + 4)) & 7, rw = el >> (LOGT + 7);
+                        const unsigned ad0 = ((rw * 4) * 8 + xq) * 16 * T + e;
+                        const unsigned wd = 64 * m + lane, plane = wd - 3 * eo[m];
+                        const size_t g = ((size_t)(__brev(row0 + rw) >> 24) * L + (size_t)(r + 2 * xq) * (16 * T) + e) * 3 + plane;
+                        NTT2_ST(dst + g, (uint64_t)xch[ad0 + (ad0 >> 4) + lds_off[m]], 2);
+                    }
+                }
+            }
+        }
         }
         }
         } else {

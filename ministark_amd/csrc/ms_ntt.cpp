@@ -517,7 +517,7 @@ static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst,
 
 // Transform `ncols` columns: src[c] -> dst[c] (may alias).  valid_rows < 256 means the
 // source only holds the first valid_rows/256 of the domain, the rest is implicit zeros.
-static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural);
+static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural, unsigned V = 1);
 int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows, bool bitrev_out) {
     if (p->is252) {
         if (valid_rows != 256 || bitrev_out) return fail(MS_ERR_INVALID, "internal: Fp252 zero extension / fused bit reversal go through plan_run252_tiled");
@@ -729,8 +729,13 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
 #ifndef MS_LDE2_MAX_LOG_N            // (a build with -DMS_LDE2_MAX_LOG_N=20 is the round-3 dispatch, for before / after timings)
 #define MS_LDE2_MAX_LOG_N 22
 #endif
+// Fq3 columns (V = 3, round 6): 2^18..2^20 rows (rows of pass B: at most 4096 elements -- the three word planes of a row share a workgroup;
+// at 2^17 rows the (256, 2, 256) plan is the faster one: 0.37 against 0.49 ms for 9 columns at blow-up 8, profiles/r06_lde_fq3_probe.txt).
 static bool lde2_applicable(const ms_ntt_plan* fwd, unsigned V, unsigned log_n, unsigned log_b) {
-    return V == 1 && log_n >= 17 && log_n <= MS_LDE2_MAX_LOG_N && log_b >= 1 && log_b <= 6 && !fwd->small && fwd->d_wr4[0] != nullptr;
+    static const bool fq3_off = getenv("MS_LDE2_FQ3") && !strcmp(getenv("MS_LDE2_FQ3"), "0");      // (before / after timings, tests of the three-pass route)
+    static const bool fq3_all = getenv("MS_LDE2_FQ3") && !strcmp(getenv("MS_LDE2_FQ3"), "all");    // (the tests reach the T = 2 instantiation)
+    if (V == 3 && (fq3_off || log_n > 20 || (log_n < 18 && !fq3_all))) return false;
+    return (V == 1 || V == 3) && log_n >= 17 && log_n <= MS_LDE2_MAX_LOG_N && log_b >= 1 && log_b <= 6 && !fwd->small && fwd->d_wr4[0] != nullptr;
 }
 static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_plan::Lde2** out) {
     for (auto& l : fwd->lde2) if (l.log_b == log_b) { *out = &l; return MS_OK; }
@@ -803,13 +808,15 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
 }
 // coefficients (2^log_n words per column, src) -> bit-reversed evaluations on the coset of N points (dst, N words per column)
 // natural (log_b = 0, 2^17 / 2^18 points): the one coset's transform in natural order -- the forward NTT of the column in two passes
-static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural) {
+// V = 3: Fq3 columns -- interleaved coefficients in, PLANAR scratch between the passes, interleaved evaluations out (lde2_kernels.h)
+static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural, unsigned V) {
     ms_ctx* ctx = fwd->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
     ms_ntt_plan::Lde2* tb = nullptr;
     MSCHK(lde2_tables(fwd, log_n, log_b, &tb));
-    const size_t n = (size_t)1 << log_n, N = n << log_b, col_bytes = N * 8;
+    const size_t n = (size_t)1 << log_n, N = n << log_b, col_bytes = N * 8 * V;
+    if (V == 3 && natural) return fail(MS_ERR_INVALID, "internal: natural-order two-pass transform is an Fp plan");
     const unsigned T = (unsigned)(n >> 16);
     unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
     group = std::min(group, ncols);
@@ -825,8 +832,13 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
         P.tw_lo = fwd->d_tw_lo; P.tw_hi = fwd->d_tw_hi; P.lo_bits = fwd->lo_bits; P.log_n = log_n; P.log_b = log_b;
         for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)src[c0 + c]; P.dst[c] = (uint64_t*)((char*)scratch + (size_t)c * col_bytes); }
         {
-            ProfScope ps(ctx, "lde2_pass_a", (double)(n * 8 + col_bytes) * nc);
-            const dim3 ga((unsigned)(n >> 14), 1u << log_b, nc);
+            ProfScope ps(ctx, "lde2_pass_a", (double)(n * 8 * V + col_bytes) * nc);
+            const dim3 ga((unsigned)(n >> 14), V << log_b, nc);
+            if (V == 3) {
+                if (!uni) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, false, 3>), ga, dim3(msntt2::NT), 0, st, P);       // T = 2
+                else if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, true, 3>), ga, dim3(msntt2::NT), 0, st, P);
+                else hipLaunchKernelGGL((mslde2::lde2_strided_pass<false, true, 3>), ga, dim3(msntt2::NT), 0, st, P);
+            } else
             if (stream_hint) { if (uni) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, true>), ga, dim3(msntt2::NT), 0, st, P);
                                else hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, false>), ga, dim3(msntt2::NT), 0, st, P); }
             else { if (uni) hipLaunchKernelGGL((mslde2::lde2_strided_pass<false, true>), ga, dim3(msntt2::NT), 0, st, P);
@@ -835,9 +847,19 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
         for (unsigned c = 0; c < nc; c++) { P.src[c] = (const uint64_t*)((char*)scratch + (size_t)c * col_bytes); P.dst[c] = (uint64_t*)dst[c0 + c]; }
         {
             ProfScope ps(ctx, "lde2_pass_b", 2.0 * col_bytes * nc);
-            const dim3 g(4 * T, nc, 1u << log_b), b(msntt2::NT);
+            const dim3 g(V == 3 ? 16 * T : 4 * T, nc, 1u << log_b), b(msntt2::NT);      // 64 / T rows per workgroup (Fq3: 16 / T rows x 3 planes)
 #define MS_RB(T_, UNI_) do { if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, T_, UNI_>), g, b, 0, st, P); \
                              else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, T_, UNI_>), g, b, 0, st, P); } while (0)
+#define MS_RB3(T_, UNI_) do { if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, T_, UNI_, false, 3>), g, b, 0, st, P); \
+                              else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, T_, UNI_, false, 3>), g, b, 0, st, P); } while (0)
+            if (V == 3) {
+                switch (T) {
+                case 16: MS_RB3(16, true); break;
+                case 8: MS_RB3(8, true); break;
+                case 4: MS_RB3(4, true); break;
+                default: MS_RB3(2, false); break;
+                }
+            } else
             if (natural) {
                 if (T != 4) return fail(MS_ERR_INVALID, "internal: natural-order two-pass transform is the 2^18-point plan");
                 if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 4, true, true>), g, b, 0, st, P);
@@ -852,6 +874,7 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
             default: MS_RB(2, false); break;
             }
 #undef MS_RB
+#undef MS_RB3
         }
     }
     HIPCHK(hipGetLastError());
@@ -980,7 +1003,7 @@ extern "C" int ms_lde(ms_ctx* ctx, int field, unsigned log_n, unsigned log_blowu
         const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
         if (rc == MS_OK && lde2_applicable(fwd, V, log_n, log_blowup)) {
             // beta coset transforms of size n in two passes each, blocks land in the bit-reversed order
-            rc = lde2_run(fwd, log_n, log_blowup, (const void* const*)d_out, d_out, ncols, false);
+            rc = lde2_run(fwd, log_n, log_blowup, (const void* const*)d_out, d_out, ncols, false, V);
             if (rc == MS_OK && !bit_reversed) rc = bit_reverse_run(ctx, V, log_N, (const void* const*)d_out, d_out, ncols);
             return rc;
         }
@@ -1028,7 +1051,7 @@ extern "C" int ms_evaluate(ms_ctx* ctx, int field, unsigned log_n, unsigned log_
         MSCHK(ctx_plan(ctx, V, log_domain, false, h, &fwd));
     }
     if (V != 4 && lde2_applicable(fwd, V, log_n, log_blowup)) {
-        MSCHK(lde2_run(fwd, log_n, log_blowup, d_in, d_out, ncols, false));
+        MSCHK(lde2_run(fwd, log_n, log_blowup, d_in, d_out, ncols, false, V));
         if (!bit_reversed) MSCHK(bit_reverse_run(ctx, V, log_domain, (const void* const*)d_out, d_out, ncols));
         return MS_OK;
     }

@@ -110,6 +110,7 @@ struct Params {
     unsigned xcd_map;          // pass 1: take tiles in the XCD-aware order of first_pass_tile (0 = workgroup b takes tile b)
     DigitField fields[3];
 };
+static_assert(sizeof(Params) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 
 __device__ __forceinline__ uint64_t tw_pow(const Params& P, uint64_t e) {
     uint64_t lo = P.tw_lo[e & ((1u << P.lo_bits) - 1)];

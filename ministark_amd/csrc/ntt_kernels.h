@@ -36,6 +36,10 @@ namespace msntt {
 
 static constexpr int MAXC = 256;       // columns per launch (grid.y): small columns need many per launch to fill the workgroup slots (round 5: 128 -> 256,
                                        // 4 KiB of pointers in the kernel arguments: 2^15 x 256 columns 0.19 -> 0.245 of HBM, 2^14 x 256 0.11 -> 0.19)
+// Every kernel takes its column pointers BY VALUE (2 x MAXC pointers = 4 KiB + the tables): the structs stay below this bound, checked
+// where each is defined.  HSA puts no 4 KiB limit on the kernel-argument segment (that is CUDA's); ROCm 7.2 on gfx950 runs 520-column
+// launches (tests/test_ntt_parity.py), and a launch a runtime refuses surfaces through hipGetLastError() as MS_ERR_HIP, never silently.
+static constexpr size_t MAX_KERNARG_BYTES = 6 * 1024;
 static constexpr int TILE = 4096;      // words per workgroup tile
 static constexpr int NT = 256;         // threads per workgroup
 static constexpr int LDS_PAD_CS = 144; // c-stride (words) of the mid-pass exchange layout (half tile + 16)
@@ -63,6 +67,7 @@ struct PassParams {
     DigitField fields[3];
     uint64_t scale_const;      // last pass, inverse & offset==1: n^-1 (plain)
 };
+static_assert(sizeof(PassParams) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 
 // w_n^e for e < n via the two-level table
 __device__ __forceinline__ uint64_t tw_pow(const PassParams& P, uint64_t e) {
@@ -310,6 +315,7 @@ struct SmallParams {
     unsigned log_n;
     unsigned V;
 };
+static_assert(sizeof(SmallParams) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 static __global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
     __shared__ uint64_t lds[2048];
     const uint64_t* __restrict__ src = P.src[blockIdx.y];
@@ -354,6 +360,7 @@ struct BitrevParams {
     uint64_t* dst[MAXC];
     unsigned log_n;
 };
+static_assert(sizeof(BitrevParams) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 template <int V>
 __global__ void __launch_bounds__(NT) bit_reverse_tiled(BitrevParams P) {
     __shared__ uint64_t tile[2][32 * 33 * V];

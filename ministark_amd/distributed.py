@@ -256,7 +256,8 @@ def _sharded_root(planner, comm, tree, hash):
 
 
 def _collect(planner, comm, buf, nbytes_of, root=0):
-    """Device buffers of nbytes_of[rank] bytes on every rank -> on `root` one DeviceBytes holding them in rank order (None elsewhere)."""
+    """Device buffers of nbytes_of[rank] bytes on every rank -> on `root` one device buffer holding them in rank order (None elsewhere): a new
+    DeviceBytes, or -- with one rank, where there is nothing to collect -- the caller's own `buf` (a DeviceBytes or a GpuVec), not a copy."""
     r, G = comm.rank, comm.world
     if G == 1 and buf is not None:                              # nothing to collect: the caller's buffer is the result
         return buf
@@ -302,18 +303,20 @@ class OpeningBatch:
 
     def __init__(self, planner, comm, root=0):
         self.planner, self.comm, self.root, self.reqs = planner, comm, root, []
-        self.arena, self.used, self.eager = DeviceBytes(planner, self.EAGER_BYTES), 0, True
+        self.arena, self.used, self.eager, self.launched = DeviceBytes(planner, self.EAGER_BYTES), 0, True, 0
 
     def add(self, sizes, run, parse):
         """sizes[q]: bytes rank q contributes; run(ptr): this rank's gathers into ptr .. ptr + sizes[rank]; parse(chunks): chunks[q] = rank q's bytes.
         The gathers are LAUNCHED HERE, behind the previous request's, while the host walks the next request's index lists (they all land
-        in one arena in request order); a batch that outgrows the arena is gathered again as a whole in `execute`."""
+        in one arena in request order).  Once a request does not fit, it and every later one wait for `execute`, which moves what was
+        gathered into a buffer of the full size (one device copy) and launches the rest behind it: every `run` is called exactly once."""
         sizes = list(sizes)
         mine = sizes[self.comm.rank]
         if self.eager and self.used + mine <= self.EAGER_BYTES:
             if mine:
                 run(self.arena.ptr + self.used)
             self.used += mine
+            self.launched = len(self.reqs) + 1
         else:
             self.eager = False
         self.reqs.append((sizes, run, parse))
@@ -325,8 +328,10 @@ class OpeningBatch:
         arena = self.arena
         if not self.eager:
             arena = DeviceBytes(pl, max(8, totals[r]))
-            off = 0
-            for sz, run, _ in self.reqs:
+            if self.used:
+                pl.lib.check(pl.lib.ms_copy(pl.handle, arena.ptr, self.arena.ptr, self.used))
+            off = self.used
+            for sz, run, _ in self.reqs[self.launched:]:
                 if sz[r]:
                     run(arena.ptr + off)
                     off += sz[r]

@@ -19,6 +19,9 @@ def main():
     from ministark_amd import GOLDILOCKS_FP, Matrix, pipeline
     from ministark_amd.distributed import RcclComm, owned_columns, prove_sharded
     pl = backends.planner("emu")
+    if os.environ.get("MS_TEST_EAGER_BYTES"):                 # the openings' batch outgrows its first arena (OpeningBatch.execute's second leg)
+        from ministark_amd import distributed
+        distributed.OpeningBatch.EAGER_BYTES = int(os.environ["MS_TEST_EAGER_BYTES"])
     if kind == "emu":
         from tests.gloo_comm import GlooComm
         comm = GlooComm(pl)

@@ -89,6 +89,14 @@ def test_whole_prover_on_row_shards_gloo(tmp_path, world):
     _run_prove_workers(tmp_path, world, "emu", dict(os.environ))
 
 
+@pytest.mark.parametrize("eager_bytes", [8, 2048])
+def test_openings_that_outgrow_the_first_arena_gloo(tmp_path, eager_bytes):
+    """OpeningBatch with an arena of 8 bytes (nothing fits: every gather waits for `execute`) and of 2 KiB (the first requests are gathered
+    at once, the rest behind them in the full-size buffer): each request's gathers run exactly once, and every Merkle view and opened row
+    still equals the single-device prover's (the second leg had no test)."""
+    _run_prove_workers(tmp_path, 2, "emu", dict(os.environ, MS_TEST_EAGER_BYTES=str(eager_bytes)))
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_whole_prover_on_row_shards_product_exchange(tmp_path, world):
     """the same through the product's communicator entry points (ms_cols_to_rows_alltoall, ms_p2p_batch, ms_allgather_digests) over

@@ -6,6 +6,8 @@ inverse -- bit-exact.  The `emu` variants run the same kernels under the simulat
 tests/emu on CPU (kernel-logic check, not gpu); the `hip` variants are the parity tests
 proper on an MI355X.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,7 @@ from tests import backends
 from ministark_amd import (GOLDILOCKS_FP, GOLDILOCKS_FQ3, GpuFft, GpuIfft, GpuVec, Matrix,
                            Radix2EvaluationDomain)
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
@@ -397,6 +400,41 @@ def test_lde_fq3_emu():
 def test_lde_two_pass_cosets_emu(log_n, log_b, bit_reversed):
     """lde2_kernels.h (columns of 2^17..2^22 rows: beta coset transforms in two passes each), smallest blow-ups."""
     _lde("emu", GOLDILOCKS_FP, log_n, log_b, ncols=2, bit_reversed=bit_reversed)
+
+
+@pytest.mark.parametrize("log_n,log_b,bit_reversed", [(18, 1, True), (18, 2, False), (19, 1, False), (20, 1, True)])
+def test_lde_two_pass_cosets_fq3_emu(log_n, log_b, bit_reversed):
+    """Fq3 columns through the two-pass coset LDE (round 6: lde2_strided_pass<.., 3> reads one word plane of the interleaved coefficients,
+    lde2_rows_pass<.., 3> brings the three planes of a row together in LDS and stores whole interleaved runs), rows of 512 .. 4096 elements
+    (T = 4, 8, 16; T = 2 in the child-process test below), natural and bit-reversed order, the input column preserved."""
+    _lde("emu", GOLDILOCKS_FQ3, log_n, log_b, ncols=2 if log_n < 19 else 1, bit_reversed=bit_reversed)
+
+
+def test_evaluate_two_pass_cosets_fq3_emu():
+    _evaluate("emu", GOLDILOCKS_FQ3, 18, 1, ncols=2)
+
+
+@pytest.mark.parametrize("switch,log_n", [("0", 18), ("all", 17)])
+def test_fq3_lde_route_switch_emu(switch, log_n):
+    """MS_LDE2_FQ3 (read once per process: a child).  "0" sends Fq3 columns down the (256, R, 256) plan again -- the route of 2^21 / 2^22-row
+    extension columns and of before / after timings; "all" takes the two-pass kernels at 2^17 rows too (T = 2: not the default there, the
+    three-pass plan is faster).  The words are the same."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\nfrom tests.test_ntt_parity import _lde\nfrom ministark_amd import GOLDILOCKS_FQ3\n"
+            "_lde('emu', GOLDILOCKS_FQ3, %d, 1, ncols=1)\nprint('ok')\n") % (ROOT, log_n)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, MS_LDE2_FQ3=switch), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,log_b", [(17, 2), (18, 3), (19, 1), (20, 3), (20, 1), (18, 5)])
+def test_lde_two_pass_cosets_fq3_hip(log_n, log_b):
+    """the Fq3 passes at every row length they take by default (T = 4, 8, 16; 2^17 rows: the three-pass plan), blow-ups 2 .. 32"""
+    _lde("hip", GOLDILOCKS_FQ3, log_n, log_b, ncols=3)
+    _lde("hip", GOLDILOCKS_FQ3, log_n, log_b, ncols=1, bit_reversed=False)
+    if log_b == 1:
+        _evaluate("hip", GOLDILOCKS_FQ3, log_n, log_b, ncols=2)
 
 
 @pytest.mark.gpu
