@@ -31,9 +31,14 @@ static inline std::string jit_source(const Instr* prog, unsigned ninstr, bool is
     std::string s;
     s.reserve(4096 + (size_t)ninstr * 64);
     s += "#include \"eval_kernels.h\"\nusing namespace mseval;\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(256) ms_eval_jit(EvalParams P) {\n";
+    // (MS_EVAL_JIT_WAVES: a minimum number of waves per SIMD for the generated kernel -- an experiment knob; part of the source, hence of the cache key)
+    const char* waves = getenv("MS_EVAL_JIT_WAVES");
+    s += "extern \"C\" __global__ void __launch_bounds__(256";
+    if (waves && atoi(waves) > 0) { s += ", "; s += std::to_string(atoi(waves)); }
+    s += ") ms_eval_jit(EvalParams P) {\n";
     s += "    using F3 = msstage::Fq3T; using F1 = msstage::FpT; using F4 = msstage::Fp252T;\n";
-    s += "    const size_t R = (size_t)blockIdx.x * 256 + threadIdx.x;\n    if (R >= P.n) return;\n    const size_t i = ev_point(P, R);\n";
+    s += is252 ? "    const size_t R = ev252_pos(P);\n" : "    const size_t R = (size_t)blockIdx.x * 256 + threadIdx.x;\n";
+    s += "    if (R >= P.n) return;\n    const size_t i = ev_point(P, R);\n";
     char b[256];
     for (unsigned r = 0; r < maxp; r++) { snprintf(b, sizeof b, is252 ? "    f252::E p%u;\n" : "    uint64_t p%u;\n", r); s += b; }
     for (unsigned r = 0; r < maxq; r++) { snprintf(b, sizeof b, "    gl::Fq3 q%u;\n", r); s += b; }

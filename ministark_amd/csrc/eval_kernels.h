@@ -130,8 +130,15 @@ __device__ __forceinline__ f252::E ev252_const(const EvalParams& P, uint32_t a) 
 __device__ __forceinline__ f252::E ev252_trace(const EvalParams& P, size_t i, uint32_t col, uint32_t off) { return ev252_load(P.base_cols[col], ev_row(P, i, off)); }
 __device__ __forceinline__ f252::E ev252_periodic(const EvalParams& P, size_t i, uint32_t id) { return ev252_load(P.periodic[id], i % P.periodic_len[id]); }
 __device__ __forceinline__ f252::E ev252_table(const EvalParams& P, size_t R, size_t i, uint32_t id, uint32_t off) { return ev252_load(P.periodic[id], off ? ev_row(P, i, off) : R); }
-__device__ __forceinline__ void ev252_store(const EvalParams& P, size_t i, uint32_t slot, const f252::E& v) {
-    msstage::Fp252T::store(slot ? (uint64_t*)P.periodic[slot - 1] : P.out, i, v);
+// The launch position of a lane of the 252-bit kernels (blocks of 256): the wave's 64 positions in gld::wave_elem order, so that the
+// result leaves in whole contiguous stores (Fp252T::store_wave); domains below one wave keep the plain order and the plain store.
+__device__ __forceinline__ size_t ev252_pos(const EvalParams& P) {
+    return (size_t)blockIdx.x * 256 + (P.n >= 64 ? gld::wave_elem(threadIdx.x) : threadIdx.x);
+}
+__device__ __forceinline__ void ev252_store(const EvalParams& P, size_t R, uint32_t slot, const f252::E& v) {
+    uint64_t* dst = slot ? (uint64_t*)P.periodic[slot - 1] : P.out;
+    if (P.n >= 64) msstage::Fp252T::store_wave(dst, R, v);
+    else msstage::Fp252T::store(dst, R, v);
 }
 
 // ---- unreduced sums of products (eval_regroup.h) ---------------------------------------------------------------------------
@@ -283,7 +290,8 @@ __global__ void __launch_bounds__(NT) eval_program(EvalParams P) {
 template <int NP>
 __global__ void __launch_bounds__(NT) eval_program252(EvalParams P) {
     using F = msstage::Fp252T;
-    const size_t R = (size_t)blockIdx.x * NT + threadIdx.x;
+    static_assert(NT == 256, "ev252_pos");
+    const size_t R = ev252_pos(P);
     if (R >= P.n) return;
     const size_t i = ev_point(P, R);
     f252::E rp[NP];
@@ -346,39 +354,59 @@ __global__ void __launch_bounds__(NT) batch_inverse(uint64_t* t, size_t n) {
 // Two levels for fields whose inverse is very expensive (the 252-bit field: ~92 000 instructions): the products of the lanes'
 // K elements go to a scratch array of n / K entries, that array is inverted by batch_inverse (one Fermat inverse per K * K
 // elements), and a second sweep turns each lane's inverted product back into the K inverses.
+// (252-bit field: the lanes of a wave take their 64 elements in gld::wave_elem order and store with store_wave -- whole contiguous stores;
+// the launches cover n exactly, a multiple of 64 K)
 template <class F, int K>
 __global__ void __launch_bounds__(NT) batch_inverse_up(const uint64_t* t, size_t n, uint64_t* prod) {
     using T = typename F::T;
-    const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;
+    const size_t tid = (size_t)blockIdx.x * NT + (F::V == 4 ? gld::wave_elem(threadIdx.x) : threadIdx.x), stride = (size_t)gridDim.x * NT;
     T acc = F::one();
     #pragma unroll
     for (int j = 0; j < K; j++) {
         const size_t i = tid + (size_t)j * stride;
         if (i < n) { const T v = F::load(t, i); if (!ev_is_zero(v)) acc = F::mul(acc, v); }
     }
-    F::store(prod, tid, acc);                                 // never zero
+    if constexpr (F::V == 4) F::store_wave(prod, tid, acc);
+    else F::store(prod, tid, acc);                            // never zero
+}
+// compile-time loop: f(ic<0>) .. f(ic<N - 1>) (UP) or the reverse.  `#pragma unroll` is not honoured around bodies as large as a 252-bit
+// product; the prefix products pre[] then live in scratch memory -- and scratch stores reach HBM: batch_inverse_down wrote 537 MB and
+// read 797 MB for a 268 MB table (round 6, WRITE_SIZE / FETCH_SIZE).
+template <int N> struct bi_ic { static constexpr int value = N; };
+template <int N, bool UP, class Fn>
+__device__ __forceinline__ void bi_static_for(Fn&& f) {
+    if constexpr (N > 0) {
+        if constexpr (UP) { bi_static_for<N - 1, UP>(f); f(bi_ic<N - 1>{}); }
+        else { f(bi_ic<N - 1>{}); bi_static_for<N - 1, UP>(f); }
+    }
 }
 template <class F, int K>
 __global__ void __launch_bounds__(NT) batch_inverse_down(uint64_t* t, size_t n, const uint64_t* prod_inv) {
     using T = typename F::T;
-    const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;
+    const size_t tid = (size_t)blockIdx.x * NT + (F::V == 4 ? gld::wave_elem(threadIdx.x) : threadIdx.x), stride = (size_t)gridDim.x * NT;
     T pre[K];
     T acc = F::one();
-    #pragma unroll
-    for (int j = 0; j < K; j++) {
+    bi_static_for<K, true>([&](auto J) {
+        constexpr int j = decltype(J)::value;
         const size_t i = tid + (size_t)j * stride;
         pre[j] = acc;
         if (i < n) { const T v = F::load(t, i); if (!ev_is_zero(v)) acc = F::mul(acc, v); }
-    }
+    });
     T inv = F::load(prod_inv, tid);
-    #pragma unroll
-    for (int j = K - 1; j >= 0; j--) {
+    bi_static_for<K, false>([&](auto J) {
+        constexpr int j = decltype(J)::value;
         const size_t i = tid + (size_t)j * stride;
         if (i < n) {
             const T v = F::load(t, i);
-            if (!ev_is_zero(v)) { F::store(t, i, F::mul(inv, pre[j])); inv = F::mul(inv, v); }
+            if constexpr (F::V == 4) {
+                // every lane stores (a zero entry stores the zero it read): the wave writes its 64 elements together (store_wave)
+                const bool z = ev_is_zero(v);
+                const T o = z ? v : F::mul(inv, pre[j]);
+                F::store_wave(t, i, o);
+                if (!z) inv = F::mul(inv, v);
+            } else if (!ev_is_zero(v)) { F::store(t, i, F::mul(inv, pre[j])); inv = F::mul(inv, v); }
         }
-    }
+    });
 }
 
 // ---- the denominators X + c of a Goldilocks program: table AND inversion in one pass (round 5) ---------------------------------------

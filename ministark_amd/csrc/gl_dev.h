@@ -283,4 +283,29 @@ __device__ __forceinline__ void wave_lockstep() { __builtin_amdgcn_wave_barrier(
 inline void wave_lockstep() { __syncthreads(); }
 #endif
 
+// The 64-bit word the neighbouring lane (lane ^ 1) holds: one DPP move per half (quad_perm [1, 0, 3, 2]), no LDS.  Both lanes of the
+// pair must be active.  The simulator has no lock-step lanes: there the exchange goes through a block-wide buffer between two barriers
+// (every live thread of the block calls it the same number of times).
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+__device__ __forceinline__ uint64_t lane_xor1(uint64_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, 0xB1, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), 0xB1, 0xF, 0xF, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+#else
+static inline uint64_t lane_xor1(uint64_t v) {
+    static uint64_t buf[1024];
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    const uint64_t r = buf[threadIdx.x ^ 1];
+    __syncthreads();
+    return r;
+}
+#endif
+
+// Which of its wave's 64 consecutive elements a lane takes when the elements are wider than one store instruction carries (32-byte
+// elements, 16 bytes per lane and instruction): even lanes the first 32 (lane / 2), odd lanes the second 32.  After the lanes of a pair
+// swap halves (lane_xor1) lane l holds bytes 16 l .. 16 l + 15 of the wave's first KiB and of its second: two fully contiguous stores.
+__device__ __forceinline__ unsigned wave_elem(unsigned tid) { return (tid & ~63u) | ((tid & 1u) << 5) | ((tid & 63u) >> 1); }
+
 }  // namespace gld

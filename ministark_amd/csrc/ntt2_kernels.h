@@ -49,26 +49,7 @@ template <class T> MS_HD T nt_load(const T* p) { return *p; }
 template <class T> MS_HD void nt_store(T* p, const T& v) { *p = v; }
 #endif
 }
-// The word of the neighbouring lane (lane ^ 1): one DPP move per 32-bit half (quad_perm [1, 0, 3, 2]), no LDS.  The simulator has no
-// lock-step lanes: there the exchange goes through a block-wide buffer between two barriers (every lane of the block calls it).
-namespace msntt2 {
-#if !defined(MS_EMU)
-__device__ __forceinline__ uint64_t lane_xor1(uint64_t v) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, 0xB1, 0xF, 0xF, true);
-    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), 0xB1, 0xF, 0xF, true);
-    return ((uint64_t)hi << 32) | lo;
-}
-#else
-static inline uint64_t lane_xor1(uint64_t v) {
-    static uint64_t buf[1024];
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    const uint64_t r = buf[threadIdx.x ^ 1];
-    __syncthreads();
-    return r;
-}
-#endif
-}
+namespace msntt2 { using gld::lane_xor1; }      // gl_dev.h: the word of the neighbouring lane (one DPP move per half)
 // STREAM is the kernels' first template parameter: the launcher sets it when data + scratch of a launch exceed the 256 MiB Infinity
 // Cache (ms_ntt.cpp).  Batches that fit stay on the default policy: the next pass finds them in the cache, and the hint costs
 // 2^17 x 64 columns 1.37 -> 1.54 us per column (profiles/r04_c2_sweep_nt_always.json).

@@ -73,6 +73,20 @@ struct Fp252T {
     static constexpr int V = 4;
     static __device__ __forceinline__ T load(const uint64_t* p, size_t i) { return {{p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]}}; }
     static __device__ __forceinline__ void store(uint64_t* p, size_t i, const T& x) { p[4 * i] = x.l[0]; p[4 * i + 1] = x.l[1]; p[4 * i + 2] = x.l[2]; p[4 * i + 3] = x.l[3]; }
+    // The same words when the 64 lanes of a wave hold 64 CONSECUTIVE elements in the order of gld::wave_elem (lane l: element
+    // i = base + wave_elem(l), all lanes active).  A store instruction carries 16 bytes per lane: written straight out, each of an
+    // element's two instructions covers half of every 32 bytes, and partially written 64-byte blocks reach HBM once per instruction --
+    // twice the bytes of the column (round 6, WRITE_SIZE of every 252-bit kernel; a pair of lanes writing one whole element per
+    // instruction, 32 of every 64 bytes, changed nothing).  The lanes of a pair swap halves (one DPP move per register) and every
+    // instruction writes one contiguous KiB.
+    static __device__ __forceinline__ void store_wave(uint64_t* p, size_t i, const T& x) {
+        const unsigned lane = threadIdx.x & 63u;
+        const bool odd = lane & 1u;
+        const uint64_t r0 = gld::lane_xor1(odd ? x.l[0] : x.l[2]), r1 = gld::lane_xor1(odd ? x.l[1] : x.l[3]);   // even lanes give their high half, odd lanes their low half
+        uint64_t* q = p + 4 * (i - gld::wave_elem(lane)) + 2 * lane;
+        q[0] = odd ? r0 : x.l[0]; q[1] = odd ? r1 : x.l[1];           // elements base .. base + 31: words 0, 1 from the even lane, 2, 3 from the odd lane
+        q[128] = odd ? x.l[2] : r0; q[129] = odd ? x.l[3] : r1;       // elements base + 32 .. base + 63
+    }
     static __device__ __forceinline__ T add(const T& a, const T& b) { return f252::add(a, b); }
     static __device__ __forceinline__ T neg(const T& a) { return f252::neg(a); }
     static __device__ __forceinline__ T mul(const T& a, const T& b) { return f252::mul(a, b); }
