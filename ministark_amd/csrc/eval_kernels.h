@@ -141,6 +141,26 @@ __device__ __forceinline__ void ev252_store(const EvalParams& P, size_t R, uint3
     else msstage::Fp252T::store(dst, R, v);
 }
 
+// ---- rows of a column (or full-length table) that a workgroup of the specialised 252-bit kernel reads at SEVERAL row offsets, staged once in
+// LDS (natural layout only).  Why: the kernel holds ~200 registers, two waves per SIMD, and reads column c at row offset 1 long before it reads
+// it at offset 0; by then the lines have left the L2 (32 CUs x 8 waves x 2 KiB per load instruction = the whole 4 MiB between the two) and come
+// from memory again: 4.7 GB fetched for 2.4 GB of columns on configs[3] (iii) (round 6, FETCH_SIZE).  The window of a workgroup is its 256
+// launch positions plus the offsets' reach: elements (R0 + lo + s) mod n, s < W, at stg[4 s ..].
+__device__ __forceinline__ void ev252_stage(uint64_t* stg, const uint64_t* g, size_t R0, int lo, unsigned W, size_t n) {
+    for (unsigned s = threadIdx.x; s < W; s += 256) {
+        const size_t j = (R0 + (size_t)(long long)((int)s + lo)) & (n - 1);
+        const uint4* src = (const uint4*)(g + 4 * j);
+        uint4* dst = (uint4*)(stg + 4 * (size_t)s);
+        const uint4 a = src[0], b = src[1];
+        dst[0] = a; dst[1] = b;
+    }
+}
+__device__ __forceinline__ f252::E ev252_lds(const uint64_t* stg, unsigned s) {
+    const uint4* p = (const uint4*)(stg + 4 * (size_t)s);
+    const uint4 a = p[0], b = p[1];
+    return f252::E{{(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32), (uint64_t)b.z | ((uint64_t)b.w << 32)}};
+}
+
 // ---- unreduced sums of products (eval_regroup.h) ---------------------------------------------------------------------------
 // Goldilocks: the first factor is cut at 32 bits, the second into 22 / 22 / 20-bit limbs; the six partial products (54 bits) go to six
 // 64-bit columns of weights 2^0, 2^22, 2^44, 2^32, 2^54, 2^76 -- six multiply-adds per term and no carry anywhere (1 024 terms fit);
@@ -156,8 +176,15 @@ __device__ __forceinline__ void acc_mac_limbs(Acc6& A, uint64_t c, uint32_t y0, 
     A.s[0] += (uint64_t)c0 * y0; A.s[1] += (uint64_t)c0 * y1; A.s[2] += (uint64_t)c0 * y2;
     A.s[3] += (uint64_t)c1 * y0; A.s[4] += (uint64_t)c1 * y1; A.s[5] += (uint64_t)c1 * y2;
 }
+// a word of the constant pool at a wave-uniform slot: read through the constant address space, so that it is a scalar load wherever the
+// compiler places it (the pool is written by the host before the launch and by nobody during it)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t ev_cword(const uint64_t* consts, uint32_t slot) { return ((const __attribute__((address_space(4))) uint64_t*)consts)[slot]; }
+#else
+__device__ __forceinline__ uint64_t ev_cword(const uint64_t* consts, uint32_t slot) { return consts[slot]; }
+#endif
 __device__ __forceinline__ void acc_macc(Acc6& A, uint64_t v, const uint64_t* consts, uint32_t slot) {     // limbs: y0 | y1 << 32, y2
-    const uint64_t w0 = consts[slot], w1 = consts[slot + 1];
+    const uint64_t w0 = ev_cword(consts, slot), w1 = ev_cword(consts, slot + 1);
     acc_mac_limbs(A, v, (uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1);
 }
 __device__ __forceinline__ void acc_macp(Acc6& A, uint64_t v, uint64_t b) {

@@ -236,7 +236,7 @@ static int eval_locked(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, con
 #ifndef MS_NO_JIT
         static const bool off = getenv("MS_EVAL_JIT") && !strcmp(getenv("MS_EVAL_JIT"), "0");
         if (off || plain) return nullptr;
-        const std::string src = jit_source(pr, cnt, is252, maxp, maxq);
+        const std::string src = jit_source(pr, cnt, is252, maxp, maxq, lde_step);
         if (const char* dump = getenv("MS_EVAL_DUMP")) { if (FILE* f = fopen(dump, "a")) { fputs(src.c_str(), f); fputs("\n// ----\n", f); fclose(f); } }
         const std::string& key = src;
         auto it = ctx->jit_cache.find(key);

@@ -11,7 +11,7 @@
 # gpurun's merge had left in place: hence the stamp (every input must be newer than it), the reduction before any delete,
 # and a non-zero exit when a counter file did not come back.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 OUT=$R/gpurun_out/profiles_raw
@@ -19,7 +19,8 @@ rm -rf $OUT; mkdir -p $OUT
 date +%s.%N > $OUT/RUN_STAMP
 cd $R
 FAIL=0
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py > $OUT/bench.json 2> $OUT/bench.err         # the one line (< 4 KiB) ...
+cp $R/bench_detail.json $OUT/bench_detail.json                # ... and the full record it summarises (round 6)
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o ntt --output-format csv -- python bench.py --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
 PM="python bench.py --steps 2 --warmup 1 --cols 2 --no-cpu-baseline --no-extras --settle 0.3"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o ntt --output-format csv -- $PM > $OUT/pmc_fetch.log 2>&1
@@ -34,6 +35,7 @@ python scripts/c2_sweep.py --all > $OUT/c2_sweep.json 2>/dev/null; python script
 python scripts/c2_sweep.py --small > $OUT/c2_sweep_small.json 2>/dev/null
 NCOLS=32 ./scripts/sq_probe.sh lde python scripts/lde_probe.py > /dev/null 2>&1; cp $R/gpurun_out/sq_lde.txt $OUT/lde_sq_counters.txt || FAIL=1
 python bench.py --mode lde-commit --steps 3 --warmup 1 > $OUT/bench_lde_commit_n1.json 2>/dev/null
+{ FQ3=1 LOGN=20 LOGB=3 NCOLS=4 python scripts/lde_probe.py; MS_LDE2_FQ3=0 FQ3=1 LOGN=20 LOGB=3 NCOLS=4 python scripts/lde_probe.py; LOGN=22 LOGB=2 NCOLS=8 python scripts/lde_probe.py; } > $OUT/summary_lde_probe.txt 2>/dev/null
 python scripts/bench_commit.py 23 32 3 > $OUT/bench_commit.json 2>&1
 # reduce on this box, from this run's files only
 python scripts/summarise_profiles.py $TAG --raw $OUT --out $OUT/summary || FAIL=1

@@ -105,7 +105,7 @@ for name, dst in (("pmc_sq", "ntt_sq_counters"), ("pmc_sha", "sha256_sq_counters
                     w.writerow([k, len(vals), cn, sum(vals) / len(vals)])
 for src, dst in (("c2_sweep.json", f"{tag}_c2_sweep.json"), ("c2_sweep_small.json", f"{tag}_c2_sweep_small.json"), ("lde_sq_counters.txt", f"{tag}_lde_sq_counters.txt"),
                  ("bench_lde_commit_n1.json", f"{tag}_bench_lde_commit_n1.json"),
-                 ("bench.json", f"{tag}_bench_ntt_2_24.json"), ("bench_configs.jsonl", f"{tag}_bench_configs.jsonl"), ("bench_commit.json", f"{tag}_bench_commit.json")):
+                 ("bench.json", f"{tag}_bench_line.json"), ("bench_detail.json", f"{tag}_bench_detail.json"), ("bench_configs.jsonl", f"{tag}_bench_configs.jsonl"), ("bench_commit.json", f"{tag}_bench_commit.json")):
     p = os.path.join(RAW, src)
     if os.path.exists(p) and os.path.getsize(p) and fresh(p, src):
         shutil.copy(p, os.path.join(PROF, dst))

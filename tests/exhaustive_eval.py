@@ -22,7 +22,9 @@ import os
 import sys
 import time
 
-os.environ.setdefault("OMP_NUM_THREADS", "1")            # 64-point evaluations: the oracle's thread pool would cost 100 x the work
+# 64-point evaluations: the oracle's thread pool would cost 100 x the work -- and eight of these processes side by side, each with eight
+# spinning OpenMP threads, take minutes instead of seconds (the test suite's environment may carry an OMP_NUM_THREADS of its own)
+os.environ["OMP_NUM_THREADS"] = os.environ.get("MS_EXHAUSTIVE_OMP_THREADS", "1")
 os.environ.setdefault("MS_EVAL_SELFCHECK", "1")
 os.environ.setdefault("MS_EVAL_SPLIT_MIN_LOG_N", "6")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

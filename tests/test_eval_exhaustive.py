@@ -57,5 +57,5 @@ def test_small_universe_through_the_specialised_kernels_hip(leaves):
     """2^16 points: every program of the two-node universe is compiled by hiprtc and runs as a specialised kernel; the self-check compares
     it with the interpreter on the original program, the oracle checks all 65536 outputs (the generated source of every opcode the rewriting
     passes emit -- csrc/eval_jit.h -- is exercised here)."""
-    rc, out = _run(["--nodes", "2", "--ops", "add,mul,div", "--leaves", leaves, "--backend", "hip", "--log-n", "16"], {"OMP_NUM_THREADS": "8"})
+    rc, out = _run(["--nodes", "2", "--ops", "add,mul,div", "--leaves", leaves, "--backend", "hip", "--log-n", "16"], {"MS_EXHAUSTIVE_OMP_THREADS": "8"})
     assert rc == 0 and "exhaustive_eval ok: 336 programs" in out, out
