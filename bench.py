@@ -124,6 +124,9 @@ def compact_line(d):
         "c4_ii_frac": _g(d, "constraint_eval", "mixed_17fp_9fq3", "roofline", "frac"),
         "c4_iii_frac": _g(d, "constraint_eval", "fib_air_fp252", "roofline", "frac"),
         "c4_iii_traffic_x": _g(d, "constraint_eval", "fib_air_fp252", "roofline", "traffic_over_algorithmic"),
+        "c4_all_outputs_equal_oracle": (all(_g(d, "constraint_eval", k, "cpu_baseline", "matches_device") is True for k in ("fib_air_fp", "mixed_17fp_9fq3", "fib_air_fp252"))
+                                        if _g(d, "constraint_eval", "fib_air_fp", "cpu_baseline") else None),
+        "lde_commit_root_equals_oracle": _g(d, "lde_commit", "cpu_baseline", "root_matches"),
         "prove_ms": _g(d, "prove", "prove_ms"),
         "prove_kernel_ms": _g(d, "prove", "kernel_ms"),
         "prove_native_ms": _g(d, "prove", "native_host", "prove_ms"),

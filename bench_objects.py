@@ -558,10 +558,10 @@ def bench_constraint_eval(pl, with_cpu, pmc=None):
                   gl_cols(8), [], rng.integers(1, P, size=(nch, 1), dtype=np.uint64), 8 * 8 + 8, "goldilocks", log_n))
     comp, nch = pipeline.mixed_air_constraints()
     cases.append(("mixed_17fp_9fq3", "(ii) 17 Fp + 9 Fq3 columns (examples/brainfuck/air.rs:26-27 shape), lde_step 2", comp, 2, 7, GOLDILOCKS_FP, True,
-                  gl_cols(17), gl_cols(9, 3), rng.integers(1, P, size=(nch, 3), dtype=np.uint64), 17 * 8 + 9 * 24 + 24, "goldilocks", log_n - 2))
+                  gl_cols(17), gl_cols(9, 3), rng.integers(1, P, size=(nch, 3), dtype=np.uint64), 17 * 8 + 9 * 24 + 24, "goldilocks", log_n))
     comp, _, nch = pipeline.fib_constraints(n >> 2, 8, STARK252_FP)
     cases.append(("fib_air_fp252", "(iii) the fib AIR over the 252-bit field (src/eval_gpu.rs:1054-1082), 8 columns, lde_step 4", comp, 4, 3, STARK252_FP, False,
-                  f252_cols(8), [], rng.integers(0, 1 << 59, size=(nch, 4), dtype=np.uint64), 8 * 32 + 32, "f252", log_n - 2))
+                  f252_cols(8), [], rng.integers(0, 1 << 59, size=(nch, 4), dtype=np.uint64), 8 * 32 + 32, "f252", log_n))        # (the whole domain since round 6: 11 s of host time, and every output word compared)
     for key, what, comp, lde_step, offset, field, fq_ext, base, ext, ch, bytes_per_point, oracle_field, cpu_log in cases:
         prog = E.compile_expr(comp, len(base), fq_ext, field)
         dbase = [GpuVec.from_numpy(pl, c, field) for c in base]

@@ -8,12 +8,16 @@
 //   key        SHA-256 over: format tag, compiler options, hiprtc version, every embedded header (name + text = the library's own
 //              device sources, so a rebuilt library with different kernels never reads an old entry), the generated source
 //   file       <key>.co = "MSJITCO1" | u64 payload bytes | SHA-256(payload) | payload; written to a temporary name and renamed
+//   size       an entry is 20 .. 90 KB (one per distinct generated source: per AIR and launch shape, not per proof); nothing is evicted --
+//              remove the directory to start over
 //   reading    magic, size and digest are checked; an entry that fails any of them (truncated, corrupted, foreign) is removed
 //              and the program is compiled again -- a cache entry can make a run faster, never different
 #pragma once
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
