@@ -160,3 +160,49 @@ def test_damaged_cache_entry_never_changes_an_output_word_hip(cache_dir):
     assert stats[2]["damaged_entries"] == stats[0]["kernels_compiled"] == stats[2]["kernels_compiled"]
     assert all(s["compile_failures"] == 0 for s in stats)
     assert stats[1]["load_ms"] < 20.0 * max(1, stats[1]["kernels_from_disk"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bit_reversed", [False, True])
+def test_lds_staging_of_twice_read_columns_252_hip(tmp_path, bit_reversed):
+    """MS_EVAL_STAGE=1 (off by default: fewer HBM fetches, slower) -- the 252-bit specialised kernel stages the columns and the
+    full-length inverse table it reads at several row offsets in LDS once per workgroup (csrc/eval_jit.h, ev252_stage).  A child process
+    (the switch is part of the generated source) evaluates a program with next / previous-row reads and boundary + terminal denominators
+    on 2^16 points, natural layout (staged) and bit-reversed layout (the staged kernel's global-load branch): every word equals the C oracle's,
+    and the domain's wrap-around rows are among the staged ones."""
+    child = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import cref
+from ministark_amd import STARK252_FP, GpuVec, Planner, expr as E
+from ministark_amd.api import Radix2EvaluationDomain
+bitrev = %r
+log_n, lde_step, offset = 16, 4, 3
+n = 1 << log_n
+dom = Radix2EvaluationDomain(n // lde_step, 1, STARK252_FP)
+g = dom.group_gen
+X = E.X()
+c = [lambda o=0, k=k: E.Trace(k, o) for k in range(3)]
+expr = (c[0](1) - c[0]() * c[1](-1) + c[2](2)) / (X - E.Constant(1)) + (c[1]() - c[2](1)) / (X - E.Constant(pow(g, dom.p - 2, dom.p))) + E.Challenge(0) * c[2]() * c[0](1)
+prog = E.compile_expr(expr, 3, False, STARK252_FP)
+def el(k, sd):
+    r = np.random.default_rng(sd)
+    a = r.integers(0, 1 << 63, size=4 * k, dtype=np.uint64)
+    a[3::4] >>= np.uint64(4)
+    return a
+base = [el(n, 900 + k) for k in range(3)]
+ch = el(1, 990).reshape(-1, 4)
+want = cref.eval_expr(expr, log_n, lde_step, offset, base, [], ch, ch[:1], False, field="f252")
+pl = Planner(0)
+cols = [GpuVec.from_numpy(pl, cref.bit_reverse(b, log_n, 4) if bitrev else b, STARK252_FP) for b in base]
+out = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, cols, [], bit_reversed=bitrev).to_numpy()
+if bitrev:
+    want = cref.bit_reverse(want, log_n, 4)
+st = pl.jit_stats()
+print("equal", bool(np.array_equal(out, want)), "compiled", st["kernels_compiled"], "failed", st["compile_failures"])
+''' % (ROOT, bit_reversed)
+    env = dict(os.environ, MS_EVAL_STAGE="1", MS_JIT_CACHE=str(tmp_path / "jit"), MS_EVAL_DUMP=str(tmp_path / "src.hip"))
+    r = subprocess.run([sys.executable, "-c", child], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "equal True" in r.stdout and "failed 0" in r.stdout, r.stdout
+    assert "ev252_stage(" in open(tmp_path / "src.hip").read()           # the staged form was generated, not skipped
