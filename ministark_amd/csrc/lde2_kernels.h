@@ -245,6 +245,10 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     const unsigned row0 = blockIdx.x * RW, my_row = row0 + row_of(rs);
     const unsigned my_plane = V == 3 ? ((rs & 3) == 3 ? 0 : (rs & 3)) : 0;
     const uint64_t* __restrict__ src = P.src[blockIdx.y] + (size_t)my_plane * (n << P.log_b) + (size_t)j * n + (size_t)my_row * L + t;
+    // Fp columns, T <= 16: the same address as a wave-uniform base + a 32-bit lane offset in words (scalar-base loads; counted: 4165 -> 4127 instructions
+    // and no register left in scratch at T = 16; at T = 32 / 64 the 64-bit form is the shorter one)
+    const uint64_t* __restrict__ sbase = P.src[blockIdx.y] + (size_t)j * n + (size_t)row0 * L;
+    const unsigned soff = (V == 3 ? my_plane * (unsigned)(n << P.log_b) : 0u) + row_of(rs) * (unsigned)L + t;
     const unsigned jr = P.log_b ? __brev(j) >> (32 - P.log_b) : 0;     // block of coset j in the bit-reversed order
     uint64_t* __restrict__ dst = P.dst[blockIdx.y] + (size_t)jr * n * V;
 
@@ -262,9 +266,15 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
     uint64_t x[2][16];
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const uint64_t* p = src + (size_t)(w + 8 * h) * T;
-        #pragma unroll
-        for (int a = 0; a < 16; a++) { x[h][a] = NTT2_LD(p, 2); p += 16 * T; }
+        if constexpr (T <= 16 && V == 1) {
+            const unsigned po = soff + (w + 8 * h) * T;
+            #pragma unroll
+            for (int a = 0; a < 16; a++) x[h][a] = NTT2_LD(sbase + (po + a * 16 * T), 2);
+        } else {
+            const uint64_t* p = src + (size_t)(w + 8 * h) * T;
+            #pragma unroll
+            for (int a = 0; a < 16; a++) { x[h][a] = NTT2_LD(p, 2); p += 16 * T; }
+        }
         glimb::Q3 qh{};
         if constexpr (UNI) qh = glimb::q3_from(gld::mmul(qm[h], 1), gld::mmul(qm[h], (uint64_t)1 << 24), gld::mmul(qm[h], (uint64_t)1 << 48));
         net1<UNI ? 2 : 0>(x[h], P, w + 8 * h, nullptr, qh);
@@ -300,7 +310,8 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
                 glimb::W4 wt[2];
                 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const msntt2::Pair* tp = (const msntt2::Pair*)(P.t2 + ((size_t)(ap + 16 * (2 * g + e)) * T + t) * 4);      // two 16-byte loads
+                    const msntt2::Pair* tp = (T <= 16 && V == 1) ? (const msntt2::Pair*)(P.t2 + (((ap + 16 * (2 * g + e)) * T + t) * 4u))
+                                                     : (const msntt2::Pair*)(P.t2 + ((size_t)(ap + 16 * (2 * g + e)) * T + t) * 4);      // two 16-byte loads
                     const msntt2::Pair lo = tp[0], hi = tp[1];
                     wt[e] = glimb::w4_from(lo.x, lo.y, hi.x, hi.y);
                 }
