@@ -158,6 +158,10 @@ int main() {
             const uint64_t want = aa(aa(mm(mm(num, zer), lin), oracle_gl_pow(tr(2, -1), 5)), mm(xi, oracle_gl_to_mont(9)));
             REQUIRE(out[i] == want);
         }
+        // the mirror's view of the kernel cache: nothing may have been left to the interpreter by a failed compilation
+        const ms_jit_stats js = pl.jit_stats();
+        REQUIRE(js.compile_failures == 0);
+        REQUIRE(js.kernels_compiled + js.kernels_from_disk <= 8);
     }
     {   // extension-column scan (examples/brainfuck/trace.rs:131-145): running product with masked rows
         const size_t n = 10000;

@@ -445,3 +445,40 @@ def test_shared_tables_in_a_program_with_extension_columns_emu(capfd, monkeypatc
     got = E.eval(prog, pl, ch, ch[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, cref.bit_reverse(c.copy(), log_n, 1), FP) for c in base],
                  [GpuVec.from_numpy(pl, cref.bit_reverse(c.copy(), log_n, 3), FQ3) for c in ext], bit_reversed=True).to_numpy()
     assert np.array_equal(got, cref.bit_reverse(want.copy(), log_n, 3))
+
+
+def test_plain_flag_gives_the_same_words_emu():
+    """MS_EVAL_PLAIN (flags bit 1 of ms_eval_program_ex): the program exactly as given on the interpreter -- no tables, no shared inverses, no sums
+    of products -- must give the words of the default path (which rewrites this program: a boundary-style and a periodic denominator, a sum of
+    products); the library's MS_EVAL_SELFCHECK compares the same two evaluations internally."""
+    import ctypes
+    pl = backends.planner("emu")
+    log_n, lde_step, n = 12, 2, 1 << 12
+    x = E.X()
+    expr = (E.Trace(0, 1) - E.Trace(0) * E.Trace(1)) / (x ** (n // lde_step) - 1) + (E.Trace(1) - E.Challenge(0)) / (x - 1) + E.Trace(0) * E.Trace(1, -1) * E.Challenge(0)
+    base = [cref.random_elements(n, 640 + c) for c in range(2)]
+    ch = cref.random_elements(1, 650).reshape(-1, 1)
+    prog = E.compile_expr(expr, 2, False)
+    cols = [GpuVec.from_numpy(pl, c, FP) for c in base]
+    want = E.eval(prog, pl, ch, ch[:1], lde_step, 7, n, cols, []).to_numpy()
+    assert np.array_equal(want, cref.eval_expr(expr, log_n, lde_step, 7, base, [], ch, ch[:1], False))
+    consts = np.array(prog.consts, dtype=np.uint64)
+    for idx, off in prog.challenge_slots.items():
+        consts[off] = ch[idx][0]
+    for idx, off in prog.hint_slots.items():
+        consts[off] = ch[idx][0]
+    code = np.array(prog.instrs, dtype=np.uint32).reshape(-1, 4)
+    out = GpuVec(pl, n, FP)
+    off = np.array([E.gl_to_mont(7)], dtype=np.uint64)
+    VP = ctypes.c_void_p
+    arr = (VP * 2)(*[c.ptr for c in cols])
+    none = (VP * 1)()
+    plen = (ctypes.c_uint * 1)()
+    L = pl.lib
+    for flags in (2, 3 & ~1):                                    # MS_EVAL_PLAIN
+        L.check(L.ms_eval_program_ex(pl.handle, code.ctypes.data, len(code), consts.ctypes.data, consts.size, log_n, lde_step, off.ctypes.data, None,
+                                     arr, 2, none, 0, none, plen, 0, FP, out.ptr, flags))
+        pl.sync()
+        assert np.array_equal(out.to_numpy(), want)
+    assert L.ms_eval_program_ex(pl.handle, code.ctypes.data, len(code), consts.ctypes.data, consts.size, log_n, lde_step, off.ctypes.data, None,
+                                arr, 2, none, 0, none, plen, 0, FP, out.ptr, 8) != 0      # unknown flag bits are refused
