@@ -280,6 +280,12 @@ int ms_scan_affine(ms_ctx* ctx, int field, size_t n, const void* d_a, const void
 int ms_gather_rows(ms_ctx* ctx, int field, size_t nrows, const void* const* d_cols, unsigned ncols,
                    const uint64_t* h_positions, size_t npos, void* d_out);
 int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_digests, const uint64_t* h_indices, size_t count, void* d_out);
+/* The same for nseg digest arrays in ONE launch: segment s gathers counts[s] records of d_digests[s] (ndigests[s] records long) into
+ * d_out[s]; h_indices holds the segments' index lists one after another.  The openings of a proof list leaves, siblings and nodes of
+ * every committed tree (two trace trees + one per FRI layer: src/prover.rs:161-173, src/fri.rs:148-165): two dozen gathers of a few
+ * records each, i.e. two dozen launch latencies -- the bindings collect them and call this once. */
+int ms_gather_digests_multi(ms_ctx* ctx, unsigned nseg, const void* const* d_digests, const size_t* ndigests, const uint64_t* h_indices,
+                            const size_t* counts, void* const* d_out);
 
 /* ---- FRI fold: apply_drp (src/fri.rs:526-567) as called by FriProver::build_layer
  * (src/fri.rs:199-231).  d_evals holds 2^log_n elements in bit-reversed order (the layer that

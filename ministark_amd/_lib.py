@@ -79,6 +79,7 @@ class Lib:
             "ms_scan_affine": (i, [vp, i, sz, vp, vp, vp, i, vp]),
             "ms_gather_rows": (i, [vp, i, sz, c_void_pp, u, vp, sz, vp]),
             "ms_gather_digests": (i, [vp, sz, vp, vp, sz, vp]),
+            "ms_gather_digests_multi": (i, [vp, u, c_void_pp, ctypes.POINTER(sz), vp, ctypes.POINTER(sz), c_void_pp]),
             "ms_merkle_view_ids": (i, [sz, vp, sz, vp, vp, vp, vp, vp]),
             "ms_fri_fold": (i, [vp, i, u, u, vp, vp, vp, vp]),
             "ms_fri_fold_rows": (i, [vp, i, u, u, vp, vp, sz, sz, vp, vp]),

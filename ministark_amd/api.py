@@ -202,6 +202,22 @@ class GatherBatch:
         self.planner, self.capacity, self.used = planner, capacity, 0
         self.buf = DeviceBytes(planner, capacity)
         self._host = None
+        self._digest_segments = []                             # (digests ptr, ndigests, index array, output ptr): launched together (flush)
+
+    def defer_digests(self, digests_ptr, ndigests, idx, out_ptr):
+        """a digest gather into a slice of this batch: it joins the ONE launch that `flush` issues (ms_gather_digests_multi)"""
+        self._digest_segments.append((digests_ptr, ndigests, idx, out_ptr))
+
+    def flush(self):
+        """launch the digest gathers collected so far (before the download, or to start them early)"""
+        segs, self._digest_segments = self._digest_segments, []
+        if not segs:
+            return
+        L, n = self.planner.lib, len(segs)
+        VP, SZ = ctypes.c_void_p, ctypes.c_size_t
+        allidx = np.ascontiguousarray(np.concatenate([s[2] for s in segs]), dtype=np.uint64)      # (kept alive through the call)
+        L.check(L.ms_gather_digests_multi(self.planner.handle, n, (VP * n)(*[s[0] for s in segs]), (SZ * n)(*[s[1] for s in segs]),
+                                          allidx.ctypes.data, (SZ * n)(*[len(s[2]) for s in segs]), (VP * n)(*[s[3] for s in segs])))
 
     def reserve(self, nbytes):
         """-> (device pointer, reader) for a slice of nbytes, or None when the batch is full or has already been fetched"""
@@ -218,6 +234,7 @@ class GatherBatch:
     def fetch(self):
         """the used part of the buffer on the host: ONE wait and one copy of `used` bytes (not of the capacity); closes the batch"""
         if self._host is None:
+            self.flush()
             self._host = self.buf.to_numpy(self.used)
         return self._host
 
@@ -240,7 +257,12 @@ def _gather_digests_launch(planner, digests, ndigests, ids, batch=None):
     idx = np.ascontiguousarray(ids, dtype=np.uint64)
     ptr, read, keep = _gather_slot(planner, 32 * len(ids), batch)
     L = planner.lib
-    L.check(L.ms_gather_digests(planner.handle, ndigests, digests.ptr, idx.ctypes.data, len(ids), ptr))
+    if keep is batch and batch is not None:                    # a slice of the batch: one launch for all of the batch's digest gathers
+        if idx.size and int(idx.max()) >= ndigests:
+            raise _lib.MsError(-1, f"digest {int(idx.max())} out of range ({ndigests})")
+        batch.defer_digests(digests.ptr, ndigests, idx, ptr)
+    else:
+        L.check(L.ms_gather_digests(planner.handle, ndigests, digests.ptr, idx.ctypes.data, len(ids), ptr))
 
     def fetch(_keep=keep):
         return np.ascontiguousarray(read()[: 32 * len(ids)]).view("V32").tolist()      # a list of 32-byte `bytes`, built in one C loop

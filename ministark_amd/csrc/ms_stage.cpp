@@ -383,6 +383,37 @@ extern "C" int ms_merkle_view_ids(size_t nleaves, const uint64_t* h_indices, siz
     return MS_OK;
 }
 
+extern "C" int ms_gather_digests_multi(ms_ctx* ctx, unsigned nseg, const void* const* d_digests, const size_t* ndigests, const uint64_t* h_indices,
+                                       const size_t* counts, void* const* d_out) {
+    if (!ctx || (nseg && (!d_digests || !ndigests || !counts || !d_out))) return fail(MS_ERR_INVALID, "ms_gather_digests_multi: null argument");
+    size_t total = 0;
+    for (unsigned s = 0; s < nseg; s++) {
+        if (counts[s] && (!d_digests[s] || !d_out[s])) return fail(MS_ERR_INVALID, "ms_gather_digests_multi: null pointer in segment %u", s);
+        total += counts[s];
+    }
+    if (total && !h_indices) return fail(MS_ERR_INVALID, "ms_gather_digests_multi: null indices");
+    if (total == 0) return MS_OK;
+    std::vector<uint64_t> pairs(2 * total);
+    size_t r = 0;
+    for (unsigned s = 0; s < nseg; s++)
+        for (size_t k = 0; k < counts[s]; k++, r++) {
+            if (h_indices[r] >= ndigests[s]) return fail(MS_ERR_INVALID, "digest %llu out of range (segment %u has %zu)", (unsigned long long)h_indices[r], s, ndigests[s]);
+            pairs[2 * r] = (uint64_t)(uintptr_t)d_digests[s] + 32 * h_indices[r];
+            pairs[2 * r + 1] = (uint64_t)(uintptr_t)d_out[s] + 32 * k;
+        }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    // the list goes to device memory by one stream-ordered copy: read in place from the pinned ring (as the short index lists of the single
+    // gathers are) its ~3 000 records cost a PCIe round trip each -- 45 us for the openings of a proof
+    void* d_pairs = nullptr;
+    LockedPoolGuard pooled(ctx);
+    MSCHK(pooled.alloc(pairs.size() * 8, &d_pairs));
+    MSCHK(stage_upload(ctx, d_pairs, pairs.data(), pairs.size() * 8));
+    { ProfScope ps(ctx, "gather_digests", 64.0 * total);
+      hipLaunchKernelGGL(msscan::copy_records32, dim3(stream_grid(total * 4)), dim3(msscan::NT), 0, ctx->stream, (const uint64_t*)d_pairs, total); }
+    HIPCHK(hipGetLastError());
+    return MS_OK;
+}
 extern "C" int ms_gather_digests(ms_ctx* ctx, size_t ndigests, const void* d_digests, const uint64_t* h_indices, size_t count, void* d_out) {
     if (!ctx || !d_digests || !d_out || (count && !h_indices)) return fail(MS_ERR_INVALID, "ms_gather_digests: null argument");
     for (size_t k = 0; k < count; k++) if (h_indices[k] >= ndigests) return fail(MS_ERR_INVALID, "digest %llu out of range", (unsigned long long)h_indices[k]);

@@ -236,6 +236,17 @@ static __global__ void __launch_bounds__(NT) gather_records(const uint64_t* __re
         out[i] = src[(size_t)idx[i / words] * words + i % words];
 }
 
+// 32-byte records from anywhere to anywhere: pairs[2 r] = address of record r, pairs[2 r + 1] = where it goes (ms_gather_digests_multi builds
+// the list on the host from validated indices: every digest gather of a proof's openings -- two dozen small launches -- in ONE)
+static __global__ void __launch_bounds__(NT) copy_records32(const uint64_t* __restrict__ pairs, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < count * 4; i += (size_t)gridDim.x * NT) {
+        const size_t r = i >> 2;
+        const uint64_t* s = (const uint64_t*)pairs[2 * r];
+        uint64_t* d = (uint64_t*)pairs[2 * r + 1];
+        d[i & 3] = s[i & 3];
+    }
+}
+
 // composition_poly.chunks(k) into k columns (src/prover.rs:113-121): out[c][j] = in[j*k + c].  Lanes run along
 // the interleaved input (coalesced reads; the k output streams are each contiguous per lane group).
 struct DeinterleaveParams {

@@ -182,7 +182,13 @@ def fri_layer_rows_launch(layer, folding_factor, positions, batch=None):
     ids = (np.asarray(positions, dtype=np.uint64)[:, None] * np.uint64(per) + np.arange(per, dtype=np.uint64)).ravel()
     from .api import _gather_slot
     ptr, read, keep = _gather_slot(pl, 32 * len(ids), batch)
-    pl.lib.check(pl.lib.ms_gather_digests(pl.handle, len(layer) * FIELD_WORDS[layer.field] // 4, layer.ptr, ids.ctypes.data, len(ids), ptr))
+    nrec = len(layer) * FIELD_WORDS[layer.field] // 4
+    if keep is batch and batch is not None:                    # a slice of the batch: joins its one launch (GatherBatch.flush)
+        if ids.size and int(ids.max()) >= nrec:
+            raise IndexError(f"row {int(ids.max()) // per} out of range")
+        batch.defer_digests(layer.ptr, nrec, ids, ptr)
+    else:
+        pl.lib.check(pl.lib.ms_gather_digests(pl.handle, nrec, layer.ptr, ids.ctypes.data, len(ids), ptr))
     return lambda _keep=keep: np.array(read()[: 32 * len(ids)]).view(np.uint64).reshape(len(positions), words)
 
 

@@ -43,7 +43,7 @@ def _expect(ctype):
         "void *": "*mut c_void", "const void *": "*const c_void", "void * *": "*mut *mut c_void",
         "void * const *": "*const *mut c_void", "const void * const *": "*const *const c_void",
         "const unsigned *": "*const c_uint", "const uint32_t *": "*const u32", "const uint64_t *": "*const u64", "uint64_t *": "*mut u64",
-        "size_t *": "*mut usize", "char *": "*mut c_char", "unsigned char *": "*mut u8", "int *": "*mut c_int", "ms_xchg_op *": "*mut ms_xchg_op", "const ms_p2p_op *": "*const ms_p2p_op", "ms_jit_stats *": "*mut ms_jit_stats",
+        "size_t *": "*mut usize", "char *": "*mut c_char", "unsigned char *": "*mut u8", "int *": "*mut c_int", "ms_xchg_op *": "*mut ms_xchg_op", "const ms_p2p_op *": "*const ms_p2p_op", "ms_jit_stats *": "*mut ms_jit_stats", "const size_t *": "*const usize",
     }
     return table[t]
 

@@ -210,3 +210,39 @@ def test_index_lists_outlive_the_staging_ring(kind):
     got = np.asarray(m.get_rows(long_pos)).reshape(len(long_pos), ncols)
     for c in range(ncols):
         assert np.array_equal(got[:, c], cols[c][long_pos])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_gather_digests_multi_equals_the_single_gathers(kind):
+    """ms_gather_digests_multi: the digest gathers of several trees in ONE launch (what GatherBatch.flush issues for a proof's openings) give the
+    bytes of one ms_gather_digests per tree; empty segments are allowed; an index past its own segment's array is refused before anything runs."""
+    import ctypes
+    from ministark_amd.api import DeviceBytes
+    pl = backends.planner(kind)
+    L = pl.lib
+    rng = np.random.default_rng(77)
+    sizes = [1 << 10, 1 << 4, 1 << 13, 2]
+    arrays = [rng.integers(0, 256, size=32 * n, dtype=np.uint8) for n in sizes]
+    devs = [DeviceBytes.from_numpy(pl, a) if hasattr(DeviceBytes, "from_numpy") else None for a in arrays]
+    if devs[0] is None:
+        devs = []
+        for a in arrays:
+            d = DeviceBytes(pl, a.size)
+            L.check(L.ms_upload(pl.handle, d.ptr, a.ctypes.data, a.size))
+            devs.append(d)
+    idx = [rng.integers(0, n, size=k, dtype=np.uint64) for n, k in zip(sizes, (37, 0, 100, 5))]
+    outs = [DeviceBytes(pl, max(32, 32 * len(i))) for i in idx]
+    VP, SZ = ctypes.c_void_p, ctypes.c_size_t
+    n = len(sizes)
+    allidx = np.ascontiguousarray(np.concatenate(idx), dtype=np.uint64)
+    L.check(L.ms_gather_digests_multi(pl.handle, n, (VP * n)(*[d.ptr for d in devs]), (SZ * n)(*sizes), allidx.ctypes.data,
+                                      (SZ * n)(*[len(i) for i in idx]), (VP * n)(*[o.ptr for o in outs])))
+    pl.sync()
+    for a, i, o in zip(arrays, idx, outs):
+        want = a.reshape(-1, 32)[i.astype(np.int64)].reshape(-1)
+        assert np.array_equal(o.to_numpy(32 * len(i)), want)
+    bad = allidx.copy()
+    bad[37] = sizes[2]                                            # first index of the third segment (the second is empty): one past its array
+    assert L.ms_gather_digests_multi(pl.handle, n, (VP * n)(*[d.ptr for d in devs]), (SZ * n)(*sizes), bad.ctypes.data,
+                                     (SZ * n)(*[len(i) for i in idx]), (VP * n)(*[o.ptr for o in outs])) != 0
+    assert b"out of range" in L.ms_last_error()
