@@ -79,13 +79,34 @@ public:
         return true;
     }
     void* dev(size_t off) const { return (char*)d_ + off; }
+    bool owns(const void* p) const { return (const char*)p >= (const char*)d_ && (const char*)p < (const char*)d_ + cap_; }
+    // a digest gather into a slice of this arena joins the ONE launch `flush` issues (ms_gather_digests_multi): the openings of a proof
+    // are two dozen gathers of a few records each, i.e. two dozen launch latencies
+    void defer_digests(const void* digests, size_t ndigests, const std::vector<uint64_t>& ids, void* out) {
+        seg_src_.push_back(digests); seg_n_.push_back(ndigests); seg_cnt_.push_back(ids.size()); seg_out_.push_back(out);
+        seg_idx_.insert(seg_idx_.end(), ids.begin(), ids.end());
+    }
+    void flush() {
+        if (seg_src_.empty()) return;
+        check(ms_gather_digests_multi(pl_->ctx(), (unsigned)seg_src_.size(), seg_src_.data(), seg_n_.data(), seg_idx_.data(), seg_cnt_.data(), seg_out_.data()));
+        seg_src_.clear(); seg_n_.clear(); seg_cnt_.clear(); seg_out_.clear(); seg_idx_.clear();
+    }
     const uint8_t* host(size_t off) {                   // waits for the stream and copies on the first call after a reserve
+        flush();
         if (fetched_ < used_) { host_.resize(used_); check(ms_download(pl_->ctx(), host_.data() + fetched_, (const char*)d_ + fetched_, used_ - fetched_)); fetched_ = used_; }
         return host_.data() + off;
     }
 private:
     Planner* pl_; void* d_ = nullptr; size_t cap_, used_ = 0, fetched_ = 0; std::vector<uint8_t> host_;
+    std::vector<const void*> seg_src_; std::vector<size_t> seg_n_, seg_cnt_; std::vector<void*> seg_out_; std::vector<uint64_t> seg_idx_;
 };
+
+// one digest gather: deferred into the arena's single launch when its output is a slice of the arena, launched at once otherwise
+inline void gather_digests_into(Planner& pl, const void* digests, size_t ndigests, const std::vector<uint64_t>& ids, void* out, GatherArena* arena) {
+    if (ids.empty()) return;
+    if (arena && arena->owns(out)) arena->defer_digests(digests, ndigests, ids, out);
+    else check(ms_gather_digests(pl.ctx(), ndigests, digests, ids.data(), ids.size(), out));
+}
 
 // The result of a gather that has been launched but not fetched: an opening launches every gather first and fetches afterwards,
 // so the host waits for the device once instead of once per call (the device runs them back to back on the context's stream).
@@ -350,7 +371,7 @@ private:
     }
     Pending gather_launch(const void* digests, const std::vector<uint64_t>& ids, GatherArena* arena) const {
         Pending out(*pl_, ids.size() * 32, arena);
-        if (!ids.empty()) check(ms_gather_digests(pl_->ctx(), n_, digests, ids.data(), ids.size(), out.ptr()));
+        gather_digests_into(*pl_, digests, n_, ids, out.ptr(), arena);
         return out;
     }
     Planner* pl_; size_t n_; void* leaves_ = nullptr; void* nodes_ = nullptr;

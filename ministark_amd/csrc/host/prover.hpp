@@ -75,7 +75,7 @@ inline Pending fri_layer_rows_launch(const GpuVec<F>& layer, unsigned folding_fa
     const size_t per = words / 4;
     std::vector<uint64_t> ids;
     for (size_t p : positions) for (size_t k = 0; k < per; k++) ids.push_back(p * per + k);
-    check(ms_gather_digests(pl.ctx(), layer.len() * F::words / 4, layer.ptr(), ids.data(), ids.size(), out.ptr()));
+    gather_digests_into(pl, layer.ptr(), layer.len() * F::words / 4, ids, out.ptr(), arena);
     return out;
 }
 template <class F>
