@@ -107,6 +107,11 @@ int ms_ntt_plan_destroy(ms_ntt_plan* plan);
 int ms_ntt_encode(ms_ntt_plan* plan, void* d_column);
 int ms_ntt_execute(ms_ntt_plan* plan);
 int ms_ntt_enqueue(ms_ntt_plan* plan, void* const* d_columns, unsigned ncols);
+/* Out of place, non-blocking: d_dst[c] = transform(d_src[c]); d_src[c] is left untouched (d_dst[c] may be d_src[c]).
+ * Matrix::interpolate / evaluate are `self.clone().into_polynomials / into_evaluations` (src/matrix.rs:155-163, 237-243): this is the clone
+ * and the transform in one -- the first pass reads the source, the last one writes the destination, no copy of the columns is made
+ * (the clones of the trace and of its polynomials were 0.57 GB of device copies per 2^22-row proof). */
+int ms_ntt_enqueue_to(ms_ntt_plan* plan, const void* const* d_src, void* const* d_dst, unsigned ncols);
 
 /* ---- bit reversal: BitReverseGpuStage + bit_reverse (gpu/src/stage.rs:280-332,
  * gpu/src/utils.rs:32-78), Matrix::bit_reverse_rows (src/matrix.rs:352-354).

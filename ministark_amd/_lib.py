@@ -61,6 +61,7 @@ class Lib:
             "ms_ntt_encode": (i, [vp, vp]),
             "ms_ntt_execute": (i, [vp]),
             "ms_ntt_enqueue": (i, [vp, c_void_pp, u]),
+            "ms_ntt_enqueue_to": (i, [vp, c_void_pp, c_void_pp, u]),
             "ms_bit_reverse": (i, [vp, i, u, c_void_pp, u]),
             "ms_lde": (i, [vp, i, u, u, vp, c_void_pp, c_void_pp, u, i]),
             "ms_evaluate": (i, [vp, i, u, u, vp, c_void_pp, c_void_pp, u, i]),

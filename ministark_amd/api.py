@@ -504,6 +504,11 @@ class _FftBase:
         arr = _ptr_array(columns)
         self.planner.lib.check(self.planner.lib.ms_ntt_enqueue(self.handle, arr, len(columns)))
 
+    def enqueue_to(self, src_columns, dst_columns):
+        """Non-blocking, out of place: dst[c] = transform(src[c]), src untouched -- `clone()` + transform without the copy (ms_ntt_enqueue_to)."""
+        assert len(src_columns) == len(dst_columns)
+        self.planner.lib.check(self.planner.lib.ms_ntt_enqueue_to(self.handle, _ptr_array(src_columns), _ptr_array(dst_columns), len(src_columns)))
+
     def close(self):
         if self.handle:
             self.planner.lib.ms_ntt_plan_destroy(self.handle)
@@ -569,8 +574,17 @@ class Matrix:
         ifft.close()
         return self
 
-    def interpolate(self, domain):        # src/matrix.rs:155-163
-        return self.clone().into_polynomials(domain)
+    def _transformed(self, cls, domain):
+        """the columns' transform in NEW columns, this matrix untouched: what `self.clone().into_...` gives, without the device copy"""
+        outs = [GpuVec(self.planner, len(c), self.field) for c in self.columns]
+        plan = cls(domain, self.field, self.planner)
+        plan.enqueue_to(self.columns, outs)
+        self.planner.sync()
+        plan.close()
+        return Matrix(outs)
+
+    def interpolate(self, domain):        # src/matrix.rs:155-163 (`self.clone().into_polynomials(domain)`)
+        return self._transformed(GpuIfft, domain)
 
     # src/matrix.rs:193-208 (into_evaluations_gpu): column.resize(domain.size(), 0) then fft
     def into_evaluations(self, domain, bit_reversed=False):
@@ -596,8 +610,25 @@ class Matrix:
         self.columns = outs
         return self
 
+    def _evaluated(self, domain, bit_reversed):
+        """evaluate / bit_reversed_evaluate: `self.clone().into_(bit_reversed_)evaluations(domain)`, never copying: columns shorter than
+        the domain go through ms_evaluate into new columns (their own storage is only read), columns of the domain's size through the
+        out-of-place transform."""
+        n = self.num_rows()
+        if n > domain.size:
+            raise ValueError("column longer than the evaluation domain")
+        if n == domain.size and not bit_reversed:
+            return self._transformed(GpuFft, domain)
+        L = self.planner.lib
+        outs = [GpuVec(self.planner, domain.size, self.field) for _ in self.columns]
+        off = _offset_words(self.field, domain.offset)
+        L.check(L.ms_evaluate(self.planner.handle, self.field, n.bit_length() - 1, domain.log_size, off.ctypes.data,
+                              _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
+        self.planner.sync()
+        return Matrix(outs)
+
     def evaluate(self, domain):           # src/matrix.rs:237-243
-        return self.clone().into_evaluations(domain)
+        return self._evaluated(domain, False)
 
     def bit_reverse_rows(self):           # src/matrix.rs:352-354
         L = self.planner.lib
@@ -623,7 +654,7 @@ class Matrix:
         return cls(outs)
 
     def bit_reversed_evaluate(self, domain):           # src/matrix.rs:245-251
-        return self.clone().into_bit_reversed_evaluations(domain)
+        return self._evaluated(domain, True)
 
     def get_rows(self, positions):
         """`Matrix::get_row` for every queried position (src/trace.rs:139-152): numpy u64 array

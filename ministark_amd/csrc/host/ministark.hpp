@@ -191,6 +191,7 @@ public:
         check(ms_ntt_encode(plan_, column.ptr()));
     }
     void execute() { check(ms_ntt_execute(plan_)); }   // plan.rs:229-232 (blocks)
+    ms_ntt_plan* plan() const { return plan_; }
 private:
     Planner* pl_; size_t n_; ms_ntt_plan* plan_ = nullptr;
 };
@@ -217,7 +218,17 @@ public:
         ifft.execute();
         return *this;
     }
-    Matrix interpolate(const Radix2EvaluationDomain& d) const { Matrix m = clone(); m.into_polynomials(d); return m; }
+    // `self.clone().into_polynomials(d)` (src/matrix.rs:155-163) without the device copy: the out-of-place transform (ms_ntt_enqueue_to)
+    Matrix interpolate(const Radix2EvaluationDomain& d) const {
+        Matrix out;
+        for (auto& c : columns) out.columns.emplace_back(planner(), c.len());
+        GpuIfft<F> ifft(planner(), d);
+        std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
+        auto o = out.ptrs();
+        check(ms_ntt_enqueue_to(ifft.plan(), in.data(), o.data(), (unsigned)in.size()));
+        planner().sync();
+        return out;
+    }
     Matrix& into_evaluations(const Radix2EvaluationDomain& d) {       // src/matrix.rs:193-208 (columns already of domain size)
         GpuFft<F> fft(planner(), d);
         for (auto& c : columns) fft.encode(c);

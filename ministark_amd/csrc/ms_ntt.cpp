@@ -895,6 +895,14 @@ extern "C" int ms_ntt_enqueue(ms_ntt_plan* plan, void* const* d_columns, unsigne
     std::lock_guard<std::mutex> lk(plan->ctx->mu);
     return plan_run(plan, (const void* const*)d_columns, d_columns, ncols, 256);
 }
+extern "C" int ms_ntt_enqueue_to(ms_ntt_plan* plan, const void* const* d_src, void* const* d_dst, unsigned ncols) {
+    if (!plan || ((!d_src || !d_dst) && ncols)) return fail(MS_ERR_INVALID, "ms_ntt_enqueue_to: null argument");
+    if (!user_plan_alive(plan)) return fail(MS_ERR_INVALID, "ms_ntt_enqueue_to: the plan's context has been destroyed");
+    for (unsigned c = 0; c < ncols; c++) if (!d_src[c] || !d_dst[c]) return fail(MS_ERR_INVALID, "ms_ntt_enqueue_to: null column %u", c);
+    if (ncols == 0) return MS_OK;
+    std::lock_guard<std::mutex> lk(plan->ctx->mu);
+    return plan_run(plan, d_src, d_dst, ncols, 256);
+}
 extern "C" int ms_ntt_execute(ms_ntt_plan* plan) {
     if (!plan) return fail(MS_ERR_INVALID, "ms_ntt_execute: null plan");
     if (!user_plan_alive(plan)) return fail(MS_ERR_INVALID, "ms_ntt_execute: the plan's context has been destroyed");

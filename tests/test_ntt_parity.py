@@ -629,3 +629,33 @@ def test_two_pass_2_18_handles_do_not_leak_hip():
     pl.sync()
     assert np.array_equal(got, want)
     assert before - free_bytes() < (8 << 20), f"device memory shrank by {before - free_bytes()} bytes over 300 handles"
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("field,log_n,inverse", [(GOLDILOCKS_FP, 8, False), (GOLDILOCKS_FP, 13, True), (GOLDILOCKS_FQ3, 12, True), (GOLDILOCKS_FP, 17, True),
+                                                   (GOLDILOCKS_FP, 18, False), (GOLDILOCKS_FQ3, 17, False), (GOLDILOCKS_FP, 20, True)])
+def test_out_of_place_transform_leaves_its_source_alone(kind, field, log_n, inverse):
+    """ms_ntt_enqueue_to (Matrix::interpolate / evaluate = `self.clone().into_...`, src/matrix.rs:155-163, 237-243, without the device copy):
+    dst = transform(src) equals the oracle, src keeps every word, and dst may be src (then it is the in-place transform).  Every plan kind:
+    one workgroup in LDS, two passes, three passes, the two-pass 2^18 forward plan, Fq3."""
+    pl = backends.planner(kind)
+    V = 3 if field == GOLDILOCKS_FQ3 else 1
+    n = 1 << log_n
+    dom = Radix2EvaluationDomain(n, 7)
+    cols = [_rand(n * V, 300 + c) for c in range(3)]
+    src = [GpuVec.from_numpy(pl, c, field) for c in cols]
+    dst = [GpuVec(pl, n, field) for _ in cols]
+    plan = (GpuIfft if inverse else GpuFft)(dom, field, pl)
+    plan.enqueue_to(src, dst)
+    pl.sync()
+    for c, s, d in zip(cols, src, dst):
+        assert np.array_equal(s.to_numpy(), c), "the source column must be preserved"
+        assert np.array_equal(d.to_numpy(), cref.ntt(c, log_n, V, inverse, 7))
+    plan.enqueue_to(src[:1], src[:1])                          # aliasing: the in-place transform
+    pl.sync()
+    assert np.array_equal(src[0].to_numpy(), cref.ntt(cols[0], log_n, V, inverse, 7))
+    plan.close()
+    m = Matrix.from_numpy(pl, cols[1:], field)
+    polys = m.interpolate(dom)                                  # the mirror's user of it
+    assert all(np.array_equal(k, c) for k, c in zip(m.to_numpy(), cols[1:]))
+    assert all(np.array_equal(g, cref.ntt(c, log_n, V, True, 7)) for g, c in zip(polys.to_numpy(), cols[1:]))
