@@ -190,6 +190,36 @@ def test_horner_three_levels_sparse(kind):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+def test_deep_rows_two_points_twenty_columns(kind):
+    """The prover's own shape -- Fq = Fp, every column opened at z and g z, ONE composition column (its point z^1 = z): two points --
+    against into_deep_poly + into_bit_reversed_evaluations, whole domain and a row shard; 20 columns per point: more than one 16-term
+    window of the limb accumulators.  (Round 6 tried walking the terms by COLUMN, one load per column for both points: HBM fetches halve,
+    2.23 -> 1.21 GB per 2^24 rows, and the kernel gets slower, 460 -> 490 us: one accumulator set per point costs the occupancy that hides its
+    loads.  Not shipped; this test is what checked it.)"""
+    from ministark_amd import Matrix
+    pl = backends.planner(kind)
+    n, blow = (4096, 2) if kind == "emu" else (1 << 14, 4)
+    rng = np.random.default_rng(99)
+    nbase = 20
+    base = [[int(x) for x in rng.integers(0, P, size=n, dtype=np.uint64)] for _ in range(nbase)]
+    comp = [[_rq(rng, False) for _ in range(n)]]
+    args = [(c, o) for c in range(nbase) for o in (0, 1)][:-1]          # the last column at one point only
+    z = _rq(rng, False)
+    bm, cm = _mat(pl, base, FP), _mat(pl, comp, FP)
+    composer = DeepPolyComposer(args, n, z, bm, None, cm)
+    composer.get_ood_evals()
+    co = DeepCompositionCoeffs([_rq(rng, False) for _ in args], [_rq(rng, False)], (_rq(rng, False), _rq(rng, False)))
+    N = n * blow
+    dom = Radix2EvaluationDomain(N, 7)
+    want = Matrix([composer.into_deep_poly(co)]).into_bit_reversed_evaluations(dom).columns[0].to_numpy()
+    bl, cl = bm.bit_reversed_evaluate(dom), cm.bit_reversed_evaluate(dom)
+    assert np.array_equal(composer.into_deep_evaluations(co, bl, None, cl, N).to_numpy(), want)
+    f, c = N // 2, N // 2                                                # the second half as a row shard
+    sl = lambda m: Matrix.from_numpy(pl, [col[f:f + c] for col in m.to_numpy()], m.field)
+    assert np.array_equal(composer.into_deep_evaluations(co, sl(bl), None, sl(cl), N, first=f).to_numpy(), want[f:f + c])
+
+
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("ext", [False, True])
 def test_deep_evaluations_on_the_committed_ldes(kind, ext):
     """ms_deep_rows: the DEEP composition polynomial's bit-reversed LDE computed pointwise from the rows of the committed LDEs equals
