@@ -52,8 +52,7 @@ extern "C" int ms_sha256_merkle(ms_ctx* ctx, size_t nleaves, const void* d_leave
     if (nleaves < 2 || (nleaves & (nleaves - 1))) return fail(MS_ERR_INVALID, "number of leaves must be a power of two >= 2");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    uint8_t* nodes = (uint8_t*)d_nodes;
-    HIPCHK(hipMemsetAsync(nodes, 0, 32, ctx->stream));
+    uint8_t* nodes = (uint8_t*)d_nodes;                       // (nodes[0] is cleared by the launch that writes the root: sha256_merkle_top)
     const uint8_t* src = (const uint8_t*)d_leaves;
     for (size_t count = nleaves / 2; count >= 1;) {
         uint8_t* dst = nodes + count * 32;

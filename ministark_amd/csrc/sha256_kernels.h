@@ -232,6 +232,9 @@ template <int PER>
 static __global__ void __launch_bounds__(NT) sha256_merkle_top(const uint8_t* __restrict__ src, uint8_t* __restrict__ nodes, unsigned count) {
     __shared__ uint32_t lvl[2][NT * 8];
     const unsigned t = threadIdx.x, b = blockIdx.x;
+    // the launch that ends in the root also clears the unused slot 0 of nodes[] (src/merkle.rs:145-147: n slots, the root in nodes[1]) -- a
+    // memset command of its own was one more launch latency per tree, eight trees per proof
+    if (count <= (unsigned)NT && b == 0 && t < 8) ((uint32_t*)nodes)[t] = 0;
     unsigned mine = count < (unsigned)NT ? count : (unsigned)NT;          // nodes of the current level this workgroup computes
     size_t level = count;                                                 // nodes of the current level in the whole tree
     Sha s;
