@@ -437,9 +437,11 @@ def bench_prove(pl, with_cpu, pmc=None):
     draws = pipeline.Draws(0xC5, ncols, nch, ce, 32, n_t * blowup, pipeline.fri_num_layers(n_t * blowup, blowup, folding, 64))
     res = {}
 
+    timed = [False]                                             # the wall clock is taken without the waits at the phase boundaries
+
     def run():
         res.clear()
-        res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, ce_blowup=ce))
+        res.update(pipeline.prove_phases(pl, trace, comp, draws, blowup, folding, 64, 8, ce_blowup=ce, time_phases=timed[0]))
     if pmc is not None:
         pmc("prove", run)
         res.clear()
@@ -447,7 +449,12 @@ def bench_prove(pl, with_cpu, pmc=None):
             c.free()
         return None
     phases = {}
-    wall, k = _profiled(pl, run, 5, after_wall=lambda: phases.update(res["phases_ms"]))      # phases of a run without events
+    def phases_of_one_run():                                    # with the waits, without events
+        timed[0] = True
+        run(); pl.sync()
+        phases.update(res["phases_ms"])
+        timed[0] = False
+    wall, k = _profiled(pl, run, 5, after_wall=phases_of_one_run)
     n_lde, n_ce = n_t * blowup, n_t * ce
     # algorithmic bytes per SURVEY.md 8(d): LDEs n s + beta n s per column, in-place transforms 2 n s, row hashing n cols s + 32 n,
     # trees 96 n, constraint evaluation sum of columns + result (on the n ce points of the constraint-evaluation domain), FRI

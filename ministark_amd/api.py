@@ -500,7 +500,10 @@ class _FftBase:
         self._keep = []
 
     def enqueue(self, columns):
-        """Non-blocking launch of a batch (no reference equivalent; used for timing)."""
+        """Non-blocking launch of a batch, in place: `encode` of every column + `execute` without the wait."""
+        for c in columns:
+            if len(c) != self.domain.size or c.field != self.field:
+                raise ValueError(f"column has {len(c)} elements of field {c.field}, the plan {self.domain.size} of field {self.field}")  # plan.rs:257 assert_eq!
         arr = _ptr_array(columns)
         self.planner.lib.check(self.planner.lib.ms_ntt_enqueue(self.handle, arr, len(columns)))
 
@@ -532,7 +535,13 @@ class GpuIfft(_FftBase):
 
 
 class Matrix:
-    """`Matrix<F>(Vec<GpuVec<F>>)` (src/matrix.rs:26): column-major, one GpuVec per column."""
+    """`Matrix<F>(Vec<GpuVec<F>>)` (src/matrix.rs:26): column-major, one GpuVec per column.
+
+    The transforms (`interpolate`, `evaluate`, `bit_reversed_evaluate`, `into_*`, `bit_reverse_rows`, `lde`) ENQUEUE on the planner's stream and
+    return: everything that consumes their result is ordered behind them on the same stream, and whatever brings bytes to the host
+    (`to_numpy`, `MerkleTree.root`, the gathers' fetch) waits.  The reference's methods block (`GpuFft::execute` waits for its command buffer,
+    gpu/src/plan.rs:378-386); a caller that wants that calls `planner.sync()` -- the prover does not: a wait after each of its eight transforms
+    was 25 us of idle device each (scripts/prove_gaps.py)."""
 
     def __init__(self, columns):
         self.columns = list(columns)
@@ -568,9 +577,7 @@ class Matrix:
     # src/matrix.rs:102-116 (into_polynomials_gpu) ------------------------------------
     def into_polynomials(self, domain):
         ifft = GpuIfft(domain, self.field, self.planner)
-        for c in self.columns:
-            ifft.encode(c)
-        ifft.execute()
+        ifft.enqueue(self.columns)                       # (encode + execute without the wait: see the class comment)
         ifft.close()
         return self
 
@@ -579,8 +586,7 @@ class Matrix:
         outs = [GpuVec(self.planner, len(c), self.field) for c in self.columns]
         plan = cls(domain, self.field, self.planner)
         plan.enqueue_to(self.columns, outs)
-        self.planner.sync()
-        plan.close()
+        plan.close()                                     # (a handle on the context's cached plan: closing it does not wait)
         return Matrix(outs)
 
     def interpolate(self, domain):        # src/matrix.rs:155-163 (`self.clone().into_polynomials(domain)`)
@@ -596,9 +602,7 @@ class Matrix:
             raise ValueError("column longer than the evaluation domain")
         if n == domain.size and not bit_reversed:
             fft = GpuFft(domain, self.field, self.planner)
-            for c in self.columns:
-                fft.encode(c)
-            fft.execute()
+            fft.enqueue(self.columns)
             fft.close()
             return self
         L = self.planner.lib
@@ -606,7 +610,6 @@ class Matrix:
         off = _offset_words(self.field, domain.offset)
         L.check(L.ms_evaluate(self.planner.handle, self.field, n.bit_length() - 1, domain.log_size, off.ctypes.data,
                               _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
-        self.planner.sync()
         self.columns = outs
         return self
 
@@ -624,7 +627,6 @@ class Matrix:
         off = _offset_words(self.field, domain.offset)
         L.check(L.ms_evaluate(self.planner.handle, self.field, n.bit_length() - 1, domain.log_size, off.ctypes.data,
                               _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
-        self.planner.sync()
         return Matrix(outs)
 
     def evaluate(self, domain):           # src/matrix.rs:237-243
@@ -635,7 +637,6 @@ class Matrix:
         n = self.num_rows()
         arr = _ptr_array(self.columns)
         L.check(L.ms_bit_reverse(self.planner.handle, self.field, n.bit_length() - 1, arr, len(self.columns)))
-        self.planner.sync()
         return self
 
     def into_bit_reversed_evaluations(self, domain):   # src/matrix.rs:225-234 (the bit reversal is fused into the last pass)
@@ -698,7 +699,6 @@ class Matrix:
         off = _offset_words(self.field, offset)
         L.check(L.ms_lde(self.planner.handle, self.field, log_n, log_b, off.ctypes.data,
                          _ptr_array(self.columns), _ptr_array(outs), len(outs), 1 if bit_reversed else 0))
-        self.planner.sync()
         return Matrix(outs)
 
 

@@ -57,6 +57,9 @@ class DeepCompositionCoeffs:                      # src/composer.rs:191-198
         self.execution_trace, self.composition_trace, self.degree = execution_trace, composition_trace, degree
 
 
+_HORNER_MAX_COLS = 96          # msdeep::MAXCOLS (csrc/deep_kernels.h): columns per ms_horner_eval call
+
+
 class DeepPolyComposer:
     """z and all coefficients are canonical Fq values: 3-tuples (Fq3) or ints (Fq = Fp AIRs, over Goldilocks
     or -- when the polynomial matrices are over it -- the 252-bit field).
@@ -99,29 +102,50 @@ class DeepPolyComposer:
         gen = self.g if offset >= 0 else self.g_inv
         return _q_mul_base(self.z, pow(gen, abs(offset), self.p), self.p)
 
-    def _horner(self, matrix, field, queries):
-        """queries: list of (column, point) -> list of Fq values."""
-        if not queries:
-            return []
-        if matrix.field != field:
-            raise ValueError("polynomial matrix is not over the expected field")
+    def _horner(self, parts):
+        """parts: list of (matrix, field, [(column, point), ...]) -> one list of Fq values per part.  Matrices over the same field with the same
+        number of rows share ONE launch and one download (an Fq = Fp AIR's trace and composition-trace polynomials: every call is a wait of the
+        host for the device and of the device for the host's next launch, ~75 us of an 8 ms proof)."""
         pl, L = self.planner, self.planner.lib
         pw = FIELD_WORDS[self.fq]
-        qcol = (ctypes.c_uint * len(queries))(*[c for c, _ in queries])
-        pts = np.array([w for _, p in queries for w in _words(p, self.fq)], dtype=np.uint64)
-        out = np.zeros(len(queries) * pw, dtype=np.uint64)
-        arr = (ctypes.c_void_p * matrix.num_cols())(*[c.ptr for c in matrix.columns])
-        L.check(L.ms_horner_eval(pl.handle, field, self.fq, matrix.num_rows(), arr, matrix.num_cols(), qcol, pts.ctypes.data,
-                                 len(queries), out.ctypes.data))
-        return [_from_words(out[pw * i:pw * i + pw]) for i in range(len(queries))]
+        results = [[] for _ in parts]
+        buckets = {}
+        for at, (matrix, field, queries) in enumerate(parts):
+            if not queries:
+                continue
+            if matrix.field != field:
+                raise ValueError("polynomial matrix is not over the expected field")
+            key, k = (field, matrix.num_rows()), 0
+            while sum(parts[m][0].num_cols() for m in buckets.get(key + (k,), [])) + matrix.num_cols() > _HORNER_MAX_COLS and buckets.get(key + (k,)):
+                k += 1                                           # a launch takes at most msdeep::MAXCOLS columns
+            buckets.setdefault(key + (k,), []).append(at)
+        for (field, nrows, _), members in buckets.items():
+            cols, qcol, qpts, spans = [], [], [], []
+            for at in members:
+                matrix, _, queries = parts[at]
+                first = len(cols)
+                cols += [c.ptr for c in matrix.columns]
+                spans.append((at, len(qcol), len(queries)))
+                qcol += [first + c for c, _ in queries]
+                qpts += [w for _, p in queries for w in _words(p, self.fq)]
+            pts = np.array(qpts, dtype=np.uint64)
+            out = np.zeros(len(qcol) * pw, dtype=np.uint64)
+            L.check(L.ms_horner_eval(pl.handle, field, self.fq, nrows, (ctypes.c_void_p * len(cols))(*cols), len(cols), (ctypes.c_uint * len(qcol))(*qcol),
+                                     pts.ctypes.data, len(qcol), out.ctypes.data))
+            for at, q0, nq in spans:
+                results[at] = [_from_words(out[pw * i:pw * i + pw]) for i in range(q0, q0 + nq)]
+        return results
 
     def get_ood_evals(self):                      # src/composer.rs:43-86
         base_q = [(c, self._point(o)) for c, o in self.args if c < self.nbase]
         ext_q = [(c - self.nbase, self._point(o)) for c, o in self.args if c >= self.nbase]
-        bv, ev = iter(self._horner(self.base, self.base_field, base_q)), iter(self._horner(self.ext, self.fq, ext_q) if ext_q else [])
-        execution = [next(bv) if c < self.nbase else next(ev) for c, _ in self.args]
         z_n = _q_pow(self.z, self.comp.num_cols(), self.p)
-        composition = self._horner(self.comp, self.fq, [(c, z_n) for c in range(self.comp.num_cols())])
+        parts = [(self.base, self.base_field, base_q)] + ([(self.ext, self.fq, ext_q)] if ext_q else []) + \
+                [(self.comp, self.fq, [(c, z_n) for c in range(self.comp.num_cols())])]
+        res = self._horner(parts)
+        bv, ev = iter(res[0]), iter(res[1] if ext_q else [])
+        execution = [next(bv) if c < self.nbase else next(ev) for c, _ in self.args]
+        composition = res[-1]
         self._ood = (execution, composition)
         return execution, composition
 
@@ -163,7 +187,6 @@ class DeepPolyComposer:
                       (VP * max(1, len(ext_list)))(*[c.ptr for c in ext_list]), len(ext_list),
                       pts.ctypes.data, len(points), (ctypes.c_uint * len(tcol))(*tcol), (ctypes.c_uint * len(tpoint))(*tpoint),
                       al.ctypes.data, od.ctypes.data, len(tcol), da.ctypes.data, db.ctypes.data, out.ptr))
-        pl.sync()
         return out
 
     def into_deep_poly(self, coeffs):             # src/composer.rs:89-188

@@ -191,6 +191,12 @@ public:
         check(ms_ntt_encode(plan_, column.ptr()));
     }
     void execute() { check(ms_ntt_execute(plan_)); }   // plan.rs:229-232 (blocks)
+    // encode of every column + execute WITHOUT the wait (the Matrix methods): in place, ordered on the planner's stream
+    void enqueue(const std::vector<GpuVec<F>>& cols) {
+        std::vector<void*> p;
+        for (auto& c : cols) { if (c.len() != n_) throw std::invalid_argument("column length differs from the domain size"); p.push_back(c.ptr()); }
+        check(ms_ntt_enqueue(plan_, p.data(), (unsigned)p.size()));
+    }
     ms_ntt_plan* plan() const { return plan_; }
 private:
     Planner* pl_; size_t n_; ms_ntt_plan* plan_ = nullptr;
@@ -200,6 +206,10 @@ template <class F> using GpuIfft = FftBase<F, 1>;
 
 class MerkleTree;
 
+// The transforms ENQUEUE on the planner's stream and return; whatever consumes their result is ordered behind them on the same stream, and
+// whatever brings bytes to the host (to_host, MerkleTree::root, a gather's fetch) waits.  The reference's block (GpuFft::execute waits for its
+// command buffer, gpu/src/plan.rs:378-386): a caller that wants that calls planner().sync() -- the prover does not (a wait after every
+// transform left the device idle until the host's next launch arrived).
 template <class F>
 class Matrix {
 public:
@@ -214,8 +224,7 @@ public:
     Matrix clone() const { Matrix m; for (auto& c : columns) m.columns.push_back(c.clone()); return m; }
     Matrix& into_polynomials(const Radix2EvaluationDomain& d) {       // src/matrix.rs:102-116
         GpuIfft<F> ifft(planner(), d);
-        for (auto& c : columns) ifft.encode(c);
-        ifft.execute();
+        ifft.enqueue(columns);                                         // encode + execute without the wait
         return *this;
     }
     // `self.clone().into_polynomials(d)` (src/matrix.rs:155-163) without the device copy: the out-of-place transform (ms_ntt_enqueue_to)
@@ -226,13 +235,11 @@ public:
         std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
         auto o = out.ptrs();
         check(ms_ntt_enqueue_to(ifft.plan(), in.data(), o.data(), (unsigned)in.size()));
-        planner().sync();
-        return out;
+        return out;                                                    // enqueued: consumers are ordered behind it on the stream (see the class comment)
     }
     Matrix& into_evaluations(const Radix2EvaluationDomain& d) {       // src/matrix.rs:193-208 (columns already of domain size)
         GpuFft<F> fft(planner(), d);
-        for (auto& c : columns) fft.encode(c);
-        fft.execute();
+        fft.enqueue(columns);
         return *this;
     }
     // evaluate / bit_reversed_evaluate (src/matrix.rs:237-251): columns shorter than the domain are coefficient
@@ -246,7 +253,6 @@ public:
         unsigned lg = 0; while (((size_t)1 << lg) < num_rows()) lg++;
         const uint64_t off = gl::to_mont(d.offset);
         check(ms_evaluate(planner().ctx(), F::id, lg, d.log_size, &off, in.data(), o.data(), (unsigned)in.size(), bit_reversed ? 1 : 0));
-        planner().sync();
         return out;
     }
     Matrix bit_reversed_evaluate(const Radix2EvaluationDomain& d) const { return evaluate(d, true); }
@@ -263,7 +269,6 @@ public:
         auto p = ptrs();
         unsigned lg = 0; while (((size_t)1 << lg) < num_rows()) lg++;
         check(ms_bit_reverse(planner().ctx(), F::id, lg, p.data(), (unsigned)p.size()));
-        planner().sync();
         return *this;
     }
     // interpolate(trace_domain) + bit_reversed_evaluate(lde_domain), src/prover.rs:50-51, fused
@@ -275,14 +280,12 @@ public:
         unsigned lg = 0; while (((size_t)1 << lg) < num_rows()) lg++;
         const uint64_t off = gl::to_mont(offset);
         check(ms_lde(planner().ctx(), F::id, lg, log_blowup, &off, in.data(), o.data(), (unsigned)in.size(), bit_reversed ? 1 : 0));
-        planner().sync();
         return out;
     }
     GpuVec<F> sum_columns() const {                                    // src/matrix.rs:357-394
         GpuVec<F> dst(planner(), num_rows());
         std::vector<const void*> in; for (auto& c : columns) in.push_back(c.ptr());
         check(ms_sum_columns(planner().ctx(), F::id, num_rows(), in.data(), (unsigned)in.size(), dst.ptr()));
-        planner().sync();
         return dst;
     }
     // Matrix::get_row for every queried position (src/trace.rs:139-152): row-major [positions][num_cols * words]

@@ -152,15 +152,43 @@ public:
     std::pair<std::vector<FqVal>, std::vector<FqVal>> get_ood_evals() {
         std::vector<unsigned> bq_col, eq_col; std::vector<FqVal> bq_pt, eq_pt;
         for (auto& a : args_) { if (a.first < nbase_) { bq_col.push_back(a.first); bq_pt.push_back(point(a.second)); } else { eq_col.push_back(a.first - nbase_); eq_pt.push_back(point(a.second)); } }
-        const auto bv = horner(base_, bq_col, bq_pt);
-        const auto ev = ext_ ? horner(*ext_, eq_col, eq_pt) : std::vector<FqVal>{};
-        size_t bi = 0, ei = 0;
-        std::vector<FqVal> execution;
-        for (auto& a : args_) execution.push_back(a.first < nbase_ ? bv[bi++] : ev[ei++]);
         const FqVal z_n = fq::pow(z_, comp_.num_cols());
         std::vector<unsigned> cc; std::vector<FqVal> cp;
         for (unsigned c = 0; c < comp_.num_cols(); c++) { cc.push_back(c); cp.push_back(z_n); }
-        ood_exec_ = execution; ood_comp_ = horner(comp_, cc, cp); have_ood_ = true;
+        // matrices over the same field with the same number of rows share ONE launch and one download (every call is a wait of the host for
+        // the device and of the device for the host's next launch): the composition-trace polynomials ride with the trace polynomials of
+        // their field -- the base trace's when Fq = Fp, the extension trace's otherwise
+        std::vector<FqVal> bv, ev, cv;
+        bool comp_done = false;
+        if constexpr (FqT::words == 1) {
+            if (comp_.num_rows() == base_.num_rows() && base_.num_cols() + comp_.num_cols() <= 96 && !bq_col.empty()) {
+                auto cols = ptrs_of(base_); for (auto& c : comp_.columns) cols.push_back(c.ptr());
+                auto qc = bq_col; auto qp = bq_pt;
+                for (unsigned c : cc) qc.push_back((unsigned)base_.num_cols() + c);
+                qp.insert(qp.end(), cp.begin(), cp.end());
+                const auto all = horner_cols<Fp>(base_.planner(), base_.num_rows(), cols, qc, qp);
+                bv.assign(all.begin(), all.begin() + bq_col.size()); cv.assign(all.begin() + bq_col.size(), all.end());
+                comp_done = true;
+            }
+        } else if (ext_ && comp_.num_rows() == ext_->num_rows() && ext_->num_cols() + comp_.num_cols() <= 96 && !eq_col.empty()) {
+            auto cols = ptrs_of(*ext_); for (auto& c : comp_.columns) cols.push_back(c.ptr());
+            auto qc = eq_col; auto qp = eq_pt;
+            for (unsigned c : cc) qc.push_back((unsigned)ext_->num_cols() + c);
+            qp.insert(qp.end(), cp.begin(), cp.end());
+            const auto all = horner_cols<FqT>(base_.planner(), ext_->num_rows(), cols, qc, qp);
+            ev.assign(all.begin(), all.begin() + eq_col.size()); cv.assign(all.begin() + eq_col.size(), all.end());
+            bv = horner(base_, bq_col, bq_pt);
+            comp_done = true;
+        }
+        if (!comp_done) {
+            bv = horner(base_, bq_col, bq_pt);
+            if (ext_) ev = horner(*ext_, eq_col, eq_pt);
+            cv = horner(comp_, cc, cp);
+        }
+        size_t bi = 0, ei = 0;
+        std::vector<FqVal> execution;
+        for (auto& a : args_) execution.push_back(a.first < nbase_ ? bv[bi++] : ev[ei++]);
+        ood_exec_ = execution; ood_comp_ = cv; have_ood_ = true;
         return {ood_exec_, ood_comp_};
     }
     GpuVec<FqT> into_deep_poly(const DeepCompositionCoeffs& coeffs) {           // src/composer.rs:89-188
@@ -209,20 +237,24 @@ private:
         t.npoints = (unsigned)points.size();
         GpuVec<FqT> out(pl, out_len);
         check(call(pl, t, out.ptr()));
-        pl.sync();
         return out;
     }
     FqVal point(int offset) const { return fq::mul_base(z_, gl::pow(offset >= 0 ? g_ : g_inv_, (uint64_t)(offset >= 0 ? offset : -offset))); }
+    template <class CF> static std::vector<const void*> ptrs_of(const Matrix<CF>& m) { std::vector<const void*> in; for (auto& c : m.columns) in.push_back(c.ptr()); return in; }
     template <class CF>
-    std::vector<FqVal> horner(const Matrix<CF>& m, const std::vector<unsigned>& qcol, const std::vector<FqVal>& qpt) {
+    static std::vector<FqVal> horner_cols(Planner& pl, size_t nrows, const std::vector<const void*>& in, const std::vector<unsigned>& qcol, const std::vector<FqVal>& qpt) {
         std::vector<FqVal> res;
         if (qcol.empty()) return res;
         std::vector<uint64_t> pts, out(qcol.size() * FqT::words);
         for (auto& p : qpt) fq::push_words<FqT>(pts, p);
-        std::vector<const void*> in; for (auto& c : m.columns) in.push_back(c.ptr());
-        check(ms_horner_eval(m.planner().ctx(), CF::id, FqT::id, m.num_rows(), in.data(), (unsigned)in.size(), qcol.data(), pts.data(), (unsigned)qcol.size(), out.data()));
+        check(ms_horner_eval(pl.ctx(), CF::id, FqT::id, nrows, in.data(), (unsigned)in.size(), qcol.data(), pts.data(), (unsigned)qcol.size(), out.data()));
         for (size_t k = 0; k < qcol.size(); k++) res.push_back(fq::from_words<FqT>(&out[k * FqT::words]));
         return res;
+    }
+    template <class CF>
+    std::vector<FqVal> horner(const Matrix<CF>& m, const std::vector<unsigned>& qcol, const std::vector<FqVal>& qpt) {
+        if (qcol.empty()) return {};
+        return horner_cols<CF>(m.planner(), m.num_rows(), ptrs_of(m), qcol, qpt);
     }
     std::vector<std::pair<unsigned, int>> args_;
     size_t n_; FqVal z_; const Matrix<Fp>& base_; const Matrix<FqT>* ext_; const Matrix<FqT>& comp_;
@@ -247,13 +279,11 @@ private:
 inline GpuVec<Fp> rpo256_rows_row_major(const GpuVec<Fp>& rows, unsigned ncols = 8) {      // GpuRpo256RowMajor: update(rows) + finish()
     GpuVec<Fp> digests(rows.planner(), rows.len() / ncols * 4);
     check(ms_rpo256_rows_row_major(rows.planner().ctx(), rows.len() / ncols, ncols, rows.ptr(), digests.ptr()));
-    rows.planner().sync();
     return digests;
 }
 inline GpuVec<Fp> gen_rpo_merkle_tree(const GpuVec<Fp>& leaves) {                          // nodes, [n][4] Fp
     GpuVec<Fp> nodes(leaves.planner(), leaves.len());
     check(ms_rpo256_merkle(leaves.planner().ctx(), leaves.len() / 4, leaves.ptr(), nodes.ptr()));
-    leaves.planner().sync();
     return nodes;
 }
 

@@ -178,27 +178,25 @@ extern "C" int ms_horner_eval(ms_ctx* ctx, int coeff_field, int point_field, siz
     for (unsigned l = 0; l < nlevels; l++) { level_blocks[l] = (unsigned)std::max<size_t>(1, (level_n[l] + 4095) >> 12); part_words += (size_t)nq * level_blocks[l] * 3; }
     const unsigned ngroups = (unsigned)(groups.size() / 2);
     if ((uint64_t)level_blocks[0] * ngroups > 0x7FFFFFFFull) return fail(MS_ERR_UNSUPPORTED, "too many (block, query group) pairs for one launch");
-    void *d_qcol = nullptr, *d_part = nullptr, *d_groups = nullptr, *d_singles = nullptr, *d_xlo = nullptr, *d_xhi = nullptr, *d_ypow = nullptr, *d_ylimb = nullptr;
+    // the seven host-built tables travel as ONE block and one copy command (each copy is a blit launch of its own on the stream: seven of
+    // them were 40 us in front of a 60 us kernel, twice per proof)
+    std::vector<char> image;
+    auto put = [&image](const void* src, size_t bytes) { const size_t at = (image.size() + 63) & ~(size_t)63; image.resize(at + bytes); if (bytes) memcpy(image.data() + at, src, bytes); return at; };
+    const size_t o_qcol = put(h_qcol, (size_t)nq * 4), o_groups = put(groups.data(), groups.size() * 4), o_singles = put(singles.data(), singles.size() * 4),
+                 o_xlo = put(xlo.data(), xlo.size() * 8), o_xhi = put(xhi.data(), xhi.size() * 8), o_ypow = put(ypow.data(), ypow.size() * 8),
+                 o_ylimb = put(ylimb.data(), ylimb.size() * 4);
+    void *d_tabs = nullptr, *d_part = nullptr;
     PoolGuard pooled(ctx);                                 // temporaries go back to the pool on every exit path
-    MSCHK(pooled.alloc((size_t)nq * 4, &d_qcol));
-    MSCHK(pooled.alloc(groups.size() * 4, &d_groups));
-    MSCHK(pooled.alloc(singles.size() * 4, &d_singles));
-    MSCHK(pooled.alloc(xlo.size() * 8, &d_xlo));
-    MSCHK(pooled.alloc(xhi.size() * 8, &d_xhi));
-    MSCHK(pooled.alloc(ypow.size() * 8, &d_ypow));
-    MSCHK(pooled.alloc(ylimb.size() * 4, &d_ylimb));
+    MSCHK(pooled.alloc(std::max<size_t>(image.size(), 64), &d_tabs));
     MSCHK(pooled.alloc(part_words * 8, &d_part));
+    const char* const tb = (const char*)d_tabs;
+    const void *d_qcol = tb + o_qcol, *d_groups = tb + o_groups, *d_singles = tb + o_singles, *d_xlo = tb + o_xlo, *d_xhi = tb + o_xhi, *d_ypow = tb + o_ypow,
+               *d_ylimb = tb + o_ylimb;
     std::vector<uint64_t> res((size_t)nq * 3);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIPCHK(hipSetDevice(ctx->device));
-        MSCHK(stage_upload(ctx, d_qcol, h_qcol, (size_t)nq * 4));
-        MSCHK(stage_upload(ctx, d_groups, groups.data(), groups.size() * 4));
-        MSCHK(stage_upload(ctx, d_singles, singles.data(), singles.size() * 4));
-        MSCHK(stage_upload(ctx, d_xlo, xlo.data(), xlo.size() * 8));
-        MSCHK(stage_upload(ctx, d_xhi, xhi.data(), xhi.size() * 8));
-        MSCHK(stage_upload(ctx, d_ypow, ypow.data(), ypow.size() * 8));
-        MSCHK(stage_upload(ctx, d_ylimb, ylimb.data(), ylimb.size() * 4));
+        MSCHK(stage_upload(ctx, d_tabs, image.data(), image.size()));
         uint64_t* part = (uint64_t*)d_part;
         const uint64_t* below = nullptr;
         for (unsigned l = 0; l < nlevels; l++) {

@@ -547,13 +547,19 @@ def prove_sharded(planner, comm, local_cols, total_cols, log_rows, comp_expr, dr
     args = list(draws.trace_args)
     helper = DeepPolyComposer.for_row_shards(args, n_t, draws.z, pl, total_cols, 0, ce_blowup, None)
     vals = np.zeros(len(args) + ce_blowup, dtype=np.uint64)
+    q = [(k, mine.index(c), helper._point(o)) for k, (c, o) in enumerate(args) if c in mine] if base_polys is not None else []
+    z_n = pow(draws.z, ce_blowup, (1 << 64) - (1 << 32) + 1)
+    parts = []                                                 # one launch and one download for the rank's trace and composition-trace polynomials
     if base_polys is not None:
-        q = [(k, mine.index(c), helper._point(o)) for k, (c, o) in enumerate(args) if c in mine]
-        for (k, _, _), v in zip(q, helper._horner(base_polys, GOLDILOCKS_FP, [(lc, p) for _, lc, p in q])):
+        parts.append((base_polys, GOLDILOCKS_FP, [(lc, p) for _, lc, p in q]))
+    if comp_polys is not None:
+        parts.append((comp_polys, GOLDILOCKS_FP, [(lc, z_n) for lc in range(len(comp_owned))]))
+    res = helper._horner(parts)
+    if base_polys is not None:
+        for (k, _, _), v in zip(q, res[0]):
             vals[k] = v
     if comp_polys is not None:
-        z_n = pow(draws.z, ce_blowup, (1 << 64) - (1 << 32) + 1)
-        for lc, v in enumerate(helper._horner(comp_polys, GOLDILOCKS_FP, [(lc, z_n) for lc in range(len(comp_owned))])):
+        for lc, v in enumerate(res[-1]):
             vals[len(args) + comp_owned[lc]] = v
     allv = _allgather_words(pl, comm, vals)
     execution = [int(allv[c % G][k]) for k, (c, _) in enumerate(args)]

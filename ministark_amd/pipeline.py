@@ -222,11 +222,12 @@ def _lowered(comp_expr, ncols):
 
 
 def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_remainder_coeffs=64, grinding_bits=8, hash="sha256",
-                 keep=False, ce_blowup=None):
+                 keep=False, ce_blowup=None, time_phases=True):
     """trace: Matrix of Fp columns (2^k rows).  ce_blowup: the AIR's ce_blowup_factor (src/air.rs:55-59; the constraint
     evaluation domain has trace_len * ce_blowup points, the composition trace ce_blowup columns); None = the LDE blow-up.
     Returns dict(roots=..., fri_roots=[...], remainder=GpuVec, nonce=int, queries=Queries, phases_ms={...}); with keep=True
-    also the intermediate device objects (for parity tests)."""
+    also the intermediate device objects (for parity tests).  time_phases=False: no device wait at the phase boundaries (two of the six
+    are waits the proof itself does not need: after the evaluation and after DEEP) and no `phases_ms`."""
     pl = planner
     n_t = trace.num_rows()
     n_lde = n_t * blowup
@@ -242,6 +243,8 @@ def prove_phases(planner, trace, comp_expr, draws, blowup=4, folding=8, max_rema
 
     def lap(name):
         nonlocal t
+        if not time_phases:
+            return
         pl.sync()
         now = time.perf_counter()
         phase[name] = (now - t) * 1e3
