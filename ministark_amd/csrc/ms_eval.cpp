@@ -10,6 +10,9 @@
 #include "eval_shift.h"
 #ifndef MS_NO_JIT
 #include "eval_jit.h"
+#elif defined(MS_EMU)
+#include "eval_jit_source.h"      // the execution-model simulator of tests/emu: the same generated source, compiled by g++ (tests/emu/emu_jit.h)
+#include "emu_jit.h"
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -244,6 +247,8 @@ static int eval_locked(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, con
         }
     }
     // specialised kernel for a program (compiled on first use), or nullptr -> interpreter
+    // (MS_EVAL_JIT_MIN_LOG_N: the tests send 256-point domains through the generated kernels; the default is 2^16 points)
+    static const unsigned jit_min_log_n = getenv("MS_EVAL_JIT_MIN_LOG_N") ? (unsigned)atoi(getenv("MS_EVAL_JIT_MIN_LOG_N")) : 16u;
     auto specialised = [&](const Instr* pr, unsigned cnt) -> hipFunction_t {
 #ifndef MS_NO_JIT
         static const bool off = getenv("MS_EVAL_JIT") && !strcmp(getenv("MS_EVAL_JIT"), "0");
@@ -284,6 +289,20 @@ static int eval_locked(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, con
             t->compile_ms += st.compile_ms; t->load_ms += st.load_ms;
         }
         ctx->jit_cache[key] = fn;
+        return fn;
+#elif defined(MS_EMU)
+        if (!emu_jit::enabled() || plain) return nullptr;
+        const std::string src = jit_source(pr, cnt, is252, maxp, maxq, lde_step);
+        if (const char* dump = getenv("MS_EVAL_DUMP")) { if (FILE* f = fopen(dump, "a")) { fputs(src.c_str(), f); fputs("\n// ----\n", f); fclose(f); } }
+        auto it = ctx->jit_cache.find(src);
+        if (it != ctx->jit_cache.end()) return it->second;
+        std::string log;
+        bool compiled = false;
+        hipFunction_t fn = emu_jit::obtain(src, log, &compiled);
+        if (!fn) { ctx->jit_stats.failures++; fprintf(stderr, "[ministark_hip simulator] specialised constraint kernel: %s\n", log.c_str()); }
+        else if (compiled) ctx->jit_stats.compiled++;
+        else ctx->jit_stats.from_disk++;
+        ctx->jit_cache[src] = fn;
         return fn;
 #else
         (void)pr; (void)cnt;
@@ -422,7 +441,7 @@ static int eval_locked(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, con
         EvalParams Q = E;
         Q.prog = (const Instr*)((char*)ctx->prog_buf + doff); Q.ninstr = den_n;
         if (den_n) {
-            hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(isplit.denom.data(), den_n) : nullptr;
+            hipFunction_t fn = log_n >= jit_min_log_n ? specialised(isplit.denom.data(), den_n) : nullptr;
             ProfScope ps(ctx, "eval_denominators", 0.0);
             launch(Q, fn);
         }
@@ -481,7 +500,7 @@ static int eval_locked(ms_ctx* ctx, const uint32_t* h_prog, unsigned ninstr, con
         }
     }
     {
-        hipFunction_t fn = n >= ((size_t)1 << 16) ? specialised(main_prog, main_n) : nullptr;   // small domains: the interpreter is quicker than a compilation
+        hipFunction_t fn = log_n >= jit_min_log_n ? specialised(main_prog, main_n) : nullptr;    // small domains: the interpreter is quicker than a compilation
         ProfScope ps(ctx, fn ? (is252 ? "eval_program252_jit" : "eval_program_jit") : (is252 ? "eval_program252" : "eval_program"),
                      is252 ? 32.0 * n * (nbase + 1) : 8.0 * n * (nbase + 3.0 * next + (out_field == MS_GOLDILOCKS_FQ3 ? 3 : 1)));
         launch(E, fn);

@@ -16,15 +16,15 @@ def build(force=False):
     sys.path.insert(0, ROOT)
     from ministark_amd.build import SOURCES                    # the same translation units as the product library
     srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "emu_runtime.cpp")]
-    deps = list(srcs) + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "ministark_hip.h")]
+    deps = list(srcs) + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "emu_jit.h"), os.path.join(ROOT, "include", "ministark_hip.h")]
     for d, _, files in os.walk(CSRC):
         deps += [os.path.join(d, f) for f in files]
     newest = max(os.path.getmtime(p) for p in deps)
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
-           "-Wno-unknown-pragmas", "-DMS_NO_JIT"] + srcs + ["-o", SO, "-ldl"]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + HERE, "-I" + CSRC, "-Wall", "-Wno-unused-function",
+           "-Wno-unknown-pragmas", "-DMS_NO_JIT", f'-DMS_EMU_DIR="{HERE}"', f'-DMS_CSRC_DIR="{CSRC}"'] + srcs + ["-o", SO, "-ldl"]
     subprocess.check_call(cmd)
     return SO
 

@@ -46,11 +46,12 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-// code-object API: the simulator build has no runtime compiler (MS_NO_JIT), these only have to exist
+// code-object API: the simulator build has no runtime compiler (MS_NO_JIT).  A hipFunction_t is the entry of a kernel that
+// tests/emu/emu_jit.h compiled with g++ from the generated source: void entry(void** kernelParams); hipModuleLaunchKernel is defined
+// below, after the launcher.
 typedef void* hipModule_t;
 typedef void* hipFunction_t;
 static inline hipError_t hipModuleUnload(hipModule_t) { return hipSuccess; }
-static inline hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t, void**, void**) { return hipErrorInvalidValue; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
@@ -96,6 +97,12 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
             }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+static inline hipError_t hipModuleLaunchKernel(hipFunction_t fn, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, unsigned, hipStream_t,
+                                               void** params, void**) {
+    if (!fn) return hipErrorInvalidValue;
+    emu_launch((void (*)(void**))fn, dim3(gx, gy, gz), dim3(bx, by, bz), params);
+    return hipSuccess;
+}
 
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
