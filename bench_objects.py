@@ -463,7 +463,8 @@ def bench_prove(pl, with_cpu, pmc=None):
            + ce * (n_t * 8 + n_lde * 8) + (n_lde * ce * 8 + 128 * n_lde) + (ncols + ce + 1) * n_t * 8 + (n_t * 8 + n_lde * 8)
            + sum((n_lde >> (3 * i)) * 8 * (1 + 1 / 8) + 128 * (n_lde >> (3 * i + 3)) for i in range(len(draws.fri_alphas))))
     kernel_ms = sum(k.values()) / 1e3
-    out = {"workload": "configs[4] on one GPU: 2^22 rows x 8 columns (Fp, Fq = Fp), the reference's fib AIR (examples/fib/main.rs:73-140: 17 constraints, ce_blowup_factor 1), ProofOptions::new(32, 4, 8, 8, 64): every data-parallel phase of default_prove, fixed challenges in place of the channel",
+    out = {"workload": "configs[4] on one GPU: 2^22 rows x 8 columns (Fp, Fq = Fp), the reference's fib AIR (examples/fib/main.rs:73-140: 17 constraints, ce_blowup_factor 1), ProofOptions::new(32, 4, 8, 8, 64): every data-parallel phase of default_prove, fixed challenges in place of the channel; prove_ms = median wall time of runs that wait only where the proof "
+                       "does (roots, out-of-domain values, the opened rows), phases_ms from one more run that also waits at every phase boundary",
            "prove_ms": round(wall * 1e3, 3), "kernel_ms": round(kernel_ms, 3), "phases_ms": phases, "kernel_us": k,
            "roofline": {"bound": "hbm (NTT / evaluation / FRI) + integer ALU (SHA-256)", "algorithmic_bytes": float(alg),
                         "achieved": round(alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

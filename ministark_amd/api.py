@@ -290,11 +290,16 @@ def merkle_view_ids(n, indices, lib=None):
 
 def _merkle_view_ids_arrays(n, indices, lib):
     """merkle_view_ids through the library, as numpy arrays (what the gathers take: no list round trip)"""
-    if not isinstance(indices, np.ndarray) or indices.dtype.kind != "u":          # validated as Python ints: a negative index is out of
-        for i in indices:                                                         # bounds, not an OverflowError of the conversion below
-            if not 0 <= int(i) < n:
-                raise IndexError(f"leaf index {int(i)} out of bounds ({n})")     # Error::LeafIndexOutOfBounds
-    idx = np.asarray(indices, dtype=np.uint64)
+    if isinstance(indices, np.ndarray) and indices.dtype.kind == "u":
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+    else:                                                                         # a negative index is out of bounds, not an OverflowError of a
+        try:                                                                      # conversion to unsigned: through int64 (one C loop, not a Python one)
+            signed = np.asarray(indices, dtype=np.int64)
+        except OverflowError:
+            raise IndexError(f"leaf index out of bounds ({n})") from None         # Error::LeafIndexOutOfBounds
+        if signed.size and int(signed.min()) < 0:
+            raise IndexError(f"leaf index {int(signed.min())} out of bounds ({n})")
+        idx = signed.astype(np.uint64)
     if idx.size and int(idx.max()) >= n:
         raise IndexError(f"leaf index {int(idx.max())} out of bounds ({n})")     # Error::LeafIndexOutOfBounds
     m = max(1, idx.size)
@@ -389,7 +394,7 @@ class MerkleTree:
     def prove_launch(self, indices, batch=None):
         """`prove` in two halves: the device gathers are launched now, the returned function fetches and assembles the view."""
         n = self.nleaves
-        leaf_ids, initial, sibling, node_ids = _merkle_view_ids_arrays(n, [int(i) for i in indices], self.planner.lib)
+        leaf_ids, initial, sibling, node_ids = _merkle_view_ids_arrays(n, indices, self.planner.lib)
         initial, sibling = initial.tolist(), sibling.tolist()
         fetch_leaves = _gather_digests_launch(self.planner, self.leaves, n, leaf_ids, batch)
         fetch_nodes = _gather_digests_launch(self.planner, self.nodes, n, node_ids, batch)

@@ -43,7 +43,15 @@ def case(name, comp, nch, log_n, lde_step, offset, field, fq_ext, base, ext, ch)
     kw = {"field": "f252"} if field == STARK252_FP else {}
     want = cref.eval_expr(comp, log_n, lde_step, offset, base, ext, ch, ch[:1], fq_ext, **kw)
     assert np.array_equal(out, want), f"{name}: {int((out != want).sum())} words differ from the oracle"
-    print(f"{name}: {got} generated kernel(s), {out.size} words equal the oracle's")
+    # other challenges, the same kernels: the generated source depends on the program, not on the values of its constants (a prover
+    # draws new challenges for every proof and must not meet the compiler again -- ADVICE r5 on csrc/ms_eval.cpp)
+    ch2 = (ch + np.uint64(12345)) % np.uint64(P) if field != STARK252_FP else ch + np.uint64(977)
+    out2 = E.eval(prog, pl, ch2, ch2[:1], lde_step, offset, n, [GpuVec.from_numpy(pl, c, field) for c in base],
+                  [GpuVec.from_numpy(pl, c, GOLDILOCKS_FQ3) for c in ext]).to_numpy()
+    again = pl.jit_stats()
+    assert (again["kernels_compiled"], again["kernels_from_disk"]) == (after["kernels_compiled"], after["kernels_from_disk"]), f"{name}: new challenges, new kernels ({after} -> {again})"
+    assert np.array_equal(out2, cref.eval_expr(comp, log_n, lde_step, offset, base, ext, ch2, ch2[:1], fq_ext, **kw)), f"{name}: second set of challenges"
+    print(f"{name}: {got} generated kernel(s), {out.size} words equal the oracle's, reused for a second set of challenges")
 
 log_n = 8
 n = 1 << log_n
