@@ -531,11 +531,17 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
     const size_t col_bytes = n * p->V * 8;
     if (p->small) {
         if (valid_rows != 256) return fail(MS_ERR_INVALID, "zero-extended input needs a domain of at least 4096 points");
-        for (unsigned c0 = 0; c0 < ncols; c0 += MAXC) {
-            unsigned nc = std::min<unsigned>(MAXC, ncols - c0);
+        constexpr unsigned PER_LAUNCH = 4096;                  // 64 KiB of pointers, read in place from the staging ring (stage_view)
+        for (unsigned c0 = 0; c0 < ncols; c0 += PER_LAUNCH) {
+            const unsigned nc = std::min<unsigned>(PER_LAUNCH, ncols - c0);
+            std::vector<const void*> tab(2 * (size_t)nc);
+            for (unsigned c = 0; c < nc; c++) { tab[2 * c] = src[c0 + c]; tab[2 * c + 1] = dst[c0 + c]; }
+            LockedPoolGuard pooled(ctx);
+            const void* d_tab = nullptr;
+            MSCHK(stage_view(ctx, tab.data(), tab.size() * sizeof(void*), &d_tab, pooled));
             msntt::SmallParams S;
             memset(&S, 0, sizeof S);
-            for (unsigned c = 0; c < nc; c++) { S.src[c] = (const uint64_t*)src[c0 + c]; S.dst[c] = (uint64_t*)dst[c0 + c]; }
+            S.cols = (const uint64_t* const*)d_tab;
             S.tw = p->d_tw; S.scale_in = p->d_scale_in; S.scale_out = p->d_scale_out; S.log_n = p->log_n; S.V = p->V;
             ProfScope ps(ctx, "ntt_small", 2.0 * col_bytes * nc);
             hipLaunchKernelGGL(msntt::ntt_small, dim3(1, nc), dim3(msntt::NT), 0, st, S);
@@ -549,6 +555,43 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
     // split of pass A's factor (T = 2) and its per-lane running product loses: 1.50 against 1.37 us -- stays on three passes.
     if (!p->inverse && p->V == 1 && valid_rows == 256 && !bitrev_out && p->log_n == 18 && p->d_wr4[0] != nullptr)
         return lde2_run(p->base ? p->base : p, p->log_n, 0, src, dst, ncols, true);   // the CACHED plan owns (and frees) the tables: a handle is a copy
+    // 2^12- and 2^13-point Fp columns (the (256, 16) / (256, 32) plans): both passes in ONE launch, the column stays in LDS in between, and one
+    // launch takes any number of columns (ntt_kernels.h ntt_fused_small; MS_NTT_FUSED_SMALL=0: the two launches, for before / after timings)
+    static const bool fused_off = getenv("MS_NTT_FUSED_SMALL") && !strcmp(getenv("MS_NTT_FUSED_SMALL"), "0");
+    static const unsigned fused_max = getenv("MS_NTT_FUSED_MAX_LOG") ? (unsigned)atoi(getenv("MS_NTT_FUSED_MAX_LOG")) : 14u;
+    if (!fused_off && p->V == 1 && p->log_n >= 12 && p->log_n <= std::min(14u, fused_max) && p->npass == 2 && p->lr[0] == 8 && p->lr[1] == p->log_n - 8 && valid_rows == 256 && !bitrev_out) {
+        constexpr unsigned PER_LAUNCH = 4096;                  // 64 KiB of pointers: an eighth of the staging ring's half (stage_view reads them in place)
+        for (unsigned c0 = 0; c0 < ncols; c0 += PER_LAUNCH) {
+            const unsigned nc = std::min<unsigned>(PER_LAUNCH, ncols - c0);
+            std::vector<const void*> tab(2 * (size_t)nc);
+            for (unsigned c = 0; c < nc; c++) { tab[2 * c] = src[c0 + c]; tab[2 * c + 1] = dst[c0 + c]; }
+            LockedPoolGuard pooled(ctx);
+            const void* d_tab = nullptr;
+            MSCHK(stage_view(ctx, tab.data(), tab.size() * sizeof(void*), &d_tab, pooled));
+            msntt::FusedParams P;
+            memset(&P, 0, sizeof P);
+            P.cols = (const uint64_t* const*)d_tab;
+            P.tw_lo = p->d_tw_lo; P.tw_hi = p->d_tw_hi; P.wr = p->d_wr[0]; P.wr2 = p->d_wr[1];
+            P.aux_lo = p->d_aux_lo; P.aux_hi = p->d_aux_hi; P.gtab = p->d_gtab;
+            P.log_n = p->log_n; P.lo_bits = p->lo_bits;
+            P.nfields = p->nfields[0];
+            for (unsigned f = 0; f < P.nfields; f++) P.fields[f] = p->fields[0][f];
+            P.scale_const = p->scale_const;
+            const dim3 grid(nc), block(msntt::NT << (p->log_n - 12));
+            ProfScope ps(ctx, "ntt_fused_small", 2.0 * col_bytes * nc);
+#define MS_FUSED(LOGN_) do { \
+            if (p->inverse) { \
+                if (p->scale_mode == 2) hipLaunchKernelGGL((msntt::ntt_fused_small<LOGN_, true, false, 2>), grid, block, 0, st, P); \
+                else if (p->scale_mode == 1) hipLaunchKernelGGL((msntt::ntt_fused_small<LOGN_, true, false, 1>), grid, block, 0, st, P); \
+                else hipLaunchKernelGGL((msntt::ntt_fused_small<LOGN_, true, false, 0>), grid, block, 0, st, P); \
+            } else if (p->coset) hipLaunchKernelGGL((msntt::ntt_fused_small<LOGN_, false, true, 0>), grid, block, 0, st, P); \
+            else hipLaunchKernelGGL((msntt::ntt_fused_small<LOGN_, false, false, 0>), grid, block, 0, st, P); } while (0)
+            if (p->log_n == 12) MS_FUSED(12); else if (p->log_n == 13) MS_FUSED(13); else MS_FUSED(14);
+#undef MS_FUSED
+        }
+        HIPCHK(hipGetLastError());
+        return MS_OK;
+    }
     unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(MAXC, ctx->group_bytes / col_bytes));
     group = std::min(group, ncols);
     // uniform-factor plans on Fp columns: pass 1 stores whole lines in a row order that permutes the words inside every run of

@@ -302,13 +302,174 @@ __global__ void __launch_bounds__(NT, BITREV ? 4 : SCALE == 2 ? 5 : MS_NTT_WAVES
     }
 }
 
+// ---- n = 4096 / 8192, Fp columns: the two passes of the (256, 16) / (256, 32) plan in ONE launch -----------------------------------------
+// A column is one tile of each pass (256 rows x 16 words, then 16 rows x 256 words): the workgroup that ran ntt_first_pass on it keeps the
+// result in LDS -- in the layout pass 1 stores, (j', k1) at 256 j' + k1 -- and runs ntt_mid_pass<1, .., LAST> on it from there.  The same
+// instruction sequence on the same values as the two launches (bit-identical), without the round trip through scratch and, what counts at
+// this size, without the second launch: a batch of 2^12-point columns is one wave of workgroups, its time is a workgroup's latency plus the
+// launch (2 x 21 us for 512 columns before, profiles/r06_c2_sweep_small.json).  The reference's own bench sizes are 2^11, 2^12, 2^15, 2^18
+// (gpu/benches/fft.rs:18).  SCALE as in ntt_mid_pass (1: n^-1, 2: n^-1 h^-k); P.wr / P.fields / P.log_s are pass 1's.
+// The column pointers come from a TABLE in memory (cols[2 c] = source, cols[2 c + 1] = destination of column c; the host's pinned staging ring,
+// read in place): one launch takes any number of columns -- with the pointers in the kernel arguments a launch ends at MAXC columns, and 256
+// workgroups are one per CU.
+struct FusedParams {
+    const uint64_t* const* cols;
+    const uint64_t* tw_lo; const uint64_t* tw_hi; const uint64_t* wr; const uint64_t* wr2; const uint64_t* aux_lo; const uint64_t* aux_hi; const uint64_t* gtab;   // wr: w_256^e (pass 1), wr2: w_R^e (pass 2)
+    unsigned log_n, lo_bits, nfields;
+    DigitField fields[3];
+    uint64_t scale_const;
+};
+__device__ __forceinline__ uint64_t tw_pow(const FusedParams& P, uint64_t e) {
+    uint64_t lo = P.tw_lo[e & ((1u << P.lo_bits) - 1)];
+    uint64_t hi_i = e >> P.lo_bits;
+    return hi_i ? gld::mmul(lo, P.tw_hi[hi_i]) : lo;
+}
+__device__ __forceinline__ uint64_t aux_pow(const FusedParams& P, uint64_t e) {
+    uint64_t lo = P.aux_lo[e & ((1u << P.lo_bits) - 1)];
+    uint64_t hi_i = e >> P.lo_bits;
+    return hi_i ? gld::mmul(lo, P.aux_hi[hi_i]) : lo;
+}
+__device__ __forceinline__ unsigned digit_rev(const FusedParams& P, unsigned x) {
+    unsigned r = 0;
+    for (unsigned f = 0; f < P.nfields; f++)
+        r |= ((x >> P.fields[f].in_shift) & P.fields[f].mask) << P.fields[f].out_shift;
+    return r;
+}
+// LOGN = 12: 256 threads, the (256, 16) plan.  LOGN = 13: 512 threads, the (256, 32) plan -- a column is TWO tiles of each pass (pass 1: words
+// 0..15 and 16..31 of every row; pass 2: low words 0..127 and 128..255) and each half of the workgroup runs the 256-thread code of
+// ntt_first_pass / ntt_mid_pass<2, .., LAST> on its tile.  Exchange buffers live inside `col` (pass 1's before the column is written, pass
+// 2's after it has been read into registers).
+template <int LOGN, bool INV, bool COSET, int SCALE>
+__global__ void __launch_bounds__(NT << (LOGN - 12), LOGN == 12 ? 5 : 4) ntt_fused_small(FusedParams P) {     // (2^14: one workgroup of sixteen waves per CU)
+    static_assert(LOGN >= 12 && LOGN <= 14, "one workgroup per column: 2^12 .. 2^14 points (128 KiB of LDS at 2^14)");
+    constexpr int H = 1 << (LOGN - 12), RB = H, ROW = 16 * H;                  // halves of the workgroup, pass 2's radix / 16, words per pass-1 row
+    __shared__ uint64_t col[TILE * H];
+    uint64_t y[16];
+    const uint64_t* __restrict__ src = P.cols[2 * (size_t)blockIdx.x];
+    uint64_t* __restrict__ dst = (uint64_t*)P.cols[2 * (size_t)blockIdx.x + 1];
+    const unsigned tid = threadIdx.x & (NT - 1), half = threadIdx.x >> 8;
+    uint64_t* const lds = col + (size_t)half * TILE;                           // this half's exchange buffer (2048 words in pass 1, 2304 in pass 2)
+    {   // pass 1, phase 1 (ntt_first_pass with row_words = ROW, w0 = 16 half): thread (t, b) owns rows j1 = 16 a + b, word w0 + t
+        const unsigned t = tid & 15, b = tid >> 4;
+        uint64_t x[16];
+        #pragma unroll
+        for (int a = 0; a < 16; a++) x[a] = src[(size_t)(16 * a + b) * ROW + 16 * half + t];
+        if constexpr (COSET) {
+            #pragma unroll
+            for (int a = 0; a < 16; a++) x[a] = gld::mmul(x[a], P.gtab[16 * a + b]);
+        }
+        gld::dft_lazy<16, INV>(x);
+        #pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = gld::mmul(x[c], P.wr[(b * c) & 255]);
+        const unsigned c2 = tid & 15, t2 = tid >> 4;
+        const unsigned A = (t * 128 + ((b & 7) << 4)) ^ (t | ((t & 1) << 4));
+        const unsigned Rb = (t2 * 128 + c2) ^ (t2 | ((t2 & 1) << 4));
+        const uint64_t* rd0 = lds + Rb;
+        const uint64_t* rd1 = lds + (Rb ^ 16);
+        if (b < 8) {
+            const unsigned A0 = gld::opaque(A);
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[A0 ^ c] = x[c];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int bb = 0; bb < 8; bb++) y[bb] = (bb & 1) ? rd1[(bb & ~1) << 4] : rd0[bb << 4];
+        __syncthreads();
+        if (b >= 8) {
+            const unsigned A1 = gld::opaque(A);
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[A1 ^ c] = x[c];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int bb = 0; bb < 8; bb++) y[8 + bb] = (bb & 1) ? rd1[(bb & ~1) << 4] : rd0[bb << 4];
+        __syncthreads();                                 // the exchange buffers become the column
+    }
+    {   // pass 1, phase 2: thread (c, t) owns b = 0..15 -> k1 = c + 16 d of word j' = 16 half + t, times (h w_n^k1)^j'
+        const unsigned tid2 = gld::opaque(tid);
+        const unsigned c = tid2 & 15, jp = 16 * half + (tid2 >> 4);
+        gld::dft_lazy<16, INV>(y);
+        const unsigned out_base = digit_rev(P, jp) << 8;
+        uint64_t A = tw_pow(P, (uint64_t)jp * c);
+        if constexpr (COSET) A = gld::mmul(A, aux_pow(P, jp));
+        const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
+        uint64_t tw = A;
+        #pragma unroll
+        for (int d = 0; d < 16; d++) {
+            col[out_base + c + 16 * d] = gld::mmul(y[d], tw);
+            if (d < 15) tw = gld::mmul(tw, B);
+        }
+    }
+    __syncthreads();
+    // pass 2 (ntt_mid_pass<RB, INV, true, SCALE> with sw = 256, tile `half` of H: low words lo0 = half T .. + T)
+    constexpr int R = 16 * RB, T = 256 / RB, G = 16 / RB;
+    const unsigned lo0 = half * T;
+    if constexpr (RB == 1) {
+        const unsigned t = gld::opaque(tid);
+        #pragma unroll
+        for (int a = 0; a < 16; a++) y[a] = col[a * 256 + t];
+        gld::dft_lazy<16, INV>(y);
+    } else {
+        const unsigned t = tid % T, b = tid / T;
+        uint64_t x[16];
+        #pragma unroll
+        for (int a = 0; a < 16; a++) x[a] = col[(size_t)(a * RB + b) * 256 + lo0 + t];
+        gld::dft_lazy<16, INV>(x);
+        #pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = gld::mmul(x[c], P.wr2[(b * c) & (R - 1)]);
+        __syncthreads();                                 // every word of the column is in registers: its memory is the exchange buffer now
+        const unsigned t2 = tid % T, cl = tid / T;
+        constexpr int HB = RB / 2;
+        if (tid < 128) {
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[c * LDS_PAD_CS + tid] = x[c];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int g = 0; g < G; g++) {
+            #pragma unroll
+            for (int bb = 0; bb < HB; bb++) y[g * RB + bb] = lds[(cl * G + g) * LDS_PAD_CS + bb * T + t2];
+        }
+        __syncthreads();
+        if (tid >= 128) {
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[c * LDS_PAD_CS + tid - 128] = x[c];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int g = 0; g < G; g++) {
+            #pragma unroll
+            for (int bb = 0; bb < HB; bb++) y[g * RB + HB + bb] = lds[(cl * G + g) * LDS_PAD_CS + bb * T + t2];
+        }
+        #pragma unroll
+        for (int g = 0; g < G; g++) gld::dft_lazy<RB, INV>(y + g * RB);
+    }
+    {   // outputs: thread (t, cl) holds k = c + 16 d, c = cl G + g, d = 0..RB-1 in y[g RB + d]
+        const unsigned tid3 = gld::opaque(tid);
+        const unsigned t = tid3 % T, cl = tid3 / T;
+        #pragma unroll
+        for (int g = 0; g < G; g++) {
+            #pragma unroll
+            for (int d = 0; d < RB; d++) {
+                const unsigned k = (cl * G + g) + 16 * d;
+                uint64_t val = y[g * RB + d];
+                const size_t pos = (size_t)k * 256 + lo0 + t;
+                if constexpr (SCALE == 1) val = gld::mmul(val, P.scale_const);
+                else if constexpr (SCALE == 2) val = gld::mmul(val, aux_pow(P, pos));
+                else val = gld::canon(val);
+                dst[pos] = val;
+            }
+        }
+    }
+}
+
 // ---- small transforms (n <= 2048): one workgroup per column, everything in LDS ----
 // scale_in[j]  (forward coset)  multiplies input j   (nullptr: none)
 // scale_out[k] (inverse)        multiplies output k  (nullptr: none)
 // tw[i] = w_n^i, i < n/2.
 struct SmallParams {
-    const uint64_t* src[MAXC];
-    uint64_t* dst[MAXC];
+    const uint64_t* const* cols;   // [2 c] = source, [2 c + 1] = destination of column c: a table in memory (the pinned staging ring), so that one
+                                   // launch takes any number of columns -- 256 workgroups, the most a by-value pointer array allows, are one per CU
     const uint64_t* tw;
     const uint64_t* scale_in;
     const uint64_t* scale_out;
@@ -318,8 +479,8 @@ struct SmallParams {
 static_assert(sizeof(SmallParams) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 static __global__ void __launch_bounds__(NT) ntt_small(SmallParams P) {
     __shared__ uint64_t lds[2048];
-    const uint64_t* __restrict__ src = P.src[blockIdx.y];
-    uint64_t* __restrict__ dst = P.dst[blockIdx.y];
+    const uint64_t* __restrict__ src = P.cols[2 * (size_t)blockIdx.y];
+    uint64_t* __restrict__ dst = (uint64_t*)P.cols[2 * (size_t)blockIdx.y + 1];
     const unsigned n = 1u << P.log_n, tid = threadIdx.x, V = P.V;
     for (unsigned v = 0; v < V; v++) {
         for (unsigned j = tid; j < n; j += NT) {

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ministark_amd import GOLDILOCKS_FP as FP, GpuFft, GpuVec, Planner, Radix2EvaluationDomain  # noqa: E402
+from ministark_amd import GOLDILOCKS_FP as FP, ColumnSet, GpuFft, GpuVec, Planner, Radix2EvaluationDomain  # noqa: E402
 
 P = (1 << 64) - (1 << 32) + 1
 pl = Planner(0)
@@ -18,14 +18,14 @@ rng = np.random.default_rng(1)
 out = {"group_bytes": os.environ.get("MS_NTT_GROUP_BYTES", "default"), "streams": os.environ.get("MS_NTT_STREAMS", "1")}
 SHAPES = ((17, 64), (18, 64), (19, 64), (20, 32), (21, 32), (22, 16), (23, 16), (24, 8)) if "--all" in sys.argv else ((20, 32), (22, 16), (24, 8))
 if "--small" in sys.argv:          # the two-pass sizes below the (256, R, 256) plans
-    SHAPES = ((12, 512), (13, 512), (14, 256), (15, 256), (16, 128))
+    SHAPES = ((10, 512), (11, 512), (12, 512), (13, 512), (14, 256), (15, 256), (16, 128))
 INVERSE = "--inverse" in sys.argv
 if INVERSE:
     from ministark_amd import GpuIfft as GpuFft  # noqa: E402,F811
     out["direction"] = "inverse"
 for log_n, ncol in SHAPES:
     n = 1 << log_n
-    cols = [GpuVec.from_numpy(pl, rng.integers(0, P, size=n, dtype=np.uint64), FP) for _ in range(ncol)]
+    cols = ColumnSet([GpuVec.from_numpy(pl, rng.integers(0, P, size=n, dtype=np.uint64), FP) for _ in range(ncol)])   # the pointer table built once: the clock sees launches, not list marshalling
     plan = GpuFft(Radix2EvaluationDomain(n, 7), FP, pl)
     t_end = time.perf_counter() + 0.4
     while time.perf_counter() < t_end:

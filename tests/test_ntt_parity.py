@@ -63,6 +63,51 @@ def test_multipass_variants_emu(log_n, inverse, offset):
     _run("emu", GOLDILOCKS_FP, log_n, inverse, offset)
 
 
+def _fused_small(kind, log_n):
+    """2^12- and 2^13-point Fp columns take ONE launch (ntt_fused_small: the column stays in LDS between the two passes, the column pointers come
+    from a table) -- forward and inverse, subgroup and coset, in place and out of place, more columns than the other kernels take per launch --
+    and the kernel that ran is that one; Fq3 columns of the same length keep the two launches.  Every word against the oracle."""
+    pl = backends.planner(kind)
+    n = 1 << log_n
+    for inverse, offset, ncols in ((False, 7, 3), (False, 1, 2), (True, 7, 2), (True, 1, 258 if log_n == 12 or kind == "hip" else 5)):
+        dom = Radix2EvaluationDomain(n, offset)
+        cols = [cref.random_elements(n, 900 + 7 * c + offset) for c in range(ncols)]
+        vecs = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FP) for c in cols]
+        outs = [GpuVec(pl, n, GOLDILOCKS_FP) for _ in cols]
+        plan = (GpuIfft if inverse else GpuFft)(dom, GOLDILOCKS_FP, pl)
+        pl.profile(True)
+        plan.enqueue_to(vecs, outs)                                # out of place: the sources stay
+        plan.enqueue(vecs)                                          # in place
+        names = set(pl.profile_read())
+        pl.profile(False)
+        plan.close()
+        assert names == {"ntt_fused_small"}, names
+        for c, v, o in zip(cols, vecs, outs):
+            want = cref.ntt(c, log_n, 1, inverse, offset)
+            assert np.array_equal(v.to_numpy(), want) and np.array_equal(o.to_numpy(), want), (inverse, offset)
+    q = cref.random_elements(3 * n, 77)
+    v = GpuVec.from_numpy(pl, q, GOLDILOCKS_FQ3)
+    plan = GpuFft(Radix2EvaluationDomain(n, 7), GOLDILOCKS_FQ3, pl)
+    pl.profile(True)
+    plan.enqueue([v])
+    names = set(pl.profile_read())
+    pl.profile(False)
+    plan.close()
+    assert "ntt_fused_small" not in names and names, names
+    assert np.array_equal(v.to_numpy(), cref.ntt(q, log_n, 3, False, 7))
+
+
+@pytest.mark.parametrize("log_n", [12, 13, 14])
+def test_fused_small_transform_emu(log_n):
+    _fused_small("emu", log_n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [12, 13, 14])
+def test_fused_small_transform_hip(log_n):
+    _fused_small("hip", log_n)
+
+
 # three-pass plans whose last radix is >= 64 (2^22 .. 2^24): pass 1's inter-pass factor comes from wave-uniform tables and
 # pass 2 applies the per-lane remainder on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
 @pytest.mark.parametrize("field,log_n,inverse,offset", [(GOLDILOCKS_FP, 22, False, 7), (GOLDILOCKS_FP, 22, True, 1),
