@@ -136,6 +136,7 @@ struct ms_ntt_plan {
     bool inverse = false, coset = false;
     // small path (log_n < 12)
     bool small = false;
+    bool tiny_fused = false;            // Fp, 2^9 .. 2^11 points: the tables of the (256, n / 256) plan are there too (ntt_fused_tiny)
     uint64_t *d_tw = nullptr, *d_scale_in = nullptr, *d_scale_out = nullptr;
     // multi-pass path
     int npass = 0;

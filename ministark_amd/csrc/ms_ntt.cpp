@@ -214,7 +214,13 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         powers(t, std::max<size_t>(n / 2, 1), w); off_tw = append(t);
         if (!p->inverse && p->coset) { powers(t, n, h); off_si = append(t); has_si = true; }
         if (p->inverse) { powers(t, n, hinv, ninv); off_so = append(t); has_so = true; }
-    } else {
+    }
+    // Fp columns of 2^11 points ALSO get the tables of the (256, 8) plan: their dense transforms run as ntt_fused_tiny (ntt_kernels.h),
+    // everything else of a small plan (Fq3 columns, zero-extended inputs) stays with ntt_small.  Measured, 512 columns, forward / inverse
+    // (profiles/r06_c2_sweep_small.json): 2^11 0.110 / 0.100 -> 0.121 / 0.121 of HBM and 29.4 -> 27.2 us for one column; at 2^10 and 2^9 the
+    // same kernel (rows of 4 and 2 words: three quarters and more of pass 1's lanes idle) LOSES, 0.086 -> 0.067 and 0.057 -> 0.035: not used there.
+    p->tiny_fused = log_n == 11 && V == 1;
+    if (log_n >= 12 || p->tiny_fused) {
         // radix decomposition: R1 = 256, the rest split as evenly as possible into radices 16..256
         const unsigned rest = log_n - 8;
         const int extra = (int)((rest + 7) / 8);
@@ -353,7 +359,8 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         p->d_tw = p->d_tables + off_tw;
         p->d_scale_in = has_si ? p->d_tables + off_si : nullptr;
         p->d_scale_out = has_so ? p->d_tables + off_so : nullptr;
-    } else {
+    }
+    if (!p->small || p->tiny_fused) {
         p->d_tw_lo = p->d_tables + off_lo; p->d_tw_hi = p->d_tables + off_hi;
         for (int q = 0; q < p->npass; q++) p->d_wr[q] = p->d_tables + off_wr[q];
         if (has_aux) { p->d_aux_lo = p->d_tables + off_alo; p->d_aux_hi = p->d_tables + off_ahi; }
@@ -529,6 +536,45 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
     HIPCHK(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << p->log_n;
     const size_t col_bytes = n * p->V * 8;
+    static const bool fused_off = getenv("MS_NTT_FUSED_SMALL") && !strcmp(getenv("MS_NTT_FUSED_SMALL"), "0");
+    // the tables every fused launch takes (ntt_fused_small / ntt_fused_tiny): the column pointers travel as a table in the staging ring
+    auto fused_params = [&](const void* d_tab) {
+        msntt::FusedParams F;
+        memset(&F, 0, sizeof F);
+        F.cols = (const uint64_t* const*)d_tab;
+        F.tw_lo = p->d_tw_lo; F.tw_hi = p->d_tw_hi; F.wr = p->d_wr[0]; F.wr2 = p->d_wr[1];
+        F.aux_lo = p->d_aux_lo; F.aux_hi = p->d_aux_hi; F.gtab = p->d_gtab;
+        F.log_n = p->log_n; F.lo_bits = p->lo_bits;
+        F.nfields = p->nfields[0];
+        for (unsigned f = 0; f < F.nfields; f++) F.fields[f] = p->fields[0][f];
+        F.scale_const = p->scale_const;
+        return F;
+    };
+    if (p->small && p->tiny_fused && !fused_off && valid_rows == 256 && !bitrev_out) {
+        constexpr unsigned PER_LAUNCH = 4096;
+        for (unsigned c0 = 0; c0 < ncols; c0 += PER_LAUNCH) {
+            const unsigned nc = std::min<unsigned>(PER_LAUNCH, ncols - c0);
+            std::vector<const void*> tab(2 * (size_t)nc);
+            for (unsigned c = 0; c < nc; c++) { tab[2 * c] = src[c0 + c]; tab[2 * c + 1] = dst[c0 + c]; }
+            LockedPoolGuard pooled(ctx);
+            const void* d_tab = nullptr;
+            MSCHK(stage_view(ctx, tab.data(), tab.size() * sizeof(void*), &d_tab, pooled));
+            const msntt::FusedParams P = fused_params(d_tab);
+            const dim3 grid(nc), block(msntt::NT);
+            ProfScope ps(ctx, "ntt_fused_tiny", 2.0 * col_bytes * nc);
+#define MS_TINY(LOGN_) do { \
+            if (p->inverse) { \
+                if (p->scale_mode == 2) hipLaunchKernelGGL((msntt::ntt_fused_tiny<LOGN_, true, false, 2>), grid, block, 0, st, P); \
+                else if (p->scale_mode == 1) hipLaunchKernelGGL((msntt::ntt_fused_tiny<LOGN_, true, false, 1>), grid, block, 0, st, P); \
+                else hipLaunchKernelGGL((msntt::ntt_fused_tiny<LOGN_, true, false, 0>), grid, block, 0, st, P); \
+            } else if (p->coset) hipLaunchKernelGGL((msntt::ntt_fused_tiny<LOGN_, false, true, 0>), grid, block, 0, st, P); \
+            else hipLaunchKernelGGL((msntt::ntt_fused_tiny<LOGN_, false, false, 0>), grid, block, 0, st, P); } while (0)
+            MS_TINY(11);
+#undef MS_TINY
+        }
+        HIPCHK(hipGetLastError());
+        return MS_OK;
+    }
     if (p->small) {
         if (valid_rows != 256) return fail(MS_ERR_INVALID, "zero-extended input needs a domain of at least 4096 points");
         constexpr unsigned PER_LAUNCH = 4096;                  // 64 KiB of pointers, read in place from the staging ring (stage_view)
@@ -557,7 +603,6 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
         return lde2_run(p->base ? p->base : p, p->log_n, 0, src, dst, ncols, true);   // the CACHED plan owns (and frees) the tables: a handle is a copy
     // 2^12- and 2^13-point Fp columns (the (256, 16) / (256, 32) plans): both passes in ONE launch, the column stays in LDS in between, and one
     // launch takes any number of columns (ntt_kernels.h ntt_fused_small; MS_NTT_FUSED_SMALL=0: the two launches, for before / after timings)
-    static const bool fused_off = getenv("MS_NTT_FUSED_SMALL") && !strcmp(getenv("MS_NTT_FUSED_SMALL"), "0");
     static const unsigned fused_max = getenv("MS_NTT_FUSED_MAX_LOG") ? (unsigned)atoi(getenv("MS_NTT_FUSED_MAX_LOG")) : 14u;
     if (!fused_off && p->V == 1 && p->log_n >= 12 && p->log_n <= std::min(14u, fused_max) && p->npass == 2 && p->lr[0] == 8 && p->lr[1] == p->log_n - 8 && valid_rows == 256 && !bitrev_out) {
         constexpr unsigned PER_LAUNCH = 4096;                  // 64 KiB of pointers: an eighth of the staging ring's half (stage_view reads them in place)
@@ -568,15 +613,7 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
             LockedPoolGuard pooled(ctx);
             const void* d_tab = nullptr;
             MSCHK(stage_view(ctx, tab.data(), tab.size() * sizeof(void*), &d_tab, pooled));
-            msntt::FusedParams P;
-            memset(&P, 0, sizeof P);
-            P.cols = (const uint64_t* const*)d_tab;
-            P.tw_lo = p->d_tw_lo; P.tw_hi = p->d_tw_hi; P.wr = p->d_wr[0]; P.wr2 = p->d_wr[1];
-            P.aux_lo = p->d_aux_lo; P.aux_hi = p->d_aux_hi; P.gtab = p->d_gtab;
-            P.log_n = p->log_n; P.lo_bits = p->lo_bits;
-            P.nfields = p->nfields[0];
-            for (unsigned f = 0; f < P.nfields; f++) P.fields[f] = p->fields[0][f];
-            P.scale_const = p->scale_const;
+            const msntt::FusedParams P = fused_params(d_tab);
             const dim3 grid(nc), block(msntt::NT << (p->log_n - 12));
             ProfScope ps(ctx, "ntt_fused_small", 2.0 * col_bytes * nc);
 #define MS_FUSED(LOGN_) do { \

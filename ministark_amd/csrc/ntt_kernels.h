@@ -463,6 +463,92 @@ __global__ void __launch_bounds__(NT << (LOGN - 12), LOGN == 12 ? 5 : 4) ntt_fus
     }
 }
 
+// ---- n = 2048, Fp columns: the (256, 8) plan in one launch (written for W = n / 256 = 2, 4, 8; only W = 8 is used: ms_ntt.cpp) -----------------
+// ntt_fused_small's scheme on a column whose pass-1 rows hold only W < 16 words: the lanes of words W..15 idle through pass 1 (a column is half a
+// tile or less), pass 2 is ONE radix-W network per thread over the W values of its k1 -- no inner twiddle, no exchange.  Replaces ntt_small's
+// log2(n) radix-2 stages with a barrier each (2^11 is one of the reference's own bench sizes, gpu/benches/fft.rs:18); ntt_small stays for
+// n <= 256, Fq3 columns and zero-extended inputs.
+template <int LOGN, bool INV, bool COSET, int SCALE>
+__global__ void __launch_bounds__(NT, 5) ntt_fused_tiny(FusedParams P) {
+    static_assert(LOGN >= 9 && LOGN <= 11, "256 rows of 2, 4 or 8 words");
+    constexpr int W = 1 << (LOGN - 8);
+    __shared__ uint64_t lds[TILE / 2];
+    __shared__ uint64_t col[256 * W];
+    uint64_t y[16];
+    const uint64_t* __restrict__ src = P.cols[2 * (size_t)blockIdx.x];
+    uint64_t* __restrict__ dst = (uint64_t*)P.cols[2 * (size_t)blockIdx.x + 1];
+    const unsigned tid = threadIdx.x;
+    {   // pass 1, phase 1: thread (t, b) owns rows j1 = 16 a + b, word t (t < W; the other lanes carry zeros)
+        const unsigned t = tid & 15, b = tid >> 4;
+        uint64_t x[16];
+        #pragma unroll
+        for (int a = 0; a < 16; a++) x[a] = t < (unsigned)W ? src[(size_t)(16 * a + b) * W + t] : 0;
+        if constexpr (COSET) {
+            #pragma unroll
+            for (int a = 0; a < 16; a++) x[a] = gld::mmul(x[a], P.gtab[16 * a + b]);
+        }
+        gld::dft_lazy<16, INV>(x);
+        #pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = gld::mmul(x[c], P.wr[(b * c) & 255]);
+        const unsigned c2 = tid & 15, t2 = tid >> 4;
+        const unsigned A = (t * 128 + ((b & 7) << 4)) ^ (t | ((t & 1) << 4));
+        const unsigned Rb = (t2 * 128 + c2) ^ (t2 | ((t2 & 1) << 4));
+        const uint64_t* rd0 = lds + Rb;
+        const uint64_t* rd1 = lds + (Rb ^ 16);
+        if (b < 8) {
+            const unsigned A0 = gld::opaque(A);
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[A0 ^ c] = x[c];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int bb = 0; bb < 8; bb++) y[bb] = (bb & 1) ? rd1[(bb & ~1) << 4] : rd0[bb << 4];
+        __syncthreads();
+        if (b >= 8) {
+            const unsigned A1 = gld::opaque(A);
+            #pragma unroll
+            for (int c = 0; c < 16; c++) lds[A1 ^ c] = x[c];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int bb = 0; bb < 8; bb++) y[8 + bb] = (bb & 1) ? rd1[(bb & ~1) << 4] : rd0[bb << 4];
+    }
+    {   // pass 1, phase 2: thread (c, j') owns b = 0..15 -> k1 = c + 16 d of word j', times (h w_n^k1)^j'
+        const unsigned tid2 = gld::opaque(tid);
+        const unsigned c = tid2 & 15, jp = tid2 >> 4;
+        if (jp < (unsigned)W) {                           // wave-uniform for W = 4 (one wave), a quarter / half of the lanes otherwise
+            gld::dft_lazy<16, INV>(y);
+            const unsigned out_base = digit_rev(P, jp) << 8;
+            uint64_t A = tw_pow(P, (uint64_t)jp * c);
+            if constexpr (COSET) A = gld::mmul(A, aux_pow(P, jp));
+            const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
+            uint64_t tw = A;
+            #pragma unroll
+            for (int d = 0; d < 16; d++) {
+                col[out_base + c + 16 * d] = gld::mmul(y[d], tw);
+                if (d < 15) tw = gld::mmul(tw, B);
+            }
+        }
+    }
+    __syncthreads();
+    {   // pass 2: thread k1 owns its W words j'; X[k1 + 256 k2] = sum_j' col[j'][k1] w_W^(j' k2)
+        const unsigned t = gld::opaque(tid);
+        uint64_t z[W];
+        #pragma unroll
+        for (int a = 0; a < W; a++) z[a] = col[a * 256 + t];
+        gld::dft_lazy<W, INV>(z);
+        #pragma unroll
+        for (int k = 0; k < W; k++) {
+            uint64_t val = z[k];
+            const size_t pos = (size_t)k * 256 + t;
+            if constexpr (SCALE == 1) val = gld::mmul(val, P.scale_const);
+            else if constexpr (SCALE == 2) val = gld::mmul(val, aux_pow(P, pos));
+            else val = gld::canon(val);
+            dst[pos] = val;
+        }
+    }
+}
+
 // ---- small transforms (n <= 2048): one workgroup per column, everything in LDS ----
 // scale_in[j]  (forward coset)  multiplies input j   (nullptr: none)
 // scale_out[k] (inverse)        multiplies output k  (nullptr: none)

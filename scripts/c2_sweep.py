@@ -18,7 +18,7 @@ rng = np.random.default_rng(1)
 out = {"group_bytes": os.environ.get("MS_NTT_GROUP_BYTES", "default"), "streams": os.environ.get("MS_NTT_STREAMS", "1")}
 SHAPES = ((17, 64), (18, 64), (19, 64), (20, 32), (21, 32), (22, 16), (23, 16), (24, 8)) if "--all" in sys.argv else ((20, 32), (22, 16), (24, 8))
 if "--small" in sys.argv:          # the two-pass sizes below the (256, R, 256) plans
-    SHAPES = ((10, 512), (11, 512), (12, 512), (13, 512), (14, 256), (15, 256), (16, 128))
+    SHAPES = ((9, 512), (10, 512), (11, 512), (12, 512), (13, 512), (14, 256), (15, 256), (16, 128))
 INVERSE = "--inverse" in sys.argv
 if INVERSE:
     from ministark_amd import GpuIfft as GpuFft  # noqa: E402,F811
