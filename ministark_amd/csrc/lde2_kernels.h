@@ -46,6 +46,12 @@ struct Params {
                                // pass B applies (G_j w_n^k1)^t, one value per lane and (wave, half), on its loads
     const uint64_t* c3;        // pass B, T >= 32: [t1][s0] w_T^(t1 s0), t1 < T / 16, s0 < 16, 4 plain copies (between radix 16 and radix T / 16)
     unsigned log_n, log_b, lo_bits;   // n = 2^log_n points per coset, beta = 2^log_b cosets
+    // INVERSE transform through the forward kernels (one coset, natural order; round 6): sum_j x_j w^(-j k) = sum_j x_((n - j) mod n) w^(j k), so
+    // pass A reads its column backwards (rev) and the forward tables of the offset-1 plan do the rest; the n^-1 h^-k of an inverse (coset)
+    // transform multiplies the natural-order output of pass B: oscale[k] (Montgomery, n words) or, on the subgroup, the constant oscale_c.
+    const uint64_t* oscale;
+    uint64_t oscale_c;
+    unsigned rev, oscale_mode;        // oscale_mode: 0 none, 1 the constant, 2 the table
 };
 static_assert(sizeof(Params) <= msntt::MAX_KERNARG_BYTES, "kernel-argument block (ntt_kernels.h: MAX_KERNARG_BYTES)");
 
@@ -112,8 +118,9 @@ __device__ __forceinline__ void net1(uint64_t* x, const Params& P, unsigned b, c
 // it reads the words 3 i + c of the coefficients (24-byte stride: each line is read by the three planes' workgroups back to back on
 // one XCD, as the cosets are) and writes plane c of the PLANAR scratch column (dst + c N): the same arithmetic, tables and twiddles as
 // for an Fp column, since all three words of an element share its index i.
-template <bool STREAM, bool UNI, int V = 1>
+template <bool STREAM, bool UNI, int V = 1, bool REV = false>      // REV: the column backwards (Params::rev), an inverse transform's pass A
 __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
+    static_assert(!REV || V == 1, "the backwards read is an Fp plan");
     __shared__ uint64_t xch[16 * 8 * TW];                    // 64 KiB: [b][a' - 8 round][lane]
     const uint64_t* __restrict__ src = P.src[blockIdx.z];
     // Which (tile, coset) this workgroup takes.  A tile of coefficients is read by all beta cosets; in plain grid order (tile fastest) the
@@ -142,6 +149,12 @@ __global__ void __launch_bounds__(NT, 4) lde2_strided_pass(Params P) {
     uint64_t x[2][16];
     #pragma unroll
     for (int h = 0; h < 2; h++) {                            // both halves requested before the first network
+        if constexpr (REV) {                                  // element (n - idx) mod n: the column backwards, index 0 stays
+            size_t idx = i0 + (size_t)(w + 8 * h) * L;
+            #pragma unroll
+            for (int a = 0; a < 16; a++) { x[h][a] = src[(n - idx) & (n - 1)]; idx += step; }
+            continue;
+        }
         const uint64_t* p = src + (i0 + (size_t)(w + 8 * h) * L) * V + plane;
         #pragma unroll
         for (int a = 0; a < 16; a++) { x[h][a] = *p; p += step * V; }
@@ -216,8 +229,9 @@ static constexpr int X2P = 65;                               // pitch of the sec
 // lane groups that are rows for an Fp column (rs = lane >> log T, 64 / T of them) become (row, word plane): rs = 4 row + plane, plane 3
 // idle -- 16 / T rows x 3 planes per workgroup, three quarters of the lanes at work -- so that the three words of every element a
 // workgroup produces meet in its LDS and leave as whole runs of 48 T consecutive words: no partial line is ever stored.
-template <bool STREAM, int T, bool UNI, bool NATURAL = false, int V = 1>
+template <bool STREAM, int T, bool UNI, bool NATURAL = false, int V = 1, int OSCALE = 0>     // OSCALE (NATURAL): 1 the constant, 2 the table of Params
 __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
+    static_assert(OSCALE == 0 || NATURAL, "the output scale of an inverse transform belongs to the natural-order stores");
     static_assert(!NATURAL || T <= 4, "natural-order stores: runs of 64 / T words, T = 2 or 4");
     static_assert(V == 1 || (V == 3 && T <= 16 && !NATURAL), "Fq3 columns: rows of at most 4096 elements, bit-reversed order");
     constexpr int LOGT = T == 64 ? 6 : T == 32 ? 5 : T == 16 ? 4 : T == 8 ? 3 : T == 4 ? 2 : T == 2 ? 1 : 0;
@@ -353,7 +367,11 @@ __global__ void __launch_bounds__(NT, 4) lde2_rows_pass(Params P) {
                 const unsigned rsel = idx % RSEL, e = idx / RSEL;
                 const unsigned tt = e & (T - 1), bq = (e >> LOGT) & 15, wq = e >> (LOGT + 4);
                 const size_t k0 = (size_t)(wq + 8 * r) + 16 * bq + 256 * (size_t)tt;
-                NTT2_ST(dst + ((size_t)(row0 + rsel) + 256 * k0), (uint64_t)xch[e * (RSEL + 1) + rsel], 2);
+                const size_t kout = (size_t)(row0 + rsel) + 256 * k0;
+                uint64_t val = xch[e * (RSEL + 1) + rsel];
+                if constexpr (OSCALE == 2) val = gld::mmul(val, P.oscale[kout]);       // an inverse transform's n^-1 h^-k
+                else if constexpr (OSCALE == 1) val = gld::mmul(val, P.oscale_c);
+                NTT2_ST(dst + kout, val, 2);
             }
         } else {
         // third trip: chunk (row, x = bitrev3(w'), c = bitrev4(b')) holds the T outputs in bit-reversed order of t'; the slot

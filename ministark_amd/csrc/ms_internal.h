@@ -162,6 +162,7 @@ struct ms_ntt_plan {
     // [gpl | aux | t2] in one allocation
     struct Lde2 { unsigned log_b = 0; uint64_t *d = nullptr, *gpl = nullptr, *aux = nullptr, *t2 = nullptr, *tin4 = nullptr, *tout4 = nullptr, *c3 = nullptr; };
     std::vector<Lde2> lde2;
+    uint64_t* d_oscale = nullptr;       // inverse plans of 2^18 points: n^-1 h^-k, k < n (Montgomery), for the two-pass route (built at first use)
     uint64_t offset_canon = 1;          // the coset offset h (canonical)
     std::vector<void*> queue;
     // Fp252 path (V == 4): plain radix-2 plan, see fp252_kernels.h

@@ -398,6 +398,7 @@ static int plan_free(ms_ntt_plan* plan) {
     (void)hipStreamSynchronize(plan->ctx->stream);
     if (plan->ctx->stream2) (void)hipStreamSynchronize(plan->ctx->stream2);
     if (plan->d_tables) (void)hipFree(plan->d_tables);
+    if (plan->d_oscale) (void)hipFree(plan->d_oscale);
     for (auto& l : plan->lde2) if (l.d) (void)hipFree(l.d);
     delete plan;
     return MS_OK;
@@ -524,7 +525,7 @@ static int plan_run252(ms_ntt_plan* p, const void* const* src, void* const* dst,
 
 // Transform `ncols` columns: src[c] -> dst[c] (may alias).  valid_rows < 256 means the
 // source only holds the first valid_rows/256 of the domain, the rest is implicit zeros.
-static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural, unsigned V = 1);
+static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural, unsigned V = 1, ms_ntt_plan* inv = nullptr);
 int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned ncols, unsigned valid_rows, bool bitrev_out) {
     if (p->is252) {
         if (valid_rows != 256 || bitrev_out) return fail(MS_ERR_INVALID, "internal: Fp252 zero extension / fused bit reversal go through plan_run252_tiled");
@@ -601,6 +602,29 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
     // split of pass A's factor (T = 2) and its per-lane running product loses: 1.50 against 1.37 us -- stays on three passes.
     if (!p->inverse && p->V == 1 && valid_rows == 256 && !bitrev_out && p->log_n == 18 && p->d_wr4[0] != nullptr)
         return lde2_run(p->base ? p->base : p, p->log_n, 0, src, dst, ncols, true);   // the CACHED plan owns (and frees) the tables: a handle is a copy
+    // ... and the INVERSE transforms of that size through the same two kernels (round 6): the column read backwards is the inverse's sum, the
+    // forward plan on the subgroup supplies every table, n^-1 h^-k multiplies pass B's natural-order output (lde2_kernels.h Params::rev).
+    // Measured, 64 columns: 2.65 -> 2.35 us per column (forward: 2.15); MS_NTT_INV18_TWO_PASS=0: the three passes.
+    static const bool inv18_off = getenv("MS_NTT_INV18_TWO_PASS") && !strcmp(getenv("MS_NTT_INV18_TWO_PASS"), "0");
+    if (p->inverse && !inv18_off && p->V == 1 && valid_rows == 256 && !bitrev_out && p->log_n == 18) {
+        ms_ntt_plan* owner = p->base ? p->base : p;
+        ms_ntt_plan* fwd1 = nullptr;
+        MSCHK(ctx_plan(ctx, 1, 18, false, 1, &fwd1));
+        if (fwd1->d_wr4[0] != nullptr) {
+            if (owner->coset && !owner->d_oscale) {               // n^-1 h^-k, k < n: built once per (cached) plan
+                const size_t n18 = (size_t)1 << 18;
+                std::vector<uint64_t> sc(n18);
+                const uint64_t hinv = gl::inv(owner->offset_canon);
+                uint64_t x = gl::inv((uint64_t)n18);
+                for (size_t k = 0; k < n18; k++) { sc[k] = gl::to_mont(x); x = gl::mul(x, hinv); }
+                uint64_t* d = nullptr;
+                if (hipMalloc(&d, n18 * 8) != hipSuccess) return fail(MS_ERR_NOMEM, "inverse scale table");
+                if (hipMemcpy(d, sc.data(), n18 * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return fail(MS_ERR_HIP, "inverse scale table upload"); }
+                owner->d_oscale = d;
+            }
+            return lde2_run(fwd1, 18, 0, src, dst, ncols, true, 1, owner);   // (the owner's d_oscale: a handle's copy of the plan may predate the table)
+        }
+    }
     // 2^12- and 2^13-point Fp columns (the (256, 16) / (256, 32) plans): both passes in ONE launch, the column stays in LDS in between, and one
     // launch takes any number of columns (ntt_kernels.h ntt_fused_small; MS_NTT_FUSED_SMALL=0: the two launches, for before / after timings)
     static const unsigned fused_max = getenv("MS_NTT_FUSED_MAX_LOG") ? (unsigned)atoi(getenv("MS_NTT_FUSED_MAX_LOG")) : 14u;
@@ -889,7 +913,7 @@ static int lde2_tables(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, ms_ntt_
 // coefficients (2^log_n words per column, src) -> bit-reversed evaluations on the coset of N points (dst, N words per column)
 // natural (log_b = 0, 2^17 / 2^18 points): the one coset's transform in natural order -- the forward NTT of the column in two passes
 // V = 3: Fq3 columns -- interleaved coefficients in, PLANAR scratch between the passes, interleaved evaluations out (lde2_kernels.h)
-static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural, unsigned V) {
+static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void* const* src, void* const* dst, unsigned ncols, bool natural, unsigned V, ms_ntt_plan* inv) {
     ms_ctx* ctx = fwd->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -907,6 +931,11 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
         mslde2::Params P;
         memset(&P, 0, sizeof P);
         P.wr4 = fwd->d_wr4[0]; P.gpl = tb->gpl; P.aux = tb->aux; P.t2 = tb->t2; P.tin4 = tb->tin4; P.tout4 = tb->tout4; P.c3 = tb->c3;
+        if (inv) {                                              // an inverse transform: the column backwards in, n^-1 h^-k on the way out
+            P.rev = 1;
+            if (inv->d_oscale) { P.oscale = inv->d_oscale; P.oscale_mode = 2; }
+            else { P.oscale_c = inv->scale_const; P.oscale_mode = 1; }
+        }
         const bool uni = tb->tin4 != nullptr;
         const bool stream_hint = 2 * (size_t)nc * col_bytes > ((size_t)256 << 20);       // as for the transforms above
         P.tw_lo = fwd->d_tw_lo; P.tw_hi = fwd->d_tw_hi; P.lo_bits = fwd->lo_bits; P.log_n = log_n; P.log_b = log_b;
@@ -918,6 +947,10 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
                 if (!uni) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, false, 3>), ga, dim3(msntt2::NT), 0, st, P);       // T = 2
                 else if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, true, 3>), ga, dim3(msntt2::NT), 0, st, P);
                 else hipLaunchKernelGGL((mslde2::lde2_strided_pass<false, true, 3>), ga, dim3(msntt2::NT), 0, st, P);
+            } else if (inv) {                                   // (2^18 points: the uniform split)
+                if (!uni) return fail(MS_ERR_INVALID, "internal: the backwards pass A is the 2^18-point plan's");
+                if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, true, 1, true>), ga, dim3(msntt2::NT), 0, st, P);
+                else hipLaunchKernelGGL((mslde2::lde2_strided_pass<false, true, 1, true>), ga, dim3(msntt2::NT), 0, st, P);
             } else
             if (stream_hint) { if (uni) hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, true>), ga, dim3(msntt2::NT), 0, st, P);
                                else hipLaunchKernelGGL((mslde2::lde2_strided_pass<true, false>), ga, dim3(msntt2::NT), 0, st, P); }
@@ -942,6 +975,13 @@ static int lde2_run(ms_ntt_plan* fwd, unsigned log_n, unsigned log_b, const void
             } else
             if (natural) {
                 if (T != 4) return fail(MS_ERR_INVALID, "internal: natural-order two-pass transform is the 2^18-point plan");
+                if (inv && P.oscale_mode == 2) {
+                    if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 4, true, true, 1, 2>), g, b, 0, st, P);
+                    else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 4, true, true, 1, 2>), g, b, 0, st, P);
+                } else if (inv) {
+                    if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 4, true, true, 1, 1>), g, b, 0, st, P);
+                    else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 4, true, true, 1, 1>), g, b, 0, st, P);
+                } else
                 if (stream_hint) hipLaunchKernelGGL((mslde2::lde2_rows_pass<true, 4, true, true>), g, b, 0, st, P);
                 else hipLaunchKernelGGL((mslde2::lde2_rows_pass<false, 4, true, true>), g, b, 0, st, P);
             } else

@@ -109,6 +109,41 @@ def test_fused_small_transform_hip(log_n):
     _fused_small("hip", log_n)
 
 
+def _inverse_2_18(kind):
+    """The inverse transforms of 2^18-point Fp columns run through the two FORWARD kernels of the two-pass plan (the column read backwards, the
+    forward tables of the subgroup, n^-1 h^-k on the natural-order output): coset and subgroup, in place and out of place, every word."""
+    pl = backends.planner(kind)
+    n = 1 << 18
+    for offset in (7, 1):
+        cols = [cref.random_elements(n, 31 + c + offset) for c in range(2)]
+        vecs = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FP) for c in cols]
+        outs = [GpuVec(pl, n, GOLDILOCKS_FP) for _ in cols]
+        plan = GpuIfft(Radix2EvaluationDomain(n, offset), GOLDILOCKS_FP, pl)
+        pl.profile(True)
+        plan.enqueue_to(vecs, outs)
+        plan.enqueue(vecs)
+        names = set(pl.profile_read())
+        pl.profile(False)
+        plan.close()
+        assert names == {"lde2_pass_a", "lde2_pass_b"}, names
+        for c, v, o in zip(cols, vecs, outs):
+            want = cref.ntt(c, 18, 1, True, offset)
+            assert np.array_equal(v.to_numpy(), want) and np.array_equal(o.to_numpy(), want), offset
+        back = GpuFft(Radix2EvaluationDomain(n, offset), GOLDILOCKS_FP, pl)          # and forward again: the column it started from
+        back.enqueue(vecs)
+        back.close()
+        assert all(np.array_equal(v.to_numpy(), c) for v, c in zip(vecs, cols))
+
+
+def test_inverse_2_18_two_pass_emu():
+    _inverse_2_18("emu")
+
+
+@pytest.mark.gpu
+def test_inverse_2_18_two_pass_hip():
+    _inverse_2_18("hip")
+
+
 # three-pass plans whose last radix is >= 64 (2^22 .. 2^24): pass 1's inter-pass factor comes from wave-uniform tables and
 # pass 2 applies the per-lane remainder on its loads (ntt2_first_pass<.., UNI>, ntt2_mid_pass<.., LOADQ>)
 @pytest.mark.parametrize("field,log_n,inverse,offset", [(GOLDILOCKS_FP, 22, False, 7), (GOLDILOCKS_FP, 22, True, 1),
