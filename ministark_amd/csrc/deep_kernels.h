@@ -217,8 +217,9 @@ struct DeepParams {
 // sorted by point so that a point's quotient factor multiplies the SUM of its terms:
 //     sum_t alpha_t (P_ct(x) - ood_t) / (x - z_pt)  =  sum_k 1/(x - z_k)  sum_{t: pt = k} alpha_t (P_ct(x) - ood_t)
 // -- nterms + npoints products per point instead of 2 nterms.  Exact field arithmetic: the same value.
-template <int PW, int PTS, int MP>       // MP: the most distinct points this instantiation serves (array sizes)
-__global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
+template <int PW, int PTS, int MP, int WAVES = 4>       // MP: the most distinct points this instantiation serves (array sizes); WAVES: waves per workgroup = denominators' pools per inversion
+__global__ void __launch_bounds__(64 * WAVES) deep_points(DeepParams P) {
+    constexpr int NT = 64 * WAVES;                  // (shadows the namespace's 256: the launch passes 64 WAVES threads)
     const size_t i0 = (size_t)blockIdx.x * (NT * PTS) + threadIdx.x;
     Q d[PTS][MP], pre[PTS][MP];
     uint64_t xv[PTS];
@@ -244,32 +245,30 @@ __global__ void __launch_bounds__(NT) deep_points(DeepParams P) {
     // The inversion (a Fermat power: ~73 dependent products for Fp, the largest single item of this kernel when it serves only the
     // PTS * npoints denominators of one lane) is pooled over the workgroup: lane l of ONE wave inverts the product of the four waves'
     // lane-l products and hands each its own inverse back (nine more products on that wave, two barriers) -- a quarter of the
-    // inversions.  The inverting wave rotates with the workgroup so that the serial chains spread over a CU's SIMDs.
-    static_assert(NT == 256, "the pooled inversion is written for four waves of 64 lanes (a[4], blockIdx.x & 3)");
+    // inversions (an eighth with WAVES = 8: the Fp launch of ms_deep_rows).  The inverting wave rotates with the workgroup so that the serial chains spread over a CU's SIMDs.
+    static_assert(WAVES == 4 || WAVES == 8, "the inverting wave is blockIdx.x & (WAVES - 1)");
     __shared__ uint64_t pool[NT * PW];
     {
         const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         #pragma unroll
         for (int w = 0; w < PW; w++) pool[(wv * PW + w) * 64 + lane] = run.w[w];
         __syncthreads();
-        if (wv == (blockIdx.x & 3)) {
-            Q a[4];
+        if (wv == (blockIdx.x & (WAVES - 1))) {
+            Q a[WAVES], pr[WAVES];                               // pr[v] = a0 .. av
             #pragma unroll
-            for (int v = 0; v < 4; v++) {
+            for (int v = 0; v < WAVES; v++) {
                 a[v] = q_zero<PW>();
                 #pragma unroll
                 for (int w = 0; w < PW; w++) a[v].w[w] = pool[(v * PW + w) * 64 + lane];
+                pr[v] = v ? q_mul<PW>(pr[v - 1], a[v]) : a[0];
             }
-            const Q p1 = q_mul<PW>(a[0], a[1]), p2 = q_mul<PW>(p1, a[2]);
-            Q t = q_inv<PW>(q_mul<PW>(p2, a[3]));
-            Q r[4];
-            r[3] = q_mul<PW>(t, p2); t = q_mul<PW>(t, a[3]);      // t = 1 / (a0 a1 a2)
-            r[2] = q_mul<PW>(t, p1); t = q_mul<PW>(t, a[2]);      // t = 1 / (a0 a1)
-            r[1] = q_mul<PW>(t, a[0]); r[0] = q_mul<PW>(t, a[1]);
+            Q t = q_inv<PW>(pr[WAVES - 1]);
             #pragma unroll
-            for (int v = 0; v < 4; v++) {
+            for (int v = WAVES - 1; v >= 0; v--) {
+                const Q r = v ? q_mul<PW>(t, pr[v - 1]) : t;     // 1 / a_v
+                if (v) t = q_mul<PW>(t, a[v]);                   // 1 / (a0 .. a(v-1))
                 #pragma unroll
-                for (int w = 0; w < PW; w++) pool[(v * PW + w) * 64 + lane] = r[v].w[w];
+                for (int w = 0; w < PW; w++) pool[(v * PW + w) * 64 + lane] = r.w[w];
             }
         }
         __syncthreads();

@@ -439,6 +439,8 @@ extern "C" int ms_deep_rows(ms_ctx* ctx, int point_field, unsigned log_domain, c
         if (PW == 1) {
             // two rows per lane: with the inversion pooled over the workgroup (deep_kernels.h) more rows per lane no longer pay for
             // themselves -- 2^24 rows x 9 columns: 466 us against 494 with four and 622 with one (scripts/deep_rows_probe.py)
+            // (the inversion pooled over EIGHT waves -- deep_points<1, 2, 3, 8>, 512 threads -- is slower: 536 against 463 us for the same rows; 76
+            // registers instead of 60 and a longer wait at the pool's barriers cost more than the halved inversions save.  Round 6, measured, not used.)
             if (npoints <= 3 && count >= 4096) hipLaunchKernelGGL((msdeep::deep_points<1, 2, 3>), blocks(2), dim3(msdeep::NT), 0, ctx->stream, D);
             else hipLaunchKernelGGL((msdeep::deep_points<1, 1, msdeep::MAXPOINTS>), blocks(1), dim3(msdeep::NT), 0, ctx->stream, D);
         } else {
