@@ -135,6 +135,28 @@ def _inverse_2_18(kind):
         assert all(np.array_equal(v.to_numpy(), c) for v, c in zip(vecs, cols))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [9, 11, 12])
+def test_more_columns_than_one_pointer_table_hip(log_n):
+    """5 000 short columns in ONE enqueue: the launches that read their column pointers from a table (ntt_small, ntt_fused_tiny, ntt_fused_small)
+    take 4 096 columns each -- the second launch starts where the first one ended.  Sampled columns against the oracle, the rest against them
+    (every column holds the same values, so every output must equal the sampled one)."""
+    pl = backends.planner("hip")
+    n, ncols = 1 << log_n, 5000
+    col = cref.random_elements(n, 4242 + log_n)
+    vecs = [GpuVec.from_numpy(pl, col, GOLDILOCKS_FP) for _ in range(ncols)]
+    plan = GpuFft(Radix2EvaluationDomain(n, 7), GOLDILOCKS_FP, pl)
+    plan.enqueue(vecs)
+    plan.close()
+    want = cref.ntt(col, log_n, 1, False, 7)
+    for c in (0, 1, 4095, 4096, 4097, ncols - 1):
+        assert np.array_equal(vecs[c].to_numpy(), want), c
+    for c in range(0, ncols, 97):                                  # a spread of the others
+        assert np.array_equal(vecs[c].to_numpy(), want), c
+    for v in vecs:
+        v.free()
+
+
 def test_inverse_2_18_two_pass_emu():
     _inverse_2_18("emu")
 
