@@ -157,6 +157,34 @@ def test_more_columns_than_one_pointer_table_hip(log_n):
         v.free()
 
 
+@pytest.mark.gpu
+def test_pointer_tables_survive_the_staging_ring_wrapping_hip():
+    """The pointer tables of the short-column launches live in the context's pinned staging ring (1 MiB), read in place by the kernels: 400
+    forward + inverse round trips over 600 columns of 2^12 points (9.4 KiB of table per launch) wrap the ring several times, with the launches
+    queued back to back.  A table overwritten while a queued launch still reads it would transform the wrong columns: every column must come
+    back as it started."""
+    pl = backends.planner("hip")
+    n, ncols = 1 << 12, 600
+    cols = [cref.random_elements(n, 9000 + c % 7) for c in range(ncols)]
+    vecs = [GpuVec.from_numpy(pl, c, GOLDILOCKS_FP) for c in cols]
+    dom = Radix2EvaluationDomain(n, 7)
+    fwd, inv = GpuFft(dom, GOLDILOCKS_FP, pl), GpuIfft(dom, GOLDILOCKS_FP, pl)
+    from ministark_amd import ColumnSet
+    cs = ColumnSet(vecs)
+    for _ in range(400):
+        fwd.enqueue(cs)
+        inv.enqueue(cs)
+    fwd.close(); inv.close()
+    for c in (0, 1, 255, 256, 511, 599):
+        assert np.array_equal(vecs[c].to_numpy(), cols[c]), c
+    fwd = GpuFft(dom, GOLDILOCKS_FP, pl)
+    fwd.enqueue(cs)
+    fwd.close()
+    assert np.array_equal(vecs[300].to_numpy(), cref.ntt(cols[300], 12, 1, False, 7))
+    for v in vecs:
+        v.free()
+
+
 def test_inverse_2_18_two_pass_emu():
     _inverse_2_18("emu")
 
