@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(NT, BITREV ? 4 : SCALE == 2 ? 5 : MS_NTT_WAVES
     }
 }
 
-// ---- n = 4096 / 8192, Fp columns: the two passes of the (256, 16) / (256, 32) plan in ONE launch -----------------------------------------
+// ---- n = 2^12 / 2^13 / 2^14, Fp columns: the two passes of the (256, 16) / (256, 32) / (256, 64) plan in ONE launch ---------------------
 // A column is one tile of each pass (256 rows x 16 words, then 16 rows x 256 words): the workgroup that ran ntt_first_pass on it keeps the
 // result in LDS -- in the layout pass 1 stores, (j', k1) at 256 j' + k1 -- and runs ntt_mid_pass<1, .., LAST> on it from there.  The same
 // instruction sequence on the same values as the two launches (bit-identical), without the round trip through scratch and, what counts at
@@ -335,9 +335,11 @@ __device__ __forceinline__ unsigned digit_rev(const FusedParams& P, unsigned x) 
         r |= ((x >> P.fields[f].in_shift) & P.fields[f].mask) << P.fields[f].out_shift;
     return r;
 }
-// LOGN = 12: 256 threads, the (256, 16) plan.  LOGN = 13: 512 threads, the (256, 32) plan -- a column is TWO tiles of each pass (pass 1: words
-// 0..15 and 16..31 of every row; pass 2: low words 0..127 and 128..255) and each half of the workgroup runs the 256-thread code of
-// ntt_first_pass / ntt_mid_pass<2, .., LAST> on its tile.  Exchange buffers live inside `col` (pass 1's before the column is written, pass
+// LOGN = 12: 256 threads, the (256, 16) plan.  LOGN = 13 (14): 512 (1024) threads, the (256, 32) ((256, 64)) plan -- a column is TWO (FOUR) tiles of
+// each pass (pass 1: words 0..15, 16..31, .. of every row; pass 2: low words 0..127 and 128..255 (four runs of 64)) and each 256-thread part
+// of the workgroup (`half` below) runs the 256-thread code of ntt_first_pass / ntt_mid_pass<2 (4), .., LAST> on its tile.  Measured, forward /
+// inverse, against the two launches: 2^12 x 512 columns 0.12 / 0.11 -> 0.21 / 0.21 of HBM, 2^13 x 512 0.15 / 0.13 -> 0.25 / 0.25, 2^14 x 256
+// 0.19 / 0.18 -> 0.235 / 0.225 (profiles/r06_c2_sweep_small.json).  Exchange buffers live inside `col` (pass 1's before the column is written, pass
 // 2's after it has been read into registers).
 template <int LOGN, bool INV, bool COSET, int SCALE>
 __global__ void __launch_bounds__(NT << (LOGN - 12), LOGN == 12 ? 5 : 4) ntt_fused_small(FusedParams P) {     // (2^14: one workgroup of sixteen waves per CU)
