@@ -215,10 +215,11 @@ static int plan_build(ms_ctx* ctx, unsigned V, unsigned log_n, bool inverse_b, u
         if (!p->inverse && p->coset) { powers(t, n, h); off_si = append(t); has_si = true; }
         if (p->inverse) { powers(t, n, hinv, ninv); off_so = append(t); has_so = true; }
     }
-    // Fp columns of 2^11 points ALSO get the tables of the (256, 8) plan: their dense transforms run as ntt_fused_tiny (ntt_kernels.h),
-    // everything else of a small plan (Fq3 columns, zero-extended inputs) stays with ntt_small.  Measured, 512 columns, forward / inverse
-    // (profiles/r06_c2_sweep_small.json): 2^11 0.110 / 0.100 -> 0.121 / 0.121 of HBM and 29.4 -> 27.2 us for one column; at 2^10 and 2^9 the
-    // same kernel (rows of 4 and 2 words: three quarters and more of pass 1's lanes idle) LOSES, 0.086 -> 0.067 and 0.057 -> 0.035: not used there.
+    // Fp columns of 2^11 points ALSO get the tables of the (256, 8) plan: their dense transforms run as ntt_fused_tiny (ntt_kernels.h: two columns
+    // per workgroup), everything else of a small plan (Fq3 columns, zero-extended inputs) stays with ntt_small.  Measured, 512 columns, forward /
+    // inverse (profiles/r06_c2_sweep_small.json): 2^11 0.103 / 0.101 -> 0.135 / 0.127 of HBM and 29.4 -> 27.3 us for one column.  At 2^10 and 2^9
+    // the same kernel (four and eight columns per workgroup) LOSES to ntt_small, 0.085 -> 0.072 and 0.055 -> 0.035: a batch of such columns is a
+    // handful of workgroups whose time is their own latency, and ntt_small's ten cheap stages are the shorter chain there.  Not used below 2^11.
     p->tiny_fused = log_n == 11 && V == 1;
     if (log_n >= 12 || p->tiny_fused) {
         // radix decomposition: R1 = 256, the rest split as evenly as possible into radices 16..256
@@ -560,8 +561,10 @@ int plan_run(ms_ntt_plan* p, const void* const* src, void* const* dst, unsigned 
             LockedPoolGuard pooled(ctx);
             const void* d_tab = nullptr;
             MSCHK(stage_view(ctx, tab.data(), tab.size() * sizeof(void*), &d_tab, pooled));
-            const msntt::FusedParams P = fused_params(d_tab);
-            const dim3 grid(nc), block(msntt::NT);
+            msntt::FusedParams P = fused_params(d_tab);
+            P.ncols = nc;
+            const unsigned pack = 16u >> (p->log_n - 8);          // columns per workgroup: 2 / 4 / 8 at 2^11 / 2^10 / 2^9 points
+            const dim3 grid((nc + pack - 1) / pack), block(msntt::NT);
             ProfScope ps(ctx, "ntt_fused_tiny", 2.0 * col_bytes * nc);
 #define MS_TINY(LOGN_) do { \
             if (p->inverse) { \

@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(NT, BITREV ? 4 : SCALE == 2 ? 5 : MS_NTT_WAVES
 struct FusedParams {
     const uint64_t* const* cols;
     const uint64_t* tw_lo; const uint64_t* tw_hi; const uint64_t* wr; const uint64_t* wr2; const uint64_t* aux_lo; const uint64_t* aux_hi; const uint64_t* gtab;   // wr: w_256^e (pass 1), wr2: w_R^e (pass 2)
-    unsigned log_n, lo_bits, nfields;
+    unsigned log_n, lo_bits, nfields, ncols;      // ncols: columns of this launch (ntt_fused_tiny packs several per workgroup)
     DigitField fields[3];
     uint64_t scale_const;
 };
@@ -465,26 +465,34 @@ __global__ void __launch_bounds__(NT << (LOGN - 12), LOGN == 12 ? 5 : 4) ntt_fus
     }
 }
 
-// ---- n = 2048, Fp columns: the (256, 8) plan in one launch (written for W = n / 256 = 2, 4, 8; only W = 8 is used: ms_ntt.cpp) -----------------
-// ntt_fused_small's scheme on a column whose pass-1 rows hold only W < 16 words: the lanes of words W..15 idle through pass 1 (a column is half a
-// tile or less), pass 2 is ONE radix-W network per thread over the W values of its k1 -- no inner twiddle, no exchange.  Replaces ntt_small's
-// log2(n) radix-2 stages with a barrier each (2^11 is one of the reference's own bench sizes, gpu/benches/fft.rs:18); ntt_small stays for
-// n <= 256, Fq3 columns and zero-extended inputs.
+// ---- n = 512 / 1024 / 2048, Fp columns: the (256, W) plan, W = n / 256 = 2 / 4 / 8, in one launch; 16 / W columns per workgroup -------------------
+// ntt_fused_small's scheme on columns whose pass-1 rows hold only W < 16 words: a workgroup takes PACK = 16 / W columns side by side -- the 16
+// "words" of a pass-1 tile row are the W words of column 0, then of column 1, ... (the arithmetic of a lane depends on its word j' = t mod W and
+// on nothing else of its column, so every lane works) -- and pass 2 is one radix-W network per thread and column over the W values of its k1:
+// no inner twiddle, no exchange.  Replaces ntt_small's log2(n) radix-2 stages with a barrier each (2^11 is one of the reference's own bench
+// sizes and its smallest transform, gpu/benches/fft.rs:18, gpu/src/plan.rs:248).  Dispatched for 2^11 only (ms_ntt.cpp: W = 2, 4 measured slower
+// than ntt_small, which also keeps Fq3 columns and zero-extended inputs).
 template <int LOGN, bool INV, bool COSET, int SCALE>
 __global__ void __launch_bounds__(NT, 5) ntt_fused_tiny(FusedParams P) {
     static_assert(LOGN >= 9 && LOGN <= 11, "256 rows of 2, 4 or 8 words");
-    constexpr int W = 1 << (LOGN - 8);
-    __shared__ uint64_t lds[TILE / 2];
-    __shared__ uint64_t col[256 * W];
+    constexpr int LOGW = LOGN - 8, W = 1 << LOGW, PACK = 16 / W;
+    __shared__ uint64_t col[TILE];                       // PACK columns of 256 W words; its first half doubles as pass 1's exchange buffer
+    uint64_t* const lds = col;
     uint64_t y[16];
-    const uint64_t* __restrict__ src = P.cols[2 * (size_t)blockIdx.x];
-    uint64_t* __restrict__ dst = (uint64_t*)P.cols[2 * (size_t)blockIdx.x + 1];
     const unsigned tid = threadIdx.x;
-    {   // pass 1, phase 1: thread (t, b) owns rows j1 = 16 a + b, word t (t < W; the other lanes carry zeros)
+    const unsigned c0 = blockIdx.x * PACK;                // this workgroup's first column
+    {   // pass 1, phase 1: thread (t, b) owns rows j1 = 16 a + b of word t mod W of column c0 + t / W
         const unsigned t = tid & 15, b = tid >> 4;
+        const unsigned c = c0 + (t >> LOGW);
         uint64_t x[16];
-        #pragma unroll
-        for (int a = 0; a < 16; a++) x[a] = t < (unsigned)W ? src[(size_t)(16 * a + b) * W + t] : 0;
+        if (c < P.ncols) {
+            const uint64_t* __restrict__ src = P.cols[2 * (size_t)c];
+            #pragma unroll
+            for (int a = 0; a < 16; a++) x[a] = src[(size_t)(16 * a + b) * W + (t & (W - 1))];
+        } else {
+            #pragma unroll
+            for (int a = 0; a < 16; a++) x[a] = 0;
+        }
         if constexpr (COSET) {
             #pragma unroll
             for (int a = 0; a < 16; a++) x[a] = gld::mmul(x[a], P.gtab[16 * a + b]);
@@ -514,39 +522,43 @@ __global__ void __launch_bounds__(NT, 5) ntt_fused_tiny(FusedParams P) {
         __syncthreads();
         #pragma unroll
         for (int bb = 0; bb < 8; bb++) y[8 + bb] = (bb & 1) ? rd1[(bb & ~1) << 4] : rd0[bb << 4];
+        __syncthreads();                                 // the exchange buffer becomes the columns
     }
-    {   // pass 1, phase 2: thread (c, j') owns b = 0..15 -> k1 = c + 16 d of word j', times (h w_n^k1)^j'
+    {   // pass 1, phase 2: thread (c, t) owns b = 0..15 -> k1 = c + 16 d of word j' = t mod W of column t / W, times (h w_n^k1)^j'
         const unsigned tid2 = gld::opaque(tid);
-        const unsigned c = tid2 & 15, jp = tid2 >> 4;
-        if (jp < (unsigned)W) {                           // wave-uniform for W = 4 (one wave), a quarter / half of the lanes otherwise
-            gld::dft_lazy<16, INV>(y);
-            const unsigned out_base = digit_rev(P, jp) << 8;
-            uint64_t A = tw_pow(P, (uint64_t)jp * c);
-            if constexpr (COSET) A = gld::mmul(A, aux_pow(P, jp));
-            const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
-            uint64_t tw = A;
-            #pragma unroll
-            for (int d = 0; d < 16; d++) {
-                col[out_base + c + 16 * d] = gld::mmul(y[d], tw);
-                if (d < 15) tw = gld::mmul(tw, B);
-            }
+        const unsigned c = tid2 & 15, t = tid2 >> 4, jp = t & (W - 1), sub = t >> LOGW;
+        gld::dft_lazy<16, INV>(y);
+        const unsigned out_base = sub * (256 * W) + (digit_rev(P, jp) << 8);
+        uint64_t A = tw_pow(P, (uint64_t)jp * c);
+        if constexpr (COSET) A = gld::mmul(A, aux_pow(P, jp));
+        const uint64_t B = tw_pow(P, (uint64_t)jp * 16);
+        uint64_t tw = A;
+        #pragma unroll
+        for (int d = 0; d < 16; d++) {
+            col[out_base + c + 16 * d] = gld::mmul(y[d], tw);
+            if (d < 15) tw = gld::mmul(tw, B);
         }
     }
     __syncthreads();
-    {   // pass 2: thread k1 owns its W words j'; X[k1 + 256 k2] = sum_j' col[j'][k1] w_W^(j' k2)
+    {   // pass 2: thread k1 owns the W words j' of every column; X[k1 + 256 k2] = sum_j' col[j'][k1] w_W^(j' k2)
         const unsigned t = gld::opaque(tid);
-        uint64_t z[W];
         #pragma unroll
-        for (int a = 0; a < W; a++) z[a] = col[a * 256 + t];
-        gld::dft_lazy<W, INV>(z);
-        #pragma unroll
-        for (int k = 0; k < W; k++) {
-            uint64_t val = z[k];
-            const size_t pos = (size_t)k * 256 + t;
-            if constexpr (SCALE == 1) val = gld::mmul(val, P.scale_const);
-            else if constexpr (SCALE == 2) val = gld::mmul(val, aux_pow(P, pos));
-            else val = gld::canon(val);
-            dst[pos] = val;
+        for (int sub = 0; sub < PACK; sub++) {
+            if (c0 + sub >= P.ncols) break;               // (wave-uniform)
+            uint64_t* __restrict__ dst = (uint64_t*)P.cols[2 * (size_t)(c0 + sub) + 1];
+            uint64_t z[W];
+            #pragma unroll
+            for (int a = 0; a < W; a++) z[a] = col[sub * (256 * W) + a * 256 + t];
+            gld::dft_lazy<W, INV>(z);
+            #pragma unroll
+            for (int k = 0; k < W; k++) {
+                uint64_t val = z[k];
+                const size_t pos = (size_t)k * 256 + t;
+                if constexpr (SCALE == 1) val = gld::mmul(val, P.scale_const);
+                else if constexpr (SCALE == 2) val = gld::mmul(val, aux_pow(P, pos));
+                else val = gld::canon(val);
+                dst[pos] = val;
+            }
         }
     }
 }
